@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Generate golden fixtures from the REAL reference (dev container only).
+
+Imports NCAR/miles-credit from /root/reference (read-only, via tools/oracle_stub.py),
+loads the build's synthetic name-keyed weights (wxengine.synth) with strict=True into
+`credit.models.crossformer.CrossFormer`, runs it on CPU fp32 and stores outputs as
+small .npz files under tests/golden/.  Only data (inputs are regenerated from the
+keyed RNG; outputs / strided samples / per-channel statistics) is written — no
+reference source.
+
+    python tools/make_goldens.py [--only T0,T1,C1,C3S,C3,pad,glue]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tools"), os.path.join(ROOT, "miles-credit_amd"), ROOT]
+
+import oracle_stub  # noqa: E402
+
+oracle_stub.install()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from wxengine.config import named_config  # noqa: E402
+from wxengine.synth import synth_denorm, synth_forcing, synth_input, synth_state_dict  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def reference_model(cfg, post_conf=None):
+    from credit.models.crossformer import CrossFormer
+    m = CrossFormer(
+        image_height=cfg.image_height, image_width=cfg.image_width, frames=cfg.frames, channels=cfg.channels,
+        surface_channels=cfg.surface_channels, input_only_channels=cfg.input_only_channels,
+        output_only_channels=cfg.output_only_channels, levels=cfg.levels, dim=cfg.dim, depth=cfg.depth,
+        dim_head=cfg.dim_head, global_window_size=cfg.global_window_size,
+        local_window_size=cfg.local_window_size[0], cross_embed_kernel_sizes=cfg.cross_embed_kernel_sizes,
+        cross_embed_strides=cfg.cross_embed_strides, use_spectral_norm=cfg.use_spectral_norm, interp=cfg.interp,
+        padding_conf={"activate": cfg.pad_activate, "mode": "earth", "pad_lat": list(cfg.pad_lat),
+                      "pad_lon": list(cfg.pad_lon)},
+        post_conf=post_conf or {"activate": False})
+    sd = synth_state_dict(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.eval()
+    return m
+
+
+def channel_stats(y):
+    """per-channel sum, sum of squares, max-abs of [1,C,1,H,W]."""
+    a = y[0, :, 0].double()
+    return (a.sum(dim=(1, 2)).numpy(), (a * a).sum(dim=(1, 2)).numpy(), a.abs().amax(dim=(1, 2)).numpy())
+
+
+def model_golden(name, stride, capture_layers):
+    cfg = named_config(name)
+    torch.manual_seed(0)
+    m = reference_model(cfg)
+    x = torch.from_numpy(synth_input(cfg))
+    caps = {}
+    hooks = []
+    if capture_layers:
+        want = {f"layers.{s}.0" for s in range(4)} | {f"layers.{s}.1" for s in range(4)}
+        want |= {"up_block1", "up_block2", "up_block3", "up_block4"}
+        for n, mod in m.named_modules():
+            if n in want:
+                hooks.append(mod.register_forward_hook(
+                    lambda _m, _i, o, n=n: caps.__setitem__(n, o.detach().clone())))
+    t = time.time()
+    with torch.no_grad():
+        y = m(x)
+    dt = time.time() - t
+    for h in hooks:
+        h.remove()
+    out = {}
+    s1, s2, mx = channel_stats(y)
+    out["ch_sum"], out["ch_sumsq"], out["ch_maxabs"] = s1, s2, mx
+    out["stride"] = np.int64(stride)
+    out["y"] = y[0, :, 0, ::stride, ::stride].numpy().astype(np.float32)
+    for n, v in caps.items():
+        out["cap/" + n] = v[0].numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, f"model_{name}.npz"), **out)
+    print(f"[golden] {name}: forward {dt:.2f}s  mean|y|={y.abs().mean():.4f} max|y|={y.abs().max():.4f}  "
+          f"y sample {out['y'].shape}")
+
+
+def pad_golden():
+    """credit/boundary_padding.py earth mode, incl. asymmetric pads (tests/test_bondary_padding.py:37-44 shapes)."""
+    from credit.boundary_padding import TensorPadding
+    out = {}
+    g = np.random.Generator(np.random.Philox(key=[7, 7]))
+    small = torch.from_numpy(g.standard_normal((1, 2, 1, 7, 10), dtype=np.float32))
+    tp = TensorPadding(mode="earth", pad_lat=[3, 2], pad_lon=[4, 3])
+    out["small_x"] = small.numpy()
+    out["small_pad"] = tp.pad(small).numpy()
+    big = torch.from_numpy(g.standard_normal((1, 3, 1, 181, 360), dtype=np.float32))
+    tp2 = TensorPadding(mode="earth", pad_lat=[12, 34], pad_lon=[56, 78])
+    pb = tp2.pad(big)
+    assert torch.equal(tp2.unpad(pb), big)
+    out["big_seed"] = np.array([7, 7])
+    out["big_pad_strided"] = pb[0, :, 0, ::7, ::11].numpy()
+    out["big_pad_sum"] = pb.double().sum(dim=(0, 2, 3, 4)).numpy()
+    out["big_pad_shape"] = np.array(pb.shape)
+    np.savez_compressed(os.path.join(GOLD, "earth_pad.npz"), **out)
+    print("[golden] earth_pad:", tuple(pb.shape))
+
+
+def glue_conf(cfg, n_static=2, n_dyn=2):
+    """Minimal data config understood by build_channel_layout (single source)."""
+    n_diag = cfg.output_only_channels
+    return {
+        "data": {"source": {"ERA5": {
+            "levels": list(range(cfg.levels)),
+            "variables": {
+                "prognostic": {"vars_3D": [f"p3_{i}" for i in range(cfg.channels)],
+                               "vars_2D": [f"p2_{i}" for i in range(cfg.surface_channels)]},
+                "static": {"vars_2D": [f"s_{i}" for i in range(n_static)]},
+                "dynamic_forcing": {"vars_2D": [f"f_{i}" for i in range(n_dyn)]},
+                "diagnostic": {"vars_2D": [f"d_{i}" for i in range(n_diag)]},
+            }}}},
+        "model": {"levels": cfg.levels},
+    }
+
+
+def glue_golden():
+    """3-step rollout on T0 through the reference's own pieces: model forward, TracerFixer
+    (credit/postblock/gen1.py:111, denorm False so no scaler files are needed), y*std+mean
+    (rollout_to_netcdf.py:287) and update_x (channel_utils.py:253)."""
+    from credit.datasets.gen_2.channel_utils import build_channel_layout, update_x
+    from credit.postblock.gen1 import TracerFixer
+    cfg = named_config("T0")
+    m = reference_model(cfg)
+    conf = glue_conf(cfg)
+    groups, n_pred = build_channel_layout(conf)
+    assert n_pred == cfg.channels * cfg.levels + cfg.surface_channels
+    q_inds = list(range(3 * cfg.levels, 4 * cfg.levels))  # 4th 3-D variable = the tracer
+    thres = [-0.05] * len(q_inds)  # normalised-space threshold that actually clamps
+    fixer = TracerFixer({"tracer_fixer": {"tracer_inds": q_inds, "tracer_thres": thres, "denorm": False}})
+    mean, std = synth_denorm(cfg.base_output_channels)
+    mean_t = torch.from_numpy(mean).view(1, -1, 1, 1, 1)
+    std_t = torch.from_numpy(std).view(1, -1, 1, 1, 1)
+    x = torch.from_numpy(synth_input(cfg))
+    out = {"tracer_inds": np.array(q_inds), "tracer_thres": np.array(thres, dtype=np.float32),
+           "n_static": np.int64(2), "n_dyn": np.int64(2)}
+    with torch.no_grad():
+        for step in range(1, 4):
+            y = m(x)
+            n_clamped = int((y[:, q_inds] < thres[0]).sum())
+            y = fixer({"y_pred": y, "x": x})["y_pred"]
+            y_phys = (y * std_t + mean_t).squeeze(2)
+            out[f"y{step}"] = y[0, :, 0].numpy().astype(np.float32)
+            out[f"yphys{step}"] = y_phys[0].numpy().astype(np.float32)
+            frc = torch.from_numpy(synth_forcing(cfg, 2, step))
+            x = update_x(x, frc, y.detach(), groups)
+            out[f"x{step}"] = x[0, :, 0].numpy().astype(np.float32)
+            print(f"[golden] glue step {step}: clamped {n_clamped} tracer cells, mean|y|={y.abs().mean():.4f}")
+    np.savez_compressed(os.path.join(GOLD, "rollout_T0.npz"), **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="pad,T0,T1,glue,C1,C3S,C3")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 1)
+    for item in args.only.split(","):
+        if item == "pad":
+            pad_golden()
+        elif item == "glue":
+            glue_golden()
+        elif item in ("T0", "T1"):
+            model_golden(item, 1, capture_layers=(item == "T0"))
+        elif item == "C1":
+            model_golden(item, 8, False)
+        elif item in ("C3S", "C3"):
+            model_golden(item, 16, False)
+        else:
+            raise SystemExit(f"unknown item {item}")
+
+
+if __name__ == "__main__":
+    main()
