@@ -1,0 +1,144 @@
+/*
+ * wxengine — C ABI of the MI355X-native CrossFormer/WXFormer rollout engine.
+ *
+ * This is the drop-in boundary for ONE hot path of NCAR/miles-credit: one
+ * autoregressive forecast step of `model.type: crossformer`
+ * (credit/models/crossformer.py:593-644 CrossFormer.forward, driven by
+ *  credit/applications/rollout_to_netcdf.py:274-310).  Plain pointers and sizes
+ * only; no torch types.  All `*_dev` pointers are device (HBM) pointers on the
+ * GPU the handle was created for; `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).  Every function returns 0 on success and a
+ * negative wx_status otherwise; wx_last_error() gives the message (thread-local).
+ *
+ * The reference is pure Python, so "the reference's FFI for this path" is the
+ * model-registry call surface; each entry point cites the
+ * reference interface it stands in for.  The ctypes binding a maintainer would add
+ * is shown in INTEGRATION.md and implemented in miles-credit_amd/wxengine/engine.py.
+ */
+#ifndef WXENGINE_H
+#define WXENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WX_ABI_VERSION 1
+
+typedef struct wx_engine* wx_handle;
+
+enum wx_status {
+  WX_OK = 0,
+  WX_ERR_INVALID = -1,     /* bad argument / unsupported configuration (reference: ValueError) */
+  WX_ERR_STATE = -2,       /* call order violated, e.g. forward before finalize (RuntimeError) */
+  WX_ERR_HIP = -3,         /* a HIP runtime call failed */
+  WX_ERR_MISSING = -4,     /* a required state-dict tensor was never loaded */
+  WX_ERR_SHAPE = -5        /* tensor shape does not match the configuration */
+};
+
+enum wx_precision {
+  WX_PREC_FP32 = 0,        /* f32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32) */
+  WX_PREC_BF16 = 1         /* bf16 storage + bf16 MFMA, fp32 accumulate / LN / softmax / GN */
+};
+
+/* The YAML `model:` mapping of the reference constructor
+ * (credit/models/crossformer.py:372-401), flattened. */
+typedef struct wx_config {
+  int32_t abi_version;              /* must be WX_ABI_VERSION */
+  int32_t image_height, image_width;
+  int32_t frames, output_frames;
+  int32_t channels, surface_channels, input_only_channels, output_only_channels, levels;
+  int32_t dim[4], depth[4], dim_head;
+  int32_t global_window_size[4], local_window_size[4];
+  int32_t n_embed_kernels[4];       /* branches per stage (<= 4) */
+  int32_t embed_kernels[4][4];      /* cross_embed_kernel_sizes */
+  int32_t embed_strides[4];         /* cross_embed_strides */
+  int32_t pad_activate;             /* padding_conf.activate (mode "earth" only) */
+  int32_t pad_lat[2], pad_lon[2];
+  int32_t interp;                   /* bilinear resize to (image_height, image_width) */
+  int32_t use_spectral_norm;
+  int32_t precision;                /* enum wx_precision */
+  int32_t max_batch;                /* largest B accepted by wx_forward (>= 1) */
+} wx_config;
+
+/* ---- lifecycle -----------------------------------------------------------
+ * wx_create      <-> CrossFormer.__init__ via load_model(conf)          (credit/models/__init__.py:301-387)
+ * wx_load_tensor <-> nn.Module.load_state_dict(strict=False) per key    (credit/models/base_model.py:57-87)
+ * wx_finalize_weights: folds spectral norm (eval-mode W = weight_orig / (u.(W v)),
+ *                crossformer.py:23-26), LayerNorm affine into the following 1x1 conv,
+ *                evaluates every DynamicPositionBias MLP once (crossformer.py:279-286),
+ *                and repacks weights into the MFMA operand layout in HBM.
+ * wx_destroy     <-> del model
+ */
+int wx_create(const wx_config* cfg, int device, wx_handle* out);
+int wx_load_tensor(wx_handle h, const char* state_dict_key, const float* host_data, int ndim,
+                   const int64_t* shape);
+int wx_finalize_weights(wx_handle h);
+int wx_destroy(wx_handle h);
+
+/* Number of state-dict tensors the configuration expects, and the i-th key/shape
+ * (so a host can enumerate what to feed to wx_load_tensor). */
+int wx_num_tensors(wx_handle h);
+int wx_tensor_info(wx_handle h, int index, const char** key, int* ndim, int64_t shape[8]);
+
+/* ---- step glue configuration ---------------------------------------------
+ * wx_set_denorm       <-> _build_output_denorm (rollout_to_netcdf.py:103-157): per-output-channel mean/std (host ptrs)
+ * wx_set_tracer_fixer <-> PostBlock/TracerFixer (credit/postblock/gen1.py:111-167): clamp y[:, i] < thres -> thres
+ *                         (thres_max may be NULL); denorm != 0 clamps in physical units using the wx_set_denorm stats
+ * wx_set_layout       <-> build_channel_layout (credit/datasets/gen_2/channel_utils.py:161-250), single source:
+ *                         x = [n_prog prognostic | n_static | n_dyn dynamic forcing]
+ */
+int wx_set_denorm(wx_handle h, const float* mean, const float* std, int n_out);
+int wx_set_tracer_fixer(wx_handle h, const int32_t* inds, const float* thres, const float* thres_max, int n,
+                        int denorm);
+int wx_set_layout(wx_handle h, int n_prog, int n_static, int n_dyn);
+
+/* ---- the hot path ---------------------------------------------------------
+ * wx_forward <-> y = model(x) under eval()/no_grad() (rollout_to_netcdf.py:275):
+ *     x_dev  float32 [B, C_in, frames, H, W]  (not modified)
+ *     y_dev  float32 [B, C_out, output_frames, H, W]   (tracer fixer applied when configured)
+ * wx_step    <-> one iteration of predict()'s loop (rollout_to_netcdf.py:274-310), B = 1:
+ *     y = model(x) [+ tracer fixer]; y_phys = y*std + mean; x_next = update_x(x, frc, y).
+ *     y_dev / y_phys_dev / x_next_dev may each be NULL to skip that output; frc_dev
+ *     float32 [1, n_dyn, 1, H, W] may be NULL when x_next_dev is NULL.
+ *     x_next_dev may not alias x_dev.
+ */
+int wx_forward(wx_handle h, const float* x_dev, float* y_dev, int batch, void* stream);
+int wx_step(wx_handle h, const float* x_dev, const float* frc_dev, float* y_dev, float* y_phys_dev,
+            float* x_next_dev, void* stream);
+
+/* ---- lat-band sharding; optional -------------------------
+ * wx_set_comm <-> DomainParallelManager (credit/domain_parallel/manager.py:22).  `nccl_comm` is an
+ * ncclComm_t (RCCL) passed as void*.  Not required for single-GPU or replica runs. */
+int wx_set_comm(wx_handle h, void* nccl_comm, int rank, int nranks);
+
+/* ---- introspection for parity tests and the roofline report ----------------
+ * wx_debug_read: copy an intermediate activation of the LAST forward (batch item 0) to host as
+ *   float32 [C, H, W].  Names follow the reference module tree: "pad", "layers.S.0", "layers.S.1",
+ *   "layers.S.1.layers.D.J", "up_block1".."up_block4".  Only valid after
+ *   wx_set_debug(h, 1) and a forward.
+ * wx_profile: when enabled, every kernel launch is bracketed by HIP events on the launch stream;
+ *   wx_profile_read returns per-kernel-class totals since the last wx_profile_reset.
+ */
+int wx_set_debug(wx_handle h, int enable);
+int wx_debug_read(wx_handle h, const char* name, float* host_out, int64_t capacity, int64_t shape[3]);
+
+typedef struct wx_kernel_stat {
+  char name[48];
+  int64_t launches;
+  double ms;          /* summed HIP-event time */
+  double flops;       /* algorithmic FLOPs issued by these launches (2*MAC) */
+  double bytes;       /* algorithmic HBM bytes (each operand read/written once) */
+} wx_kernel_stat;
+int wx_profile(wx_handle h, int enable);
+int wx_profile_reset(wx_handle h);
+int wx_profile_read(wx_handle h, wx_kernel_stat* out, int capacity, int* count);
+
+const char* wx_last_error(void);
+const char* wx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WXENGINE_H */

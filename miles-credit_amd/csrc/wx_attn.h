@@ -1,0 +1,239 @@
+// Window attention core (short = contiguous wsz x wsz block, long = dilated grid) on MFMA.
+// Reference: credit/models/crossformer.py:247-316 (Attention.forward) minus LayerNorm / to_qkv /
+// to_out, which run as conv_gemm launches around this kernel.
+//
+// One wave owns one (window, head) pair; N = wsz^2 tokens (<= 128), d = dim_head = 32.
+//   S^T = K . Q^T           MFMA A = K rows (keys), B = Q rows (queries): the accumulator lane
+//                           (col = query lane&15, rows = keys (lane>>4)*4+r) keeps a whole softmax row's
+//                           keys inside the 4 lanes sharing lane&15 -> 2 xor-shuffles per reduction
+//   P   = softmax(S*scale + bias)   fp32, bias = dynamic position bias [N][N] (precomputed at load)
+//   O^T = V^T . P^T         MFMA A = V^T fragment read from a per-wave LDS transpose of V,
+//                           B = P^T taken straight from the S^T accumulator registers (P never leaves
+//                           the register file); the key<->k-slot mapping is chosen to match that layout
+// Token (query/key) rows are gathered straight from the token-major qkv buffer: a token's head slice is
+// 64 B (bf16) / 128 B (f32) contiguous, so both window kinds load full lines with no staging.
+#pragma once
+#include "wx_common.h"
+#include "wx_gemm.h"
+
+namespace wx {
+
+struct AttnParams {
+  const void* qkv;  // [H*W][ld_qkv]: q | k | v, each C wide
+  int64_t ld_qkv;
+  void* out;        // [H*W][ld_out]
+  int64_t ld_out;
+  const float* bias;  // [NP][NP] fp32, NP = 16*NKF; padded keys hold -1e30
+  int H, W, C, heads, wsz, kind;  // kind 0 short, 1 long
+  float scale;
+};
+
+template <typename T, int NKF>
+__global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
+  constexpr int D = 32;
+  constexpr int NP = NKF * 16;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int QK_SUBS = D * (int)sizeof(T) / 64;       // 16-byte pieces per lane for a Q/K fragment
+  constexpr int NKB = (NKF + 1) / 2;                     // 32-key steps (bf16 PV)
+  constexpr int VT_COLS = (sizeof(T) == 2) ? (NKB * 32 + 8) : (NP + 4);
+  constexpr int VT_BYTES = D * VT_COLS * (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int N = p.wsz * p.wsz;
+  const int wins_x = p.W / p.wsz, wins_y = p.H / p.wsz;
+  const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t n_tasks = (int64_t)wins_x * wins_y * p.heads;
+  const bool active = task < n_tasks;
+  const int head = active ? (int)(task % p.heads) : 0;
+  const int win = active ? (int)(task / p.heads) : 0;
+  const int wy = win / wins_x, wx_ = win - wy * wins_x;
+
+  auto token_pixel = [&](int t) -> int64_t {
+    const int ty = t / p.wsz, tx = t - ty * p.wsz;
+    int py, px;
+    if (p.kind == 0) {
+      py = wy * p.wsz + ty;
+      px = wx_ * p.wsz + tx;
+    } else {
+      py = ty * wins_y + wy;
+      px = tx * wins_x + wx_;
+    }
+    return (int64_t)py * p.W + px;
+  };
+
+  const T* __restrict__ qkv = reinterpret_cast<const T*>(p.qkv);
+  T* vt = reinterpret_cast<T*>(smem + wave * VT_BYTES);
+
+  // ---- V^T into this wave's LDS slice (zero-filled beyond N) -------------------------------
+  {
+    constexpr int PIECES = D / VEC;  // 16-byte pieces per token row
+    constexpr int COLS_FILL = (sizeof(T) == 2) ? NKB * 32 : NP;
+    for (int idx = lane; idx < COLS_FILL * PIECES; idx += 64) {
+      const int t = idx % COLS_FILL, piece = idx / COLS_FILL;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (active && t < N) v = *reinterpret_cast<const uint4*>(qkv + token_pixel(t) * p.ld_qkv + 2 * p.C + head * D + piece * VEC);
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) vt[(piece * VEC + i) * VT_COLS + t] = e[i];
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+
+  // ---- K fragments (A operand of S^T) and V^T fragments (A operand of O^T) ------------------
+  uint4 kf[NKF][QK_SUBS];
+#pragma unroll
+  for (int j = 0; j < NKF; ++j) {
+    const int key = j * 16 + li;
+#pragma unroll
+    for (int s = 0; s < QK_SUBS; ++s) {
+      kf[j][s] = make_uint4(0u, 0u, 0u, 0u);
+      if (key < N)
+        kf[j][s] = *reinterpret_cast<const uint4*>(qkv + token_pixel(key) * p.ld_qkv + p.C + head * D + (s * 64 + g * 16) / (int)sizeof(T));
+    }
+  }
+  constexpr int NVF = (sizeof(T) == 2) ? NKB : NKF;
+  uint4 vf[2][NVF];
+#pragma unroll
+  for (int df = 0; df < 2; ++df) {
+    const T* row = vt + (df * 16 + li) * VT_COLS;
+#pragma unroll
+    for (int b = 0; b < NVF; ++b) {
+      if constexpr (sizeof(T) == 2) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(row + b * 32 + g * 4);
+        const uint2 hi = *reinterpret_cast<const uint2*>(row + b * 32 + 16 + g * 4);
+        vf[df][b] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      } else {
+        vf[df][b] = *reinterpret_cast<const uint4*>(row + b * 16 + g * 4);
+      }
+    }
+  }
+
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+  const int nqb = (N + 15) / 16;
+  for (int qb = 0; qb < nqb; ++qb) {
+    const int query = qb * 16 + li;
+    const bool qok = query < N;
+    const int64_t qpix = qok ? token_pixel(query) : 0;
+    uint4 qf[QK_SUBS];
+#pragma unroll
+    for (int s = 0; s < QK_SUBS; ++s) {
+      qf[s] = make_uint4(0u, 0u, 0u, 0u);
+      if (qok) qf[s] = *reinterpret_cast<const uint4*>(qkv + qpix * p.ld_qkv + head * D + (s * 64 + g * 16) / (int)sizeof(T));
+    }
+    // Scores/probabilities live in plain float arrays (not ext-vector elements): hipcc (ROCm 7.2) was
+    // observed to fold element writes `vec[r] = expf(..)` so that all four PV B-operands read element 0.
+    float sv[NKF][4];
+    float mx = -3.0e38f;
+    const float* brow = p.bias + (int64_t)query * NP + g * 4;  // query < NP always
+#pragma unroll
+    for (int j = 0; j < NKF; ++j) {
+      f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < QK_SUBS; ++s) a = mma_sub<T>(kf[j][s], qf[s], a);
+      const float4 bb = *reinterpret_cast<const float4*>(brow + j * 16);
+      sv[j][0] = a[0] * p.scale + bb.x;
+      sv[j][1] = a[1] * p.scale + bb.y;
+      sv[j][2] = a[2] * p.scale + bb.z;
+      sv[j][3] = a[3] * p.scale + bb.w;
+      mx = fmaxf(mx, fmaxf(fmaxf(sv[j][0], sv[j][1]), fmaxf(sv[j][2], sv[j][3])));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKF; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sv[j][r] = expf(sv[j][r] - mx);
+        sum += sv[j][r];
+      }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    f32x4_t oacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int b = 0; b < NKB; ++b) {
+        float lo[4], hi[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lo[r] = sv[2 * b][r];
+          hi[r] = (2 * b + 1 < NKF) ? sv[(2 * b + 1 < NKF) ? 2 * b + 1 : 0][r] : 0.f;
+        }
+        uint4 pf;
+        pf.x = (uint32_t)f2bf(lo[0]) | ((uint32_t)f2bf(lo[1]) << 16);
+        pf.y = (uint32_t)f2bf(lo[2]) | ((uint32_t)f2bf(lo[3]) << 16);
+        pf.z = (uint32_t)f2bf(hi[0]) | ((uint32_t)f2bf(hi[1]) << 16);
+        pf.w = (uint32_t)f2bf(hi[2]) | ((uint32_t)f2bf(hi[3]) << 16);
+#pragma unroll
+        for (int df = 0; df < 2; ++df) oacc[df] = mma_sub<T>(vf[df][b], pf, oacc[df]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+#pragma unroll
+        for (int df = 0; df < 2; ++df) {
+          const uint4 va = vf[df][j];
+          oacc[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, va.x), sv[j][0], oacc[df], 0, 0, 0);
+          oacc[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, va.y), sv[j][1], oacc[df], 0, 0, 0);
+          oacc[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, va.z), sv[j][2], oacc[df], 0, 0, 0);
+          oacc[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, va.w), sv[j][3], oacc[df], 0, 0, 0);
+        }
+      }
+    }
+    if (qok) {
+#pragma unroll
+      for (int df = 0; df < 2; ++df) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = oacc[df][r] * inv;
+        store4<T>(out + qpix * p.ld_out + head * D + df * 16 + g * 4, v);
+      }
+    }
+  }
+}
+
+template <typename T, int NKF>
+inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
+  constexpr int NKB = (NKF + 1) / 2;
+  constexpr int VT_COLS = (sizeof(T) == 2) ? (NKB * 32 + 8) : (NKF * 16 + 4);
+  constexpr int LDS = 4 * 32 * VT_COLS * (int)sizeof(T);
+  auto kern = window_attn_kernel<T, NKF>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
+  }
+  const int64_t tasks = (int64_t)(p.H / p.wsz) * (p.W / p.wsz) * p.heads;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((tasks + 3) / 4)), dim3(256), LDS, stream, p);
+  WX_HIP(hipGetLastError());
+}
+
+inline int attn_nkf(int wsz) {
+  const int n = wsz * wsz;
+  if (n <= 16) return 1;
+  if (n <= 32) return 2;
+  if (n <= 64) return 4;
+  if (n <= 112) return 7;
+  if (n <= 128) return 8;
+  return -1;
+}
+
+template <typename T>
+inline void launch_window_attn(const AttnParams& p, hipStream_t stream) {
+  switch (attn_nkf(p.wsz)) {
+    case 1: launch_window_attn_n<T, 1>(p, stream); break;
+    case 2: launch_window_attn_n<T, 2>(p, stream); break;
+    case 4: launch_window_attn_n<T, 4>(p, stream); break;
+    case 7: launch_window_attn_n<T, 7>(p, stream); break;
+    case 8: launch_window_attn_n<T, 8>(p, stream); break;
+    default: throw std::runtime_error("window attention supports at most 128 tokens per window (wsz <= 11)");
+  }
+}
+
+}  // namespace wx

@@ -1,0 +1,981 @@
+// wxengine: MI355X-native CrossFormer/WXFormer forecast step behind the C ABI of include/wxengine.h.
+//
+// Host side: owns the reference-layout state dict, folds it once (spectral norm sigma, LayerNorm
+// affine into the following 1x1 conv, DynamicPositionBias tables, MFMA-friendly K-contiguous weight
+// layout), owns every activation buffer in HBM (token-major H x W x C), and issues the kernels of
+// wx_gemm.h / wx_attn.h / wx_elem.h on the caller's HIP stream.
+#include "../../include/wxengine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "wx_attn.h"
+#include "wx_common.h"
+#include "wx_elem.h"
+#include "wx_gemm.h"
+
+namespace wx {
+
+static thread_local std::string g_last_error;
+
+struct ConfigError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct StateError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct MissingError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ShapeError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool loaded = false;
+  int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct ConvW {          // one repacked GEMM operand in the weight arena
+  int64_t wt = -1;      // element offset into the T arena
+  int n = 0, cin = 0, kh = 1, kw = 1;
+  int64_t bias = -1;    // float-arena offsets (-1 = absent)
+  int64_t colsum = -1;
+  int cin_true = 0;     // unpadded channels (flop accounting)
+};
+struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1; int wsz = 0, kind = 0; };
+struct FFL { ConvW w1, w2; };
+struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
+struct StageL { std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<BlockL> blocks; };
+struct UpL { ConvW convt, c1, c2; int64_t g1 = -1, b1 = -1, g2 = -1, b2 = -1; int cin = 0, cout = 0; };
+
+struct KernelStatAcc { int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
+
+class EngineBase {
+ public:
+  virtual ~EngineBase() {}
+  virtual void load_tensor(const char* key, const float* data, int ndim, const int64_t* shape) = 0;
+  virtual void finalize() = 0;
+  virtual void forward(const float* x, float* y, int batch, hipStream_t s) = 0;
+  virtual void step(const float* x, const float* frc, float* y, float* y_phys, float* x_next, hipStream_t s) = 0;
+  virtual void set_denorm(const float* mean, const float* stdv, int n) = 0;
+  virtual void set_tracer(const int32_t* inds, const float* thres, const float* thres_max, int n, int denorm) = 0;
+  virtual void set_layout(int n_prog, int n_static, int n_dyn) = 0;
+  virtual int num_tensors() = 0;
+  virtual void tensor_info(int i, const char** key, int* ndim, int64_t shape[8]) = 0;
+  virtual void set_debug(int on) = 0;
+  virtual void debug_read(const char* name, float* out, int64_t cap, int64_t shape[3]) = 0;
+  virtual void profile(int on) = 0;
+  virtual void profile_reset() = 0;
+  virtual int profile_read(wx_kernel_stat* out, int cap) = 0;
+  int device = 0;
+};
+
+template <typename T>
+class Engine : public EngineBase {
+ public:
+  explicit Engine(const wx_config& c, int dev) : cfg(c) {
+    device = dev;
+    derive();
+    build_spec();
+  }
+  ~Engine() override {
+    (void)hipSetDevice(device);
+    for (void* p : allocs) (void)hipFree(p);
+    for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
+
+  // ------------------------------------------------------------------ config
+  wx_config cfg;
+  int C_in = 0, C_out = 0, Hp = 0, Wp = 0, halo = 0, cpad0 = 0;
+  int sh[4], sw[4];           // stage maps
+  int Hd = 0, Wd = 0, Hu = 0, Wu = 0, Ho = 0, Wo = 0, ld_dec = 0;
+  bool finalized = false;
+
+  void derive() {
+    if (cfg.abi_version != WX_ABI_VERSION) throw ConfigError("wx_config.abi_version mismatch");
+    if (cfg.frames < 1 || cfg.output_frames < 1) throw ConfigError("frames/output_frames must be >= 1");
+    if (cfg.dim_head != 32) throw ConfigError("engine supports dim_head == 32 only (reference default)");
+    C_in = (cfg.channels * cfg.levels + cfg.surface_channels + cfg.input_only_channels) * cfg.frames;
+    C_out = (cfg.channels * cfg.levels + cfg.surface_channels + cfg.output_only_channels) * cfg.output_frames;
+    Hp = cfg.image_height + (cfg.pad_activate ? cfg.pad_lat[0] + cfg.pad_lat[1] : 0);
+    Wp = cfg.image_width + (cfg.pad_activate ? cfg.pad_lon[0] + cfg.pad_lon[1] : 0);
+    if (cfg.pad_activate && cfg.pad_lat[0] > 0 && cfg.pad_lat[1] == 0)
+      throw ConfigError("pad_lat=[p,0] hits a slicing quirk of the reference (boundary_padding.py:66); unsupported");
+    if (cfg.pad_activate && (cfg.pad_lat[0] > cfg.image_height || cfg.pad_lat[1] > cfg.image_height))
+      throw ConfigError("pad_lat larger than the image");
+    int h = Hp, w = Wp;
+    for (int s = 0; s < 4; ++s) {
+      const int st = cfg.embed_strides[s];
+      if (cfg.n_embed_kernels[s] < 1 || cfg.n_embed_kernels[s] > 4) throw ConfigError("1..4 cross-embed kernels per stage");
+      int oh = -1, ow = -1;
+      for (int b = 0; b < cfg.n_embed_kernels[s]; ++b) {
+        const int k = cfg.embed_kernels[s][b];
+        if (k < st) throw ConfigError("cross-embed kernel smaller than stride");
+        const int pd = (k - st) / 2;
+        const int h2 = (h + 2 * pd - k) / st + 1, w2 = (w + 2 * pd - k) / st + 1;
+        if (oh >= 0 && (h2 != oh || w2 != ow)) throw ConfigError("cross-embed branches disagree on output size");
+        oh = h2; ow = w2;
+        if (s == 0) halo = std::max(halo, pd);
+      }
+      sh[s] = h = oh; sw[s] = w = ow;
+      if (cfg.dim[s] % 32) throw ConfigError("dim must be a multiple of 32");
+      for (int wsz : {cfg.local_window_size[s], cfg.global_window_size[s]}) {
+        if (wsz < 1 || h % wsz || w % wsz) throw ConfigError("stage map not divisible by window size");
+        if (attn_nkf(wsz) < 0) throw ConfigError("window size > 11 (more than 128 tokens) unsupported");
+      }
+    }
+    for (int s = 0; s < 3; ++s) {
+      if (sh[s] != 2 * sh[s + 1] || sw[s] != 2 * sw[s + 1]) throw ConfigError("stage maps must halve (decoder skip concat)");
+      if (cfg.dim[s + 1] != 2 * cfg.dim[s]) throw ConfigError("dim must double per stage (decoder skip widths)");
+    }
+    cpad0 = ((C_in + 31) / 32) * 32;
+    Hd = sh[3] * 16; Wd = sw[3] * 16;
+    Hu = Hd - (cfg.pad_activate ? cfg.pad_lat[0] + cfg.pad_lat[1] : 0);
+    Wu = Wd - (cfg.pad_activate ? cfg.pad_lon[0] + cfg.pad_lon[1] : 0);
+    if (Hu < 1 || Wu < 1) throw ConfigError("decoder output smaller than the padding");
+    Ho = cfg.interp ? cfg.image_height : Hu;
+    Wo = cfg.interp ? cfg.image_width : Wu;
+    ld_dec = ((C_out + 7) / 8) * 8;
+    if (cfg.max_batch < 1) cfg.max_batch = 1;
+  }
+
+  // ------------------------------------------------------------------ state dict
+  std::vector<std::string> keys;
+  std::map<std::string, HostTensor> tensors;
+
+  void add_key(const std::string& k, std::vector<int64_t> shape) {
+    keys.push_back(k);
+    HostTensor t;
+    t.shape = std::move(shape);
+    tensors[k] = std::move(t);
+  }
+  void add_conv(const std::string& p, std::vector<int64_t> shape, bool bias, bool transposed = false) {
+    const int64_t nb = transposed ? shape[1] : shape[0];
+    if (cfg.use_spectral_norm) {
+      if (bias) add_key(p + ".bias", {nb});
+      add_key(p + ".weight_orig", shape);
+      int64_t rest = 1;
+      if (transposed) {
+        rest = shape[0];
+        for (size_t i = 2; i < shape.size(); ++i) rest *= shape[i];
+        add_key(p + ".weight_u", {shape[1]});
+      } else {
+        for (size_t i = 1; i < shape.size(); ++i) rest *= shape[i];
+        add_key(p + ".weight_u", {shape[0]});
+      }
+      add_key(p + ".weight_v", {rest});
+    } else {
+      add_key(p + ".weight", shape);
+      if (bias) add_key(p + ".bias", {nb});
+    }
+  }
+  void build_spec() {
+    int dims[5] = {C_in, cfg.dim[0], cfg.dim[1], cfg.dim[2], cfg.dim[3]};
+    for (int s = 0; s < 4; ++s) {
+      const int cin = dims[s], cout = dims[s + 1];
+      std::vector<int> ks(cfg.embed_kernels[s], cfg.embed_kernels[s] + cfg.n_embed_kernels[s]);
+      std::sort(ks.begin(), ks.end());
+      std::vector<int> sc;
+      int acc = 0;
+      for (size_t i = 1; i < ks.size(); ++i) { sc.push_back((int)(cout / (1 << i))); acc += sc.back(); }
+      sc.push_back(cout - acc);
+      for (size_t b = 0; b < ks.size(); ++b)
+        add_conv("layers." + std::to_string(s) + ".0.convs." + std::to_string(b), {sc[b], cin, ks[b], ks[b]}, true);
+      const int dq = cout / 4;
+      for (int d = 0; d < cfg.depth[s]; ++d) {
+        for (int j = 0; j < 4; ++j) {
+          const std::string p = "layers." + std::to_string(s) + ".1.layers." + std::to_string(d) + "." + std::to_string(j);
+          if (j == 0 || j == 2) {
+            add_key(p + ".norm.g", {1, cout, 1, 1});
+            add_key(p + ".norm.b", {1, cout, 1, 1});
+            add_conv(p + ".to_qkv", {3 * cout, cout, 1, 1}, false);
+            add_conv(p + ".to_out", {cout, cout, 1, 1}, true);
+            add_conv(p + ".dpb.layers.0", {dq, 2}, true);
+            add_key(p + ".dpb.layers.1.weight", {dq});
+            add_key(p + ".dpb.layers.1.bias", {dq});
+            add_conv(p + ".dpb.layers.3", {dq, dq}, true);
+            add_key(p + ".dpb.layers.4.weight", {dq});
+            add_key(p + ".dpb.layers.4.bias", {dq});
+            add_conv(p + ".dpb.layers.6", {dq, dq}, true);
+            add_key(p + ".dpb.layers.7.weight", {dq});
+            add_key(p + ".dpb.layers.7.bias", {dq});
+            add_conv(p + ".dpb.layers.9", {1, dq}, true);
+          } else {
+            add_key(p + ".layers.0.g", {1, cout, 1, 1});
+            add_key(p + ".layers.0.b", {1, cout, 1, 1});
+            add_conv(p + ".layers.1", {4 * cout, cout, 1, 1}, true);
+            add_conv(p + ".layers.4", {cout, 4 * cout, 1, 1}, true);
+          }
+        }
+      }
+    }
+    const int last = cfg.dim[3];
+    const int ups[3][2] = {{last, last / 2}, {2 * (last / 2), last / 4}, {2 * (last / 4), last / 8}};
+    for (int i = 0; i < 3; ++i) {
+      const std::string p = "up_block" + std::to_string(i + 1);
+      add_conv(p + ".conv", {ups[i][0], ups[i][1], 2, 2}, true, true);
+      for (int j : {0, 3}) {
+        add_conv(p + ".b." + std::to_string(j), {ups[i][1], ups[i][1], 3, 3}, true);
+        add_key(p + ".b." + std::to_string(j + 1) + ".weight", {ups[i][1]});
+        add_key(p + ".b." + std::to_string(j + 1) + ".bias", {ups[i][1]});
+      }
+    }
+    add_conv("up_block4", {2 * (last / 8), C_out, 4, 4}, true, true);
+  }
+
+  void load_tensor(const char* key, const float* data, int ndim, const int64_t* shape) override {
+    auto it = tensors.find(key);
+    if (it == tensors.end()) {
+      // reference semantics: load_state_dict(strict=False) ignores unexpected keys (base_model.py:77-80)
+      return;
+    }
+    HostTensor& t = it->second;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    if (n != t.numel())
+      throw ShapeError(std::string("tensor '") + key + "' has " + std::to_string(n) + " elements, expected " +
+                       std::to_string(t.numel()));
+    t.data.assign(data, data + n);
+    t.loaded = true;
+    finalized = false;
+  }
+  int num_tensors() override { return (int)keys.size(); }
+  void tensor_info(int i, const char** key, int* ndim, int64_t shape[8]) override {
+    if (i < 0 || i >= (int)keys.size()) throw ConfigError("tensor index out of range");
+    const HostTensor& t = tensors[keys[i]];
+    *key = keys[i].c_str();
+    *ndim = (int)t.shape.size();
+    for (size_t d = 0; d < t.shape.size() && d < 8; ++d) shape[d] = t.shape[d];
+  }
+  const HostTensor& need(const std::string& k) {
+    auto it = tensors.find(k);
+    if (it == tensors.end() || !it->second.loaded) throw MissingError("state-dict tensor '" + k + "' was not loaded");
+    return it->second;
+  }
+
+  // ------------------------------------------------------------------ weight folding (host)
+  std::vector<T> wt_host;      // T arena
+  std::vector<float> f_host;   // float arena
+  T* wt_dev = nullptr;
+  float* f_dev = nullptr;
+  StageL stages[4];
+  UpL ups[3];
+  ConvW up4[4];
+
+  // eval-mode spectral norm: W / (u . (W_mat v)); W_mat rows = dim 0 (dim 1 for ConvTranspose2d)
+  std::vector<double> folded(const std::string& p, bool transposed) {
+    if (!cfg.use_spectral_norm) {
+      const HostTensor& w = need(p + ".weight");
+      return std::vector<double>(w.data.begin(), w.data.end());
+    }
+    const HostTensor& w = need(p + ".weight_orig");
+    const HostTensor& u = need(p + ".weight_u");
+    const HostTensor& v = need(p + ".weight_v");
+    const int64_t d0 = w.shape[0], d1 = w.shape.size() > 1 ? w.shape[1] : 1;
+    int64_t rest = 1;
+    for (size_t i = 2; i < w.shape.size(); ++i) rest *= w.shape[i];
+    double sigma = 0.0;
+    if (!transposed) {
+      const int64_t cols = d1 * rest;
+      for (int64_t r = 0; r < d0; ++r) {
+        double acc = 0.0;
+        const float* row = w.data.data() + r * cols;
+        for (int64_t c = 0; c < cols; ++c) acc += (double)row[c] * v.data[c];
+        sigma += acc * u.data[r];
+      }
+    } else {
+      // W_mat[o][i*rest + k] = W[i][o][k]
+      for (int64_t o = 0; o < d1; ++o) {
+        double acc = 0.0;
+        for (int64_t i = 0; i < d0; ++i)
+          for (int64_t k = 0; k < rest; ++k) acc += (double)w.data[(i * d1 + o) * rest + k] * v.data[i * rest + k];
+        sigma += acc * u.data[o];
+      }
+    }
+    std::vector<double> out(w.data.size());
+    for (size_t i = 0; i < out.size(); ++i) out[i] = (double)w.data[i] / sigma;
+    return out;
+  }
+  int64_t push_f(const std::vector<float>& v) {
+    // keep every float-arena block 16-byte aligned
+    while (f_host.size() % 4) f_host.push_back(0.f);
+    const int64_t off = (int64_t)f_host.size();
+    f_host.insert(f_host.end(), v.begin(), v.end());
+    return off;
+  }
+  int64_t push_w(const std::vector<double>& rows, int n, int64_t k) {
+    while (wt_host.size() % 8) wt_host.push_back(Elem<T>::from_f(0.f));
+    const int64_t off = (int64_t)wt_host.size();
+    wt_host.resize(off + (int64_t)n * k);
+    for (int64_t i = 0; i < (int64_t)n * k; ++i) wt_host[off + i] = Elem<T>::from_f((float)rows[i]);
+    return off;
+  }
+  // Conv2d weight W[n][c][kh][kw] (rows [r0, r1)) -> [n][kh][kw][cpad]; optional LayerNorm fold (g, b per input channel)
+  ConvW make_conv(const std::string& p, int r0, int r1, int cin, int cpad, int kh, int kw, bool has_bias,
+                  const float* ln_g, const float* ln_b) {
+    const std::vector<double> w = folded(p, false);
+    const int n = r1 - r0;
+    const int64_t k = (int64_t)kh * kw * cpad;
+    std::vector<double> rows((size_t)n * k, 0.0);
+    std::vector<float> bias(n, 0.f), colsum;
+    const HostTensor* bt = has_bias ? &need(p + ".bias") : nullptr;
+    for (int o = 0; o < n; ++o) {
+      double tshift = 0.0;
+      for (int c = 0; c < cin; ++c)
+        for (int y = 0; y < kh; ++y)
+          for (int x = 0; x < kw; ++x) {
+            double v = w[(((int64_t)(r0 + o) * cin + c) * kh + y) * kw + x];
+            if (ln_b) tshift += v * ln_b[c];
+            if (ln_g) v *= ln_g[c];
+            rows[(size_t)o * k + ((int64_t)y * kw + x) * cpad + c] = v;
+          }
+      bias[o] = (float)(tshift + (bt ? (double)bt->data[r0 + o] : 0.0));
+    }
+    ConvW cw;
+    cw.n = n; cw.cin = cpad; cw.cin_true = cin; cw.kh = kh; cw.kw = kw;
+    cw.wt = push_w(rows, n, k);
+    if (ln_g) {  // colsum over the ROUNDED weights so that acc - mean*colsum == sum((x-mean)*w) exactly
+      colsum.resize(n);
+      for (int o = 0; o < n; ++o) {
+        double s = 0.0;
+        for (int64_t i = 0; i < k; ++i) s += (double)Elem<T>::to_f(wt_host[cw.wt + (int64_t)o * k + i]);
+        colsum[o] = (float)s;
+      }
+      cw.colsum = push_f(colsum);
+    }
+    if (has_bias || ln_b) cw.bias = push_f(bias);
+    return cw;
+  }
+  // ConvTranspose2d k2 s2: W[ci][co][dy][dx] -> rows n = (dy*2+dx)*cout + co, K = ci; bias expanded x4
+  ConvW make_convt2(const std::string& p, int cin, int cout) {
+    const std::vector<double> w = folded(p, true);
+    std::vector<double> rows((size_t)4 * cout * cin);
+    for (int ci = 0; ci < cin; ++ci)
+      for (int co = 0; co < cout; ++co)
+        for (int q = 0; q < 4; ++q) rows[((size_t)q * cout + co) * cin + ci] = w[((int64_t)ci * cout + co) * 4 + q];
+    const HostTensor& b = need(p + ".bias");
+    std::vector<float> bias(4 * cout);
+    for (int q = 0; q < 4; ++q)
+      for (int co = 0; co < cout; ++co) bias[q * cout + co] = b.data[co];
+    ConvW cw;
+    cw.n = 4 * cout; cw.cin = cin; cw.cin_true = cin;
+    cw.wt = push_w(rows, 4 * cout, cin);
+    cw.bias = push_f(bias);
+    return cw;
+  }
+  // ConvTranspose2d k4 s2 p1 as four 2x2-tap parity convs: out(2y+py, 2x+px) = sum_{ty,tx} in(y-1+py+ty, x-1+px+tx) W[ci][co][3-py-2ty][3-px-2tx]
+  void make_convt4(const std::string& p, int cin, int cout) {
+    const std::vector<double> w = folded(p, true);
+    const HostTensor& b = need(p + ".bias");
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        std::vector<double> rows((size_t)cout * 4 * cin);
+        for (int co = 0; co < cout; ++co)
+          for (int ty = 0; ty < 2; ++ty)
+            for (int tx = 0; tx < 2; ++tx)
+              for (int ci = 0; ci < cin; ++ci)
+                rows[((size_t)co * 4 + ty * 2 + tx) * cin + ci] =
+                    w[(((int64_t)ci * cout + co) * 4 + (3 - py - 2 * ty)) * 4 + (3 - px - 2 * tx)];
+        ConvW cw;
+        cw.n = cout; cw.cin = cin; cw.cin_true = cin; cw.kh = 2; cw.kw = 2;
+        cw.wt = push_w(rows, cout, (int64_t)4 * cin);
+        cw.bias = push_f(std::vector<float>(b.data.begin(), b.data.end()));
+        up4[py * 2 + px] = cw;
+      }
+  }
+  // DynamicPositionBias (crossformer.py:158-176) evaluated on the (2w+1)^2 offsets, gathered with the
+  // reference's stride-(2w-1) indices (crossformer.py:238-245, :284), padded to [NP][NP].
+  int64_t make_bias_table(const std::string& p, int wsz, int dq) {
+    const int side = 2 * wsz + 1, npos = side * side;
+    std::vector<double> w0 = folded(p + ".layers.0", false), w3 = folded(p + ".layers.3", false),
+                        w6 = folded(p + ".layers.6", false), w9 = folded(p + ".layers.9", false);
+    const HostTensor &b0 = need(p + ".layers.0.bias"), &b3 = need(p + ".layers.3.bias"), &b6 = need(p + ".layers.6.bias"),
+                     &b9 = need(p + ".layers.9.bias");
+    const HostTensor* lnw[3] = {&need(p + ".layers.1.weight"), &need(p + ".layers.4.weight"), &need(p + ".layers.7.weight")};
+    const HostTensor* lnb[3] = {&need(p + ".layers.1.bias"), &need(p + ".layers.4.bias"), &need(p + ".layers.7.bias")};
+    std::vector<double> table(npos);
+    std::vector<double> h(dq), h2(dq);
+    auto ln_relu = [&](std::vector<double>& v, int i) {
+      double m = 0, q = 0;
+      for (double x : v) m += x;
+      m /= dq;
+      for (double x : v) q += (x - m) * (x - m);
+      q /= dq;
+      const double r = 1.0 / std::sqrt(q + 1e-5);
+      for (int k = 0; k < dq; ++k) {
+        const double y = (v[k] - m) * r * lnw[i]->data[k] + lnb[i]->data[k];
+        v[k] = y > 0 ? y : 0;
+      }
+    };
+    for (int a = 0; a < side; ++a)
+      for (int b = 0; b < side; ++b) {
+        const double pr = a - wsz, pc = b - wsz;
+        for (int k = 0; k < dq; ++k) h[k] = w0[2 * k] * pr + w0[2 * k + 1] * pc + b0.data[k];
+        ln_relu(h, 0);
+        for (int k = 0; k < dq; ++k) { double s = b3.data[k]; for (int j = 0; j < dq; ++j) s += w3[(size_t)k * dq + j] * h[j]; h2[k] = s; }
+        ln_relu(h2, 1);
+        for (int k = 0; k < dq; ++k) { double s = b6.data[k]; for (int j = 0; j < dq; ++j) s += w6[(size_t)k * dq + j] * h2[j]; h[k] = s; }
+        ln_relu(h, 2);
+        double s = b9.data[0];
+        for (int j = 0; j < dq; ++j) s += w9[j] * h[j];
+        table[a * side + b] = s;
+      }
+    const int N = wsz * wsz, NP = attn_nkf(wsz) * 16;
+    std::vector<float> padded((size_t)NP * NP, 0.f);
+    for (int i = 0; i < NP; ++i)
+      for (int j = 0; j < NP; ++j) {
+        float v;
+        if (j >= N) v = -1.0e30f;
+        else if (i >= N) v = 0.f;
+        else {
+          const int dr = i / wsz - j / wsz + wsz - 1, dc = i % wsz - j % wsz + wsz - 1;
+          v = (float)table[dr * (2 * wsz - 1) + dc];
+        }
+        padded[(size_t)i * NP + j] = v;
+      }
+    return push_f(padded);
+  }
+  AttnL make_attn(const std::string& p, int c, int wsz, int kind) {
+    AttnL a;
+    a.wsz = wsz; a.kind = kind;
+    const HostTensor &g = need(p + ".norm.g"), &b = need(p + ".norm.b");
+    if (wsz == 1) {
+      // one token per window: softmax == 1, attention output == v (crossformer.py:286-295) -> only the v rows
+      a.vonly = make_conv(p + ".to_qkv", 2 * c, 3 * c, c, c, 1, 1, false, g.data.data(), b.data.data());
+    } else {
+      a.qkv = make_conv(p + ".to_qkv", 0, 3 * c, c, c, 1, 1, false, g.data.data(), b.data.data());
+      a.bias_tab = make_bias_table(p + ".dpb", wsz, c / 4);
+    }
+    a.out = make_conv(p + ".to_out", 0, c, c, c, 1, 1, true, nullptr, nullptr);
+    return a;
+  }
+  FFL make_ff(const std::string& p, int c) {
+    FFL f;
+    const HostTensor &g = need(p + ".layers.0.g"), &b = need(p + ".layers.0.b");
+    f.w1 = make_conv(p + ".layers.1", 0, 4 * c, c, c, 1, 1, true, g.data.data(), b.data.data());
+    f.w2 = make_conv(p + ".layers.4", 0, c, 4 * c, 4 * c, 1, 1, true, nullptr, nullptr);
+    return f;
+  }
+
+  void finalize() override {
+    WX_HIP(hipSetDevice(device));
+    for (const auto& k : keys) need(k);
+    wt_host.clear(); f_host.clear();
+    int dims[5] = {C_in, cfg.dim[0], cfg.dim[1], cfg.dim[2], cfg.dim[3]};
+    for (int s = 0; s < 4; ++s) {
+      StageL st;
+      std::vector<int> ks(cfg.embed_kernels[s], cfg.embed_kernels[s] + cfg.n_embed_kernels[s]);
+      std::sort(ks.begin(), ks.end());
+      const int cin = dims[s], cout = dims[s + 1];
+      const int cpad = s == 0 ? cpad0 : cin;
+      int acc = 0;
+      for (size_t b = 0; b < ks.size(); ++b) {
+        const int co = (b + 1 < ks.size()) ? (int)(cout / (1 << (b + 1))) : cout - acc;
+        acc += co;
+        st.embed.push_back(make_conv("layers." + std::to_string(s) + ".0.convs." + std::to_string(b), 0, co, cin, cpad,
+                                     ks[b], ks[b], true, nullptr, nullptr));
+        st.embed_k.push_back(ks[b]);
+      }
+      for (int d = 0; d < cfg.depth[s]; ++d) {
+        const std::string p = "layers." + std::to_string(s) + ".1.layers." + std::to_string(d);
+        BlockL bl;
+        bl.sa = make_attn(p + ".0", cout, cfg.local_window_size[s], 0);
+        bl.sf = make_ff(p + ".1", cout);
+        bl.la = make_attn(p + ".2", cout, cfg.global_window_size[s], 1);
+        bl.lf = make_ff(p + ".3", cout);
+        st.blocks.push_back(bl);
+      }
+      stages[s] = std::move(st);
+    }
+    const int last = cfg.dim[3];
+    const int upc[3][2] = {{last, last / 2}, {2 * (last / 2), last / 4}, {2 * (last / 4), last / 8}};
+    for (int i = 0; i < 3; ++i) {
+      const std::string p = "up_block" + std::to_string(i + 1);
+      UpL u;
+      u.cin = upc[i][0]; u.cout = upc[i][1];
+      if (u.cout % 32) throw ConfigError("decoder widths must be multiples of 32");
+      u.convt = make_convt2(p + ".conv", u.cin, u.cout);
+      u.c1 = make_conv(p + ".b.0", 0, u.cout, u.cout, u.cout, 3, 3, true, nullptr, nullptr);
+      u.c2 = make_conv(p + ".b.3", 0, u.cout, u.cout, u.cout, 3, 3, true, nullptr, nullptr);
+      u.g1 = push_f(need(p + ".b.1.weight").data); u.b1 = push_f(need(p + ".b.1.bias").data);
+      u.g2 = push_f(need(p + ".b.4.weight").data); u.b2 = push_f(need(p + ".b.4.bias").data);
+      ups[i] = u;
+    }
+    make_convt4("up_block4", 2 * (last / 8), C_out);
+
+    // upload
+    if (wt_dev) { (void)hipFree(wt_dev); allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)wt_dev)); wt_dev = nullptr; }
+    if (f_dev) { (void)hipFree(f_dev); allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)f_dev)); f_dev = nullptr; }
+    wt_dev = (T*)dalloc(wt_host.size() * sizeof(T) + 256);
+    f_dev = (float*)dalloc(f_host.size() * sizeof(float) + 256);
+    WX_HIP(hipMemcpy(wt_dev, wt_host.data(), wt_host.size() * sizeof(T), hipMemcpyHostToDevice));
+    WX_HIP(hipMemcpy(f_dev, f_host.data(), f_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<T>().swap(wt_host);
+    alloc_activations();
+    finalized = true;
+  }
+
+  // ------------------------------------------------------------------ buffers
+  std::vector<void*> allocs;
+  void* dalloc(size_t bytes) {
+    void* p = nullptr;
+    WX_HIP(hipMalloc(&p, bytes));
+    allocs.push_back(p);
+    return p;
+  }
+  T* xin = nullptr;          // packed, halo'd input
+  T* cat[3] = {nullptr, nullptr, nullptr};   // [HW_s][2*C_s]: [up-block output | encoder stream]
+  T* x3 = nullptr;           // stage-3 stream
+  T* scratch = nullptr;      // qkv / FF hidden
+  T* attn_o = nullptr;       // attention output before to_out
+  T* dtmp[3] = {nullptr, nullptr, nullptr};  // decoder temporaries
+  T* dec = nullptr;          // up_block4 output [Hd][Wd][ld_dec]
+  float2* rowstat = nullptr;
+  double* gn_acc = nullptr;
+  float *gn_scale = nullptr, *gn_shift = nullptr;
+  float *d_mean = nullptr, *d_std = nullptr, *d_lo = nullptr, *d_hi = nullptr;
+  bool have_denorm = false, have_tracer = false;
+  int tracer_denorm = 0, n_prog = -1, n_static = 0, n_dyn = 0;
+  bool acts_ready = false;
+
+  void alloc_activations() {
+    if (acts_ready) return;
+    const int64_t xin_elems = (int64_t)(Hp + 2 * halo + 2) * (Wp + 2 * halo + 2) * cpad0;
+    xin = (T*)dalloc(xin_elems * sizeof(T));
+    WX_HIP(hipMemset(xin, 0, xin_elems * sizeof(T)));
+    int64_t max_sc = 0, max_ao = 0, max_hw = 0;
+    for (int s = 0; s < 4; ++s) {
+      const int64_t hw = (int64_t)sh[s] * sw[s];
+      if (s < 3) cat[s] = (T*)dalloc(hw * 2 * cfg.dim[s] * sizeof(T));
+      else x3 = (T*)dalloc(hw * cfg.dim[s] * sizeof(T));
+      max_sc = std::max(max_sc, hw * 4 * cfg.dim[s]);
+      max_ao = std::max(max_ao, hw * cfg.dim[s]);
+      max_hw = std::max(max_hw, hw);
+    }
+    scratch = (T*)dalloc(max_sc * sizeof(T));
+    attn_o = (T*)dalloc(max_ao * sizeof(T));
+    int64_t max_dt = 0;
+    for (int i = 0; i < 3; ++i) max_dt = std::max(max_dt, (int64_t)sh[2 - i] * sw[2 - i] * ups[i].cout);
+    for (int i = 0; i < 3; ++i) dtmp[i] = (T*)dalloc(max_dt * sizeof(T));
+    dec = (T*)dalloc((int64_t)Hd * Wd * ld_dec * sizeof(T));
+    WX_HIP(hipMemset(dec, 0, (int64_t)Hd * Wd * ld_dec * sizeof(T)));
+    rowstat = (float2*)dalloc(max_hw * sizeof(float2));
+    const int cmax = cfg.dim[3];
+    gn_acc = (double*)dalloc(2 * cmax * sizeof(double));
+    gn_scale = (float*)dalloc(cmax * sizeof(float));
+    gn_shift = (float*)dalloc(cmax * sizeof(float));
+    d_mean = (float*)dalloc(C_out * sizeof(float));
+    d_std = (float*)dalloc(C_out * sizeof(float));
+    d_lo = (float*)dalloc(C_out * sizeof(float));
+    d_hi = (float*)dalloc(C_out * sizeof(float));
+    acts_ready = true;
+  }
+
+  T* stream_ptr(int s) { return s < 3 ? cat[s] + cfg.dim[s] : x3; }
+  int64_t stream_ld(int s) { return s < 3 ? 2 * cfg.dim[s] : cfg.dim[s]; }
+
+  // ------------------------------------------------------------------ step glue state
+  void set_denorm(const float* mean, const float* stdv, int n) override {
+    if (n != C_out) throw ShapeError("wx_set_denorm: n must equal the number of output channels");
+    WX_HIP(hipSetDevice(device));
+    alloc_small();
+    WX_HIP(hipMemcpy(d_mean, mean, n * sizeof(float), hipMemcpyHostToDevice));
+    WX_HIP(hipMemcpy(d_std, stdv, n * sizeof(float), hipMemcpyHostToDevice));
+    have_denorm = true;
+  }
+  void set_tracer(const int32_t* inds, const float* thres, const float* thres_max, int n, int denorm) override {
+    WX_HIP(hipSetDevice(device));
+    alloc_small();
+    if (n == 0) { have_tracer = false; return; }
+    std::vector<float> lo(C_out, -3.4e38f), hi(C_out, 3.4e38f);
+    for (int i = 0; i < n; ++i) {
+      if (inds[i] < 0 || inds[i] >= C_out) throw ConfigError("tracer index out of range");
+      lo[inds[i]] = thres[i];
+      if (thres_max) hi[inds[i]] = thres_max[i];
+    }
+    if (denorm && !have_denorm) throw StateError("wx_set_tracer_fixer(denorm=1) needs wx_set_denorm first");
+    WX_HIP(hipMemcpy(d_lo, lo.data(), C_out * sizeof(float), hipMemcpyHostToDevice));
+    WX_HIP(hipMemcpy(d_hi, hi.data(), C_out * sizeof(float), hipMemcpyHostToDevice));
+    have_tracer = true;
+    tracer_denorm = denorm;
+  }
+  void set_layout(int np, int ns, int nd) override {
+    if (np < 0 || ns < 0 || nd < 0 || np + ns + nd != C_in / cfg.frames || np > C_out)
+      throw ConfigError("wx_set_layout: n_prog + n_static + n_dyn must equal the input channels");
+    n_prog = np; n_static = ns; n_dyn = nd;
+  }
+  void alloc_small() {
+    if (!acts_ready) throw StateError("call wx_finalize_weights before configuring the step glue");
+  }
+
+  // ------------------------------------------------------------------ profiling + debug
+  bool prof_on = false;
+  struct Pending { std::string name; double flops, bytes; int ev; };
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  std::vector<Pending> pending;
+  std::map<std::string, KernelStatAcc> stats;
+  hipStream_t cur_stream = nullptr;
+
+  void profile(int on) override { prof_on = on != 0; }
+  void profile_reset() override { drain(); stats.clear(); }
+  void drain() {
+    if (pending.empty()) return;
+    WX_HIP(hipSetDevice(device));
+    for (auto& pd : pending) {
+      WX_HIP(hipEventSynchronize(ev_pool[pd.ev].second));
+      float ms = 0.f;
+      WX_HIP(hipEventElapsedTime(&ms, ev_pool[pd.ev].first, ev_pool[pd.ev].second));
+      auto& st = stats[pd.name];
+      st.launches += 1; st.ms += ms; st.flops += pd.flops; st.bytes += pd.bytes;
+    }
+    pending.clear();
+  }
+  int profile_read(wx_kernel_stat* out, int cap) override {
+    drain();
+    int i = 0;
+    for (auto& kv : stats) {
+      if (i >= cap) break;
+      std::memset(&out[i], 0, sizeof(wx_kernel_stat));
+      std::strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+      out[i].launches = kv.second.launches; out[i].ms = kv.second.ms;
+      out[i].flops = kv.second.flops; out[i].bytes = kv.second.bytes;
+      ++i;
+    }
+    return i;
+  }
+  template <typename F>
+  void timed(const char* name, double flops, double bytes, F&& fn) {
+    if (!prof_on) { fn(); return; }
+    const int idx = (int)pending.size();
+    while ((int)ev_pool.size() <= idx) {
+      hipEvent_t a, b;
+      WX_HIP(hipEventCreate(&a)); WX_HIP(hipEventCreate(&b));
+      ev_pool.push_back({a, b});
+    }
+    WX_HIP(hipEventRecord(ev_pool[idx].first, cur_stream));
+    fn();
+    WX_HIP(hipEventRecord(ev_pool[idx].second, cur_stream));
+    pending.push_back({name, flops, bytes, idx});
+  }
+
+  bool dbg_on = false;
+  struct DbgT { int64_t c, h, w; std::vector<float> data; };
+  std::map<std::string, DbgT> dbg;
+  void set_debug(int on) override { dbg_on = on != 0; if (!dbg_on) dbg.clear(); }
+  void capture(const std::string& name, const T* base, int h, int w, int c, int64_t ld, int64_t row_pitch_px) {
+    if (!dbg_on) return;
+    WX_HIP(hipStreamSynchronize(cur_stream));
+    std::vector<T> raw((size_t)h * row_pitch_px * ld);
+    const size_t used = ((size_t)(h - 1) * row_pitch_px + (w - 1)) * ld + c;  // do not run past a strided view
+    WX_HIP(hipMemcpy(raw.data(), base, used * sizeof(T), hipMemcpyDeviceToHost));
+    DbgT d;
+    d.c = c; d.h = h; d.w = w;
+    d.data.resize((size_t)c * h * w);
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x)
+        for (int k = 0; k < c; ++k)
+          d.data[((size_t)k * h + y) * w + x] = Elem<T>::to_f(raw[((size_t)y * row_pitch_px + x) * ld + k]);
+    dbg[name] = std::move(d);
+  }
+  void debug_read(const char* name, float* out, int64_t cap, int64_t shape[3]) override {
+    auto it = dbg.find(name);
+    if (it == dbg.end()) throw StateError(std::string("no debug capture named '") + name + "'");
+    shape[0] = it->second.c; shape[1] = it->second.h; shape[2] = it->second.w;
+    if (out) {
+      if (cap < (int64_t)it->second.data.size()) throw ShapeError("debug_read: output buffer too small");
+      std::memcpy(out, it->second.data.data(), it->second.data.size() * sizeof(float));
+    }
+  }
+
+  // ------------------------------------------------------------------ launch helpers
+  void gemm(const char* cls, const ConvW& w, const T* in, int in_h, int in_w, int64_t in_ld, int stride, int pad_y,
+            int pad_x, int out_h, int out_w, T* out, int64_t out_ld, const float2* rs, int act, const T* res,
+            int64_t res_ld, int out_mode = 0, int cout = 0, int py = 0, int px = 0) {
+    ConvGemmParams p;
+    p.in = in; p.in_h = in_h; p.in_w = in_w; p.in_ld = in_ld; p.cin = w.cin;
+    p.kh = w.kh; p.kw = w.kw; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.out_h = out_h; p.out_w = out_w;
+    p.wt = wt_dev + w.wt; p.n = w.n; p.n_alloc = w.n;
+    p.bias = w.bias >= 0 ? f_dev + w.bias : nullptr;
+    p.rowstat = rs; p.colsum = (rs && w.colsum >= 0) ? f_dev + w.colsum : nullptr;
+    if (rs && w.colsum < 0) throw StateError("LayerNorm-folded GEMM without column sums");
+    p.act = act; p.res = res; p.res_ld = res_ld; p.out = out; p.out_ld = out_ld;
+    p.out_mode = out_mode; p.cout = cout; p.py = py; p.px = px;
+    const double m = (double)out_h * out_w;
+    const double flops = 2.0 * m * w.n * w.kh * w.kw * w.cin_true;
+    const double bytes = (m * w.n * (res ? 2.0 : 1.0) + (double)in_h * in_w * w.cin_true + (double)w.n * w.kh * w.kw * w.cin) * sizeof(T);
+    timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, cur_stream); });
+  }
+  void ln_stats(const T* x, int64_t ld, int c, int m) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int pieces = c / VEC;
+    const int lpt = pieces >= 64 ? 64 : pieces;
+    if (pieces / lpt > 4 || (lpt & (lpt - 1))) throw ConfigError("LayerNorm width unsupported (need power-of-two pieces, C <= 1024 fp32)");
+    const int pix_per_block = 4 * (64 / lpt);
+    timed("ln_stats", 0.0, (double)m * c * sizeof(T), [&] {
+      hipLaunchKernelGGL(ln_stats_kernel<T>, dim3(cdiv(m, pix_per_block)), dim3(256), 0, cur_stream, x, ld, c, m, 1e-5f, rowstat);
+      WX_HIP(hipGetLastError());
+    });
+  }
+  void attention(const AttnL& a, int s, const std::string& dbg_name) {
+    const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
+    T* x = stream_ptr(s);
+    const int64_t ld = stream_ld(s);
+    ln_stats(x, ld, c, m);
+    if (a.wsz == 1) {
+      gemm("gemm_qkv", a.vonly, x, h, w, ld, 1, 0, 0, h, w, attn_o, c, rowstat, 0, nullptr, 0);
+    } else {
+      gemm("gemm_qkv", a.qkv, x, h, w, ld, 1, 0, 0, h, w, scratch, 3 * c, rowstat, 0, nullptr, 0);
+      AttnParams p;
+      p.qkv = scratch; p.ld_qkv = 3 * c; p.out = attn_o; p.ld_out = c; p.bias = f_dev + a.bias_tab;
+      p.H = h; p.W = w; p.C = c; p.heads = c / 32; p.wsz = a.wsz; p.kind = a.kind;
+      p.scale = 1.0f / std::sqrt(32.0f);
+      const double n = (double)a.wsz * a.wsz;
+      timed("window_attn", 4.0 * m * n * c, 4.0 * m * c * sizeof(T), [&] { launch_window_attn<T>(p, cur_stream); });
+      capture(dbg_name + ".qkv", scratch, h, w, 3 * c, 3 * c, w);
+    }
+    capture(dbg_name + ".attn", attn_o, h, w, c, c, w);
+    gemm("gemm_out", a.out, attn_o, h, w, c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld);
+    capture(dbg_name, x, h, w, c, ld, w);
+  }
+  void feedforward(const FFL& f, int s, const std::string& dbg_name) {
+    const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
+    T* x = stream_ptr(s);
+    const int64_t ld = stream_ld(s);
+    ln_stats(x, ld, c, m);
+    gemm("gemm_ff1", f.w1, x, h, w, ld, 1, 0, 0, h, w, scratch, 4 * c, rowstat, 1, nullptr, 0);
+    gemm("gemm_ff2", f.w2, scratch, h, w, 4 * c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld);
+    capture(dbg_name, x, h, w, c, ld, w);
+  }
+  void group_norm_silu(const T* x, int c, int64_t m, int64_t g_off, int64_t b_off, const T* res, int64_t res_ld, T* out,
+                       int64_t out_ld) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    if (c / VEC > 256) throw ConfigError("GroupNorm width unsupported");
+    WX_HIP(hipMemsetAsync(gn_acc, 0, 2 * c * sizeof(double), cur_stream));
+    const int rows_per_block = 256 / (c / VEC);
+    int blocks = (int)std::min<int64_t>(2048, (m + rows_per_block - 1) / rows_per_block);
+    timed("gn_stats", 0.0, (double)m * c * sizeof(T), [&] {
+      hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(blocks), dim3(256), 2 * c * sizeof(double), cur_stream, x, (int64_t)c, c, m, gn_acc);
+      WX_HIP(hipGetLastError());
+    });
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(c, 128)), dim3(128), 0, cur_stream, gn_acc, f_dev + g_off, f_dev + b_off, c,
+                       cfg.dim[0], (double)m, 1e-5f, gn_scale, gn_shift);
+    WX_HIP(hipGetLastError());
+    const int64_t total = m * (c / VEC);
+    const int ablocks = (int)std::min<int64_t>(4096, (total + 255) / 256);
+    timed("gn_apply", 0.0, (double)m * c * sizeof(T) * (res ? 3.0 : 2.0), [&] {
+      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(ablocks), dim3(256), 0, cur_stream, x, (int64_t)c, c, m, gn_scale, gn_shift, res, res_ld, out, out_ld);
+      WX_HIP(hipGetLastError());
+    });
+  }
+
+  // ------------------------------------------------------------------ forward
+  void core(const float* x_item) {
+    // a1: pack + earth halo
+    {
+      PackParams p;
+      p.x = x_item; p.dst = xin; p.C = C_in; p.H = cfg.image_height; p.W = cfg.image_width;
+      p.p0 = cfg.pad_activate ? cfg.pad_lat[0] : 0; p.p1 = cfg.pad_activate ? cfg.pad_lat[1] : 0;
+      p.pl = cfg.pad_activate ? cfg.pad_lon[0] : 0; p.pr = cfg.pad_activate ? cfg.pad_lon[1] : 0;
+      p.halo = halo; p.cpad = cpad0;
+      timed("pack_input", 0.0, (double)C_in * cfg.image_height * cfg.image_width * 4.0 + (double)Hp * Wp * cpad0 * sizeof(T), [&] {
+        hipLaunchKernelGGL(pack_input_kernel<T>, dim3(cdiv(Wp, 64), Hp), dim3(256), 0, cur_stream, p);
+        WX_HIP(hipGetLastError());
+      });
+      capture("pad", xin + ((int64_t)halo * (Wp + 2 * halo) + halo) * cpad0, Hp, Wp, C_in, cpad0, Wp + 2 * halo);
+    }
+    // encoder
+    for (int s = 0; s < 4; ++s) {
+      const StageL& st = stages[s];
+      T* x = stream_ptr(s);
+      const int64_t ld = stream_ld(s);
+      int choff = 0;
+      for (size_t b = 0; b < st.embed.size(); ++b) {
+        const int k = st.embed_k[b], stv = cfg.embed_strides[s], pd = (k - stv) / 2;
+        if (s == 0)
+          gemm("gemm_embed", st.embed[b], xin, Hp + 2 * halo, Wp + 2 * halo, cpad0, stv, pd - halo, pd - halo, sh[0], sw[0],
+               x + choff, ld, nullptr, 0, nullptr, 0);
+        else
+          gemm("gemm_embed", st.embed[b], stream_ptr(s - 1), sh[s - 1], sw[s - 1], stream_ld(s - 1), stv, pd, pd, sh[s], sw[s],
+               x + choff, ld, nullptr, 0, nullptr, 0);
+        choff += st.embed[b].n;
+      }
+      const std::string sp = "layers." + std::to_string(s);
+      capture(sp + ".0", x, sh[s], sw[s], cfg.dim[s], ld, sw[s]);
+      for (size_t d = 0; d < st.blocks.size(); ++d) {
+        const std::string bp = sp + ".1.layers." + std::to_string(d);
+        attention(st.blocks[d].sa, s, bp + ".0");
+        feedforward(st.blocks[d].sf, s, bp + ".1");
+        attention(st.blocks[d].la, s, bp + ".2");
+        feedforward(st.blocks[d].lf, s, bp + ".3");
+      }
+      capture(sp + ".1", x, sh[s], sw[s], cfg.dim[s], ld, sw[s]);
+    }
+    // decoder
+    for (int i = 0; i < 3; ++i) {
+      const UpL& u = ups[i];
+      const int si = 3 - i;             // input stage map
+      const int so = 2 - i;             // output stage map
+      const T* in = (i == 0) ? x3 : cat[si];
+      const int64_t in_ld = (i == 0) ? cfg.dim[3] : 2 * cfg.dim[si];
+      const int64_t mo = (int64_t)sh[so] * sw[so];
+      T *scut = dtmp[0], *ta = dtmp[1], *tb = dtmp[2];
+      gemm("gemm_convT2", u.convt, in, sh[si], sw[si], in_ld, 1, 0, 0, sh[si], sw[si], scut, u.cout, nullptr, 0, nullptr, 0, 1, u.cout);
+      gemm("gemm_conv3", u.c1, scut, sh[so], sw[so], u.cout, 1, 1, 1, sh[so], sw[so], ta, u.cout, nullptr, 0, nullptr, 0);
+      group_norm_silu(ta, u.cout, mo, u.g1, u.b1, nullptr, 0, tb, u.cout);
+      gemm("gemm_conv3", u.c2, tb, sh[so], sw[so], u.cout, 1, 1, 1, sh[so], sw[so], ta, u.cout, nullptr, 0, nullptr, 0);
+      group_norm_silu(ta, u.cout, mo, u.g2, u.b2, scut, u.cout, cat[so], 2 * cfg.dim[so]);
+      capture("up_block" + std::to_string(i + 1), cat[so], sh[so], sw[so], u.cout, 2 * cfg.dim[so], sw[so]);
+    }
+    for (int q = 0; q < 4; ++q) {
+      const int py = q >> 1, px = q & 1;
+      gemm("gemm_convT4", up4[q], cat[0], sh[0], sw[0], 2 * cfg.dim[0], 1, 1 - py, 1 - px, sh[0], sw[0], dec, ld_dec, nullptr, 0,
+           nullptr, 0, 2, 0, py, px);
+    }
+    capture("up_block4", dec, Hd, Wd, C_out, ld_dec, Wd);
+  }
+  void tail(float* y, float* y_phys, float* x_next) {
+    TailParams p;
+    p.dec = dec; p.ld = ld_dec; p.Hd = Hd; p.Wd = Wd;
+    p.off_y = cfg.pad_activate ? cfg.pad_lat[0] : 0; p.off_x = cfg.pad_activate ? cfg.pad_lon[0] : 0;
+    p.Hu = Hu; p.Wu = Wu; p.H = Ho; p.W = Wo; p.C = C_out; p.interp = cfg.interp;
+    p.y = y; p.y_phys = y_phys; p.x_next = x_next; p.n_prog = n_prog < 0 ? 0 : n_prog;
+    p.mean = have_denorm ? d_mean : nullptr; p.stdv = have_denorm ? d_std : nullptr;
+    p.thr_lo = have_tracer ? d_lo : nullptr; p.thr_hi = have_tracer ? d_hi : nullptr;
+    p.tracer_denorm = tracer_denorm;
+    const size_t lds = (size_t)C_out * 65 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+      WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done = true;
+    }
+    if (lds > 160 * 1024) throw ConfigError("too many output channels for the tail kernel");
+    const double plane = (double)Ho * Wo * C_out;
+    timed("tail", 0.0, plane * (2.0 * sizeof(T) + 4.0 * ((y ? 1 : 0) + (y_phys ? 1 : 0)) + (x_next ? 4.0 : 0.0)), [&] {
+      hipLaunchKernelGGL(tail_kernel<T>, dim3(cdiv(Wo, 64), Ho), dim3(256), lds, cur_stream, p);
+      WX_HIP(hipGetLastError());
+    });
+  }
+  void check_ready() {
+    if (!finalized) throw StateError("weights not finalized (call wx_finalize_weights after loading every tensor)");
+    WX_HIP(hipSetDevice(device));
+  }
+  void forward(const float* x, float* y, int batch, hipStream_t s) override {
+    check_ready();
+    if (batch < 1) throw ConfigError("batch must be >= 1");
+    cur_stream = s;
+    const int64_t in_item = (int64_t)C_in * cfg.image_height * cfg.image_width;
+    const int64_t out_item = (int64_t)C_out * Ho * Wo;
+    for (int b = 0; b < batch; ++b) {
+      core(x + b * in_item);
+      tail(y + b * out_item, nullptr, nullptr);
+    }
+    if (prof_on) drain();
+  }
+  void step(const float* x, const float* frc, float* y, float* y_phys, float* x_next, hipStream_t s) override {
+    check_ready();
+    if (cfg.frames != 1 || cfg.output_frames != 1) throw ConfigError("wx_step needs frames == output_frames == 1");
+    if (x_next) {
+      if (n_prog < 0) throw StateError("wx_step with x_next needs wx_set_layout first");
+      if (x_next == x) throw ConfigError("x_next may not alias x");
+      if (n_dyn > 0 && !frc) throw ConfigError("forcing pointer is NULL but the layout has dynamic forcing channels");
+      if (Ho != cfg.image_height || Wo != cfg.image_width) throw ConfigError("wx_step needs output size == input size");
+    }
+    if (y_phys && !have_denorm) throw StateError("wx_step with y_phys needs wx_set_denorm first");
+    cur_stream = s;
+    core(x);
+    tail(y, y_phys, x_next);
+    if (x_next) {
+      const int64_t plane = (int64_t)cfg.image_height * cfg.image_width;
+      if (n_static > 0)
+        WX_HIP(hipMemcpyAsync(x_next + n_prog * plane, x + n_prog * plane, n_static * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
+      if (n_dyn > 0)
+        WX_HIP(hipMemcpyAsync(x_next + (n_prog + n_static) * plane, frc, n_dyn * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (prof_on) drain();
+  }
+};
+
+}  // namespace wx
+
+// ======================================================================================= C ABI
+struct wx_engine {
+  std::unique_ptr<wx::EngineBase> impl;
+};
+
+template <typename F>
+static int guarded(F&& fn) {
+  try {
+    fn();
+    return WX_OK;
+  } catch (const wx::ConfigError& e) { wx::g_last_error = e.what(); return WX_ERR_INVALID;
+  } catch (const wx::StateError& e) { wx::g_last_error = e.what(); return WX_ERR_STATE;
+  } catch (const wx::MissingError& e) { wx::g_last_error = e.what(); return WX_ERR_MISSING;
+  } catch (const wx::ShapeError& e) { wx::g_last_error = e.what(); return WX_ERR_SHAPE;
+  } catch (const wx::HipError& e) { wx::g_last_error = e.what(); return WX_ERR_HIP;
+  } catch (const std::exception& e) { wx::g_last_error = e.what(); return WX_ERR_INVALID; }
+}
+#define WX_NEED(h) if (!(h) || !(h)->impl) throw wx::ConfigError("null engine handle")
+
+extern "C" {
+
+int wx_create(const wx_config* cfg, int device, wx_handle* out) {
+  return guarded([&] {
+    if (!cfg || !out) throw wx::ConfigError("wx_create: null argument");
+    int ndev = 0;
+    WX_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) throw wx::ConfigError("wx_create: no such GPU device");
+    WX_HIP(hipSetDevice(device));
+    std::unique_ptr<wx_engine> h(new wx_engine);
+    if (cfg->precision == WX_PREC_FP32) h->impl.reset(new wx::Engine<float>(*cfg, device));
+    else if (cfg->precision == WX_PREC_BF16) h->impl.reset(new wx::Engine<wx::bf16_t>(*cfg, device));
+    else throw wx::ConfigError("wx_create: unknown precision");
+    *out = h.release();
+  });
+}
+int wx_destroy(wx_handle h) {
+  return guarded([&] { delete h; });
+}
+int wx_load_tensor(wx_handle h, const char* key, const float* data, int ndim, const int64_t* shape) {
+  return guarded([&] { WX_NEED(h); if (!key || !data || !shape) throw wx::ConfigError("wx_load_tensor: null argument"); h->impl->load_tensor(key, data, ndim, shape); });
+}
+int wx_finalize_weights(wx_handle h) { return guarded([&] { WX_NEED(h); h->impl->finalize(); }); }
+int wx_num_tensors(wx_handle h) { return (h && h->impl) ? h->impl->num_tensors() : WX_ERR_INVALID; }
+int wx_tensor_info(wx_handle h, int index, const char** key, int* ndim, int64_t shape[8]) {
+  return guarded([&] { WX_NEED(h); h->impl->tensor_info(index, key, ndim, shape); });
+}
+int wx_set_denorm(wx_handle h, const float* mean, const float* stdv, int n) {
+  return guarded([&] { WX_NEED(h); if (!mean || !stdv) throw wx::ConfigError("wx_set_denorm: null argument"); h->impl->set_denorm(mean, stdv, n); });
+}
+int wx_set_tracer_fixer(wx_handle h, const int32_t* inds, const float* thres, const float* thres_max, int n, int denorm) {
+  return guarded([&] { WX_NEED(h); if (n > 0 && (!inds || !thres)) throw wx::ConfigError("wx_set_tracer_fixer: null argument"); h->impl->set_tracer(inds, thres, thres_max, n, denorm); });
+}
+int wx_set_layout(wx_handle h, int n_prog, int n_static, int n_dyn) {
+  return guarded([&] { WX_NEED(h); h->impl->set_layout(n_prog, n_static, n_dyn); });
+}
+int wx_forward(wx_handle h, const float* x_dev, float* y_dev, int batch, void* stream) {
+  return guarded([&] { WX_NEED(h); if (!x_dev || !y_dev) throw wx::ConfigError("wx_forward: null pointer"); h->impl->forward(x_dev, y_dev, batch, (hipStream_t)stream); });
+}
+int wx_step(wx_handle h, const float* x_dev, const float* frc_dev, float* y_dev, float* y_phys_dev, float* x_next_dev, void* stream) {
+  return guarded([&] { WX_NEED(h); if (!x_dev) throw wx::ConfigError("wx_step: null input"); h->impl->step(x_dev, frc_dev, y_dev, y_phys_dev, x_next_dev, (hipStream_t)stream); });
+}
+int wx_set_comm(wx_handle h, void* nccl_comm, int rank, int nranks) {
+  return guarded([&] {
+    WX_NEED(h);
+    (void)nccl_comm; (void)rank;
+    if (nranks != 1) throw wx::ConfigError("lat-band sharding is not built yet: run one replica per GPU (SURVEY.md §8(e) 'replicas')");
+  });
+}
+int wx_set_debug(wx_handle h, int enable) { return guarded([&] { WX_NEED(h); h->impl->set_debug(enable); }); }
+int wx_debug_read(wx_handle h, const char* name, float* host_out, int64_t capacity, int64_t shape[3]) {
+  return guarded([&] { WX_NEED(h); if (!name || !shape) throw wx::ConfigError("wx_debug_read: null argument"); h->impl->debug_read(name, host_out, capacity, shape); });
+}
+int wx_profile(wx_handle h, int enable) { return guarded([&] { WX_NEED(h); h->impl->profile(enable); }); }
+int wx_profile_reset(wx_handle h) { return guarded([&] { WX_NEED(h); h->impl->profile_reset(); }); }
+int wx_profile_read(wx_handle h, wx_kernel_stat* out, int capacity, int* count) {
+  return guarded([&] { WX_NEED(h); if (!out || !count) throw wx::ConfigError("wx_profile_read: null argument"); *count = h->impl->profile_read(out, capacity); });
+}
+const char* wx_last_error(void) { return wx::g_last_error.c_str(); }
+const char* wx_version(void) { return "wxengine 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,321 @@
+// Implicit-GEMM convolution on MFMA for token-major (H, W, C) activations.
+//
+//   out[pix(m), n] = epilogue( sum_{ky,kx,c} in[(oy*s - pad_y + ky), (ox*s - pad_x + kx), c] * wt[n][ky][kx][c] )
+//
+// One kernel serves every GEMM-shaped op of the CrossFormer step: the multi-scale
+// strided CrossEmbed convs (a2), the 1x1 convs of attention / feed-forward with the
+// channel-LayerNorm folded into the epilogue (a3, a4, a6), the decoder's 3x3 convs,
+// ConvTranspose k2s2 (a GEMM whose epilogue scatters 2x2 pixels) and ConvTranspose
+// k4s2p1 (four 2x2-tap parity convs) (a8).  SURVEY.md §8(a).
+//
+// MFMA mapping (gfx950): D = A.B with A = weight fragment (16 output channels x K),
+// B = activation fragment (K x 16 pixels); D[row = channel (lane>>4)*4+r][col = pixel lane&15],
+// so every lane ends up with 4 consecutive channels of one pixel -> one 8/16-byte store.
+//   T = bf16 : v_mfma_f32_16x16x32_bf16 (fp32 accumulate)
+//   T = float: v_mfma_f32_16x16x4_f32   (exact f32, k-ordered fma chain)
+// Both fragment kinds are read from LDS with the same addressing: lane (i = lane&15, g = lane>>4)
+// reads the 16 bytes at row i, byte offset sub*64 + g*16 of a K-step; the contraction is
+// order-agnostic as long as A and B agree on the (step, g) -> k mapping, which they do.
+#pragma once
+#include "wx_common.h"
+
+namespace wx {
+
+struct ConvGemmParams {
+  const void* in;      // activations, element type T
+  int in_h, in_w;      // logical size for bounds checks (out-of-range taps read as 0)
+  int64_t in_ld;       // elements between consecutive pixels
+  int cin;             // channels contracted per tap (cin*sizeof(T) % KB == 0)
+  int kh, kw, stride, pad_y, pad_x;
+  int out_h, out_w;    // M = out_h*out_w output positions
+  const void* wt;      // [n_alloc][kh*kw*cin] K-contiguous, element type T
+  int n;               // logical output channels
+  int n_alloc;         // rows present in wt (rows >= n are zero)
+  const float* bias;   // [n] or nullptr
+  const float2* rowstat;  // [M] (mean, rstd) of the input pixel, or nullptr  (LayerNorm fold)
+  const float* colsum;    // [n] sum_c wt[n][c] (with rowstat)
+  int act;             // 0 none, 1 exact GELU
+  const void* res;     // residual added after activation (indexed like out), or nullptr
+  int64_t res_ld;
+  void* out;
+  int64_t out_ld;
+  int out_mode;        // 0: pixel m, channel n
+                       // 1: ConvT k2s2: n = q*cout + co, q = dy*2+dx -> pixel (2oy+dy, 2ox+dx), channel co
+                       // 2: parity conv: pixel (2oy+py, 2ox+px), channel n
+  int cout;            // mode 1: channels per sub-pixel
+  int py, px;          // mode 2
+};
+
+template <typename T>
+__device__ inline f32x4_t mma_sub(const uint4& a, const uint4& b, f32x4_t acc);
+template <>
+__device__ inline f32x4_t mma_sub<bf16_t>(const uint4& a, const uint4& b, f32x4_t acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
+                                                 0, 0, 0);
+}
+template <>
+__device__ inline f32x4_t mma_sub<float>(const uint4& a, const uint4& b, f32x4_t acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+  return acc;
+}
+
+template <typename T>
+__device__ inline void load4(const T* p, float* v);
+template <>
+__device__ inline void load4<float>(const float* p, float* v) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <>
+__device__ inline void load4<bf16_t>(const bf16_t* p, float* v) {
+  const uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __builtin_bit_cast(float, t.x << 16); v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, t.y << 16); v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+}
+template <typename T>
+__device__ inline void store4(T* p, const float* v);
+template <>
+__device__ inline void store4<float>(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ inline void store4<bf16_t>(bf16_t* p, const float* v) {
+  uint2 t;
+  t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = t;
+}
+
+// KB = bytes of K contracted per pipeline step and per tile row (64 or 128).
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_gemm_kernel(const ConvGemmParams p) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int BKE = KB / (int)sizeof(T);
+  constexpr int PPR = KB / 16;  // 16-byte pieces per tile row
+  constexpr int SUBS = KB / 64;
+  constexpr int ROWB = KB + 16;  // padded LDS row stride (bytes)
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int A_PER_T = (BM * PPR + NT - 1) / NT;
+  constexpr int B_PER_T = (BN * PPR + NT - 1) / NT;
+  constexpr int TILE_BYTES = (BM + BN) * ROWB;
+  static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+  const int li = lane & 15, g = lane >> 4;
+
+  const int M = p.out_h * p.out_w;
+  const int n_tiles = (p.n + BN - 1) / BN;
+  const int tile_n = blockIdx.x % n_tiles;
+  const int tile_m = blockIdx.x / n_tiles;
+  const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+
+  const int cchunks = p.cin / BKE;
+  const int nk = p.kh * p.kw * cchunks;
+  const int64_t ktot = (int64_t)p.kh * p.kw * p.cin;
+
+  const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
+  const T* __restrict__ wt = reinterpret_cast<const T*>(p.wt);
+
+  // per-thread staging coordinates (fixed across the K loop)
+  int a_iy0[A_PER_T], a_ix0[A_PER_T];
+  bool a_ok[A_PER_T];
+  int a_lds[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int piece = tid + i * NT;
+    const int row = piece / PPR;
+    const int m = m_blk + row;
+    a_ok[i] = (piece < BM * PPR) && (m < M);
+    const int oy = m / p.out_w, ox = m - oy * p.out_w;
+    a_iy0[i] = oy * p.stride - p.pad_y;
+    a_ix0[i] = ox * p.stride - p.pad_x;
+    a_lds[i] = row * ROWB + (piece % PPR) * 16;
+  }
+  const T* b_src[B_PER_T];
+  bool b_ok[B_PER_T];
+  int b_lds[B_PER_T];
+#pragma unroll
+  for (int i = 0; i < B_PER_T; ++i) {
+    const int piece = tid + i * NT;
+    const int row = piece / PPR;
+    const int n = n_blk + row;
+    b_ok[i] = (piece < BN * PPR) && (n < p.n_alloc);
+    b_src[i] = wt + (int64_t)n * ktot + (piece % PPR) * VEC;
+    b_lds[i] = BM * ROWB + row * ROWB + (piece % PPR) * 16;
+  }
+  const int a_coff = (tid % PPR) * VEC;  // NT % PPR == 0, so piece % PPR == tid % PPR
+
+  uint4 ra[A_PER_T], rb[B_PER_T];
+  int ky = 0, kx = 0, cc = 0;  // coordinates of the K-step being fetched
+
+  auto fetch = [&](int ks) {
+    const int c0 = cc * BKE + a_coff;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+      const bool ok = a_ok[i] && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+      ra[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (ok) ra[i] = *reinterpret_cast<const uint4*>(in + ((int64_t)iy * p.in_w + ix) * p.in_ld + c0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      rb[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (b_ok[i]) rb[i] = *reinterpret_cast<const uint4*>(b_src[i] + (int64_t)ks * BKE);
+    }
+    if (++cc == cchunks) {
+      cc = 0;
+      if (++kx == p.kw) { kx = 0; ++ky; }
+    }
+  };
+  auto stash = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i)
+      if (tid + i * NT < BM * PPR) *reinterpret_cast<uint4*>(buf + a_lds[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i)
+      if (tid + i * NT < BN * PPR) *reinterpret_cast<uint4*>(buf + b_lds[i]) = rb[i];
+  };
+
+  f32x4_t acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int x_frag = (wm * WM + li) * ROWB + g * 16;             // activation fragment base
+  const int w_frag = BM * ROWB + (wn * WN + li) * ROWB + g * 16;  // weight fragment base
+
+  fetch(0);
+  stash(smem);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    char* cur = smem + (ks & 1) * TILE_BYTES;
+    if (ks + 1 < nk) fetch(ks + 1);
+#pragma unroll
+    for (int s = 0; s < SUBS; ++s) {
+      uint4 xf[FM], wf[FN];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const uint4*>(cur + x_frag + b * 16 * ROWB + s * 64);
+#pragma unroll
+      for (int a = 0; a < FN; ++a) wf[a] = *reinterpret_cast<const uint4*>(cur + w_frag + a * 16 * ROWB + s * 64);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<T>(wf[a], xf[b], acc[a][b]);
+    }
+    if (ks + 1 < nk) stash(smem + ((ks + 1) & 1) * TILE_BYTES);
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int m = m_blk + wm * WM + b * 16 + li;
+    if (m >= M) continue;
+    float mean = 0.f, rstd = 1.f;
+    if (p.rowstat) {
+      const float2 st = p.rowstat[m];
+      mean = st.x;
+      rstd = st.y;
+    }
+    const int oy = m / p.out_w, ox = m - oy * p.out_w;
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const int n0 = n_blk + wn * WN + a * 16 + g * 4;
+      if (n0 >= p.n) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + r;
+        float t = acc[a][b][r];
+        if (n < p.n) {
+          if (p.rowstat) t = rstd * (t - mean * p.colsum[n]);
+          if (p.bias) t += p.bias[n];
+          if (p.act == 1) t = gelu_erf(t);
+        }
+        v[r] = t;
+      }
+      int64_t pix;
+      int ch;
+      if (p.out_mode == 0) {
+        pix = m;
+        ch = n0;
+      } else if (p.out_mode == 1) {
+        const int q = n0 / p.cout;
+        ch = n0 - q * p.cout;
+        pix = (int64_t)(2 * oy + (q >> 1)) * (2 * p.out_w) + 2 * ox + (q & 1);
+      } else {
+        pix = (int64_t)(2 * oy + p.py) * (2 * p.out_w) + 2 * ox + p.px;
+        ch = n0;
+      }
+      if (n0 + 3 < p.n) {
+        if (res) {
+          float rv[4];
+          load4<T>(res + pix * p.res_ld + ch, rv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        }
+        store4<T>(out + pix * p.out_ld + ch, v);
+      } else {
+        for (int r = 0; r < 4 && n0 + r < p.n; ++r) {
+          float t = v[r];
+          if (res) t += Elem<T>::to_f(res[pix * p.res_ld + ch + r]);
+          out[pix * p.out_ld + ch + r] = Elem<T>::from_f(t);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB>
+inline void launch_conv_gemm_cfg(const ConvGemmParams& p, hipStream_t stream) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int LDS = 2 * (BM + BN) * (KB + 16);
+  auto kern = conv_gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, KB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
+  }
+  const int M = p.out_h * p.out_w;
+  const int64_t blocks = (int64_t)cdiv(M, BM) * cdiv(p.n, BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), LDS, stream, p);
+  WX_HIP(hipGetLastError());
+}
+
+template <typename T, int KB>
+inline void launch_conv_gemm_kb(const ConvGemmParams& p, hipStream_t stream) {
+  if (p.n >= 96)
+    launch_conv_gemm_cfg<T, 128, 128, 2, 2, KB>(p, stream);
+  else if (p.n >= 48)
+    launch_conv_gemm_cfg<T, 128, 64, 2, 2, KB>(p, stream);
+  else if (p.n >= 24)
+    launch_conv_gemm_cfg<T, 256, 32, 4, 1, KB>(p, stream);
+  else
+    launch_conv_gemm_cfg<T, 256, 16, 4, 1, KB>(p, stream);
+}
+
+template <typename T>
+inline void launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
+  const int row_bytes = p.cin * (int)sizeof(T);
+  if (row_bytes % 128 == 0)
+    launch_conv_gemm_kb<T, 128>(p, stream);
+  else if (row_bytes % 64 == 0)
+    launch_conv_gemm_kb<T, 64>(p, stream);
+  else
+    throw std::runtime_error("conv_gemm: cin*sizeof(T) must be a multiple of 64 bytes");
+}
+
+}  // namespace wx

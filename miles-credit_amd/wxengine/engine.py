@@ -1,0 +1,257 @@
+"""ctypes binding of libwxengine.so (C ABI in include/wxengine.h).
+
+PyTorch is used only as the owner of device memory and streams: tensors are handed to
+the engine as raw device pointers.  There is NO CPU fallback: if the HIP library is
+missing or no GPU is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from .config import WXConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwxengine.so")
+
+WX_ABI_VERSION = 1
+PREC = {"fp32": 0, "bf16": 1}
+
+
+class wx_config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("frames", C.c_int32), ("output_frames", C.c_int32),
+        ("channels", C.c_int32), ("surface_channels", C.c_int32), ("input_only_channels", C.c_int32),
+        ("output_only_channels", C.c_int32), ("levels", C.c_int32),
+        ("dim", C.c_int32 * 4), ("depth", C.c_int32 * 4), ("dim_head", C.c_int32),
+        ("global_window_size", C.c_int32 * 4), ("local_window_size", C.c_int32 * 4),
+        ("n_embed_kernels", C.c_int32 * 4), ("embed_kernels", (C.c_int32 * 4) * 4), ("embed_strides", C.c_int32 * 4),
+        ("pad_activate", C.c_int32), ("pad_lat", C.c_int32 * 2), ("pad_lon", C.c_int32 * 2),
+        ("interp", C.c_int32), ("use_spectral_norm", C.c_int32), ("precision", C.c_int32), ("max_batch", C.c_int32),
+    ]
+
+
+class wx_kernel_stat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+class WXEngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_PROTOTYPES = {
+    "wx_create": ([C.POINTER(wx_config), C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    "wx_load_tensor": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int64)], C.c_int),
+    "wx_finalize_weights": ([C.c_void_p], C.c_int),
+    "wx_destroy": ([C.c_void_p], C.c_int),
+    "wx_num_tensors": ([C.c_void_p], C.c_int),
+    "wx_tensor_info": ([C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int64)], C.c_int),
+    "wx_set_denorm": ([C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int], C.c_int),
+    "wx_set_tracer_fixer": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int], C.c_int),
+    "wx_set_layout": ([C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_int),
+    "wx_forward": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
+    "wx_step": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "wx_set_comm": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int], C.c_int),
+    "wx_set_debug": ([C.c_void_p, C.c_int], C.c_int),
+    "wx_debug_read": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)], C.c_int),
+    "wx_profile": ([C.c_void_p, C.c_int], C.c_int),
+    "wx_profile_reset": ([C.c_void_p], C.c_int),
+    "wx_profile_read": ([C.c_void_p, C.POINTER(wx_kernel_stat), C.c_int, C.POINTER(C.c_int)], C.c_int),
+    "wx_last_error": ([], C.c_char_p),
+    "wx_version": ([], C.c_char_p),
+}
+
+
+def exported_symbols():
+    return sorted(_PROTOTYPES)
+
+
+def load_library():
+    """dlopen libwxengine.so (torch must be imported first so its bundled HIP runtime is the one bound)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WXEngineError(f"{LIB_PATH} not found: build it with `python miles-credit_amd/build.py` "
+                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    import torch  # noqa: F401  (loads libamdhip64 with the SONAME our library needs)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (args, res) in _PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def _check(status: int):
+    if status != 0:
+        msg = load_library().wx_last_error().decode()
+        raise WXEngineError(f"wxengine error {status}: {msg}")
+
+
+def make_c_config(cfg: WXConfig, precision: str = "bf16", max_batch: int = 1) -> wx_config:
+    c = wx_config()
+    c.abi_version = WX_ABI_VERSION
+    for f in ("image_height", "image_width", "frames", "output_frames", "channels", "surface_channels",
+              "input_only_channels", "output_only_channels", "levels", "dim_head"):
+        setattr(c, f, int(getattr(cfg, f)))
+    for i in range(4):
+        c.dim[i] = cfg.dim[i]
+        c.depth[i] = cfg.depth[i]
+        c.global_window_size[i] = cfg.global_window_size[i]
+        c.local_window_size[i] = cfg.local_window_size[i]
+        ks = cfg.cross_embed_kernel_sizes[i]
+        c.n_embed_kernels[i] = len(ks)
+        for j, k in enumerate(ks):
+            c.embed_kernels[i][j] = k
+        c.embed_strides[i] = cfg.cross_embed_strides[i]
+    c.pad_activate = int(cfg.pad_activate)
+    c.pad_lat[0], c.pad_lat[1] = cfg.pad_lat
+    c.pad_lon[0], c.pad_lon[1] = cfg.pad_lon
+    c.interp = int(cfg.interp)
+    c.use_spectral_norm = int(cfg.use_spectral_norm)
+    c.precision = PREC[precision]
+    c.max_batch = max_batch
+    return c
+
+
+class WXEngine:
+    """Owns one wx_handle.  Inputs/outputs are torch CUDA (HIP) tensors, float32, contiguous."""
+
+    def __init__(self, cfg: WXConfig, precision: str = "bf16", device: int = 0):
+        import torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise WXEngineError("no GPU visible: the wxengine HIP path cannot run and there is no CPU fallback")
+        self.cfg = cfg
+        self.precision = precision
+        self.device = device
+        self._h = C.c_void_p()
+        cc = make_c_config(cfg, precision)
+        _check(self.lib.wx_create(C.byref(cc), device, C.byref(self._h)))
+        self._finalized = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self.lib.wx_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---- weights -----------------------------------------------------------------
+    def expected_tensors(self) -> Dict[str, Tuple[int, ...]]:
+        out = {}
+        key = C.c_char_p()
+        nd = C.c_int()
+        shape = (C.c_int64 * 8)()
+        for i in range(self.lib.wx_num_tensors(self._h)):
+            _check(self.lib.wx_tensor_info(self._h, i, C.byref(key), C.byref(nd), shape))
+            out[key.value.decode()] = tuple(shape[d] for d in range(nd.value))
+        return out
+
+    def load_state_dict(self, sd) -> None:
+        """sd: mapping key -> numpy array / torch tensor (reference state-dict layout)."""
+        for k, v in sd.items():
+            if hasattr(v, "detach"):
+                v = v.detach().to("cpu").float().numpy()
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            shp = (C.c_int64 * max(a.ndim, 1))(*a.shape) if a.ndim else (C.c_int64 * 1)(1)
+            _check(self.lib.wx_load_tensor(self._h, k.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), max(a.ndim, 1), shp))
+        self._finalized = False
+
+    def finalize(self) -> None:
+        _check(self.lib.wx_finalize_weights(self._h))
+        self._finalized = True
+
+    # ---- glue configuration --------------------------------------------------------
+    def set_denorm(self, mean, std) -> None:
+        m = np.ascontiguousarray(mean, dtype=np.float32).ravel()
+        s = np.ascontiguousarray(std, dtype=np.float32).ravel()
+        _check(self.lib.wx_set_denorm(self._h, m.ctypes.data_as(C.POINTER(C.c_float)), s.ctypes.data_as(C.POINTER(C.c_float)), m.size))
+
+    def set_tracer_fixer(self, inds, thres, thres_max=None, denorm: bool = False) -> None:
+        i = np.ascontiguousarray(inds, dtype=np.int32)
+        t = np.ascontiguousarray(thres, dtype=np.float32)
+        tm = None if thres_max is None else np.ascontiguousarray(thres_max, dtype=np.float32)
+        _check(self.lib.wx_set_tracer_fixer(
+            self._h, i.ctypes.data_as(C.POINTER(C.c_int32)), t.ctypes.data_as(C.POINTER(C.c_float)),
+            None if tm is None else tm.ctypes.data_as(C.POINTER(C.c_float)), i.size, int(denorm)))
+
+    def set_layout(self, n_prog: int, n_static: int, n_dyn: int) -> None:
+        _check(self.lib.wx_set_layout(self._h, n_prog, n_static, n_dyn))
+
+    # ---- hot path -------------------------------------------------------------------
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _chk_in(self, t, name):
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise WXEngineError(f"{name} must be a contiguous float32 tensor on the GPU")
+
+    def forward(self, x, out=None):
+        import torch
+        self._chk_in(x, "x")
+        cfg = self.cfg
+        if x.dim() == 4:
+            x = x.unsqueeze(2)
+        b = x.shape[0]
+        if tuple(x.shape[1:]) != (cfg.base_input_channels, cfg.frames, cfg.image_height, cfg.image_width):
+            raise WXEngineError(f"x has shape {tuple(x.shape)}, expected [B, {cfg.base_input_channels}, {cfg.frames}, "
+                                f"{cfg.image_height}, {cfg.image_width}]")
+        oh, ow = cfg.out_hw
+        if out is None:
+            out = torch.empty((b, cfg.base_output_channels, cfg.output_frames, oh, ow), dtype=torch.float32, device=x.device)
+        _check(self.lib.wx_forward(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), b, self._stream()))
+        return out
+
+    def step(self, x, frc=None, want_y=True, want_phys=True, want_next=True):
+        """One rollout iteration. Returns (y, y_phys, x_next); entries are None when not requested."""
+        import torch
+        self._chk_in(x, "x")
+        cfg = self.cfg
+        oh, ow = cfg.out_hw
+        y = torch.empty((1, cfg.base_output_channels, 1, oh, ow), dtype=torch.float32, device=x.device) if want_y else None
+        yp = torch.empty((1, cfg.base_output_channels, oh, ow), dtype=torch.float32, device=x.device) if want_phys else None
+        xn = torch.empty_like(x) if want_next else None
+        if frc is not None:
+            self._chk_in(frc, "frc")
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        _check(self.lib.wx_step(self._h, p(x), p(frc), p(y), p(yp), p(xn), self._stream()))
+        return y, yp, xn
+
+    # ---- introspection -----------------------------------------------------------------
+    def set_debug(self, on: bool) -> None:
+        _check(self.lib.wx_set_debug(self._h, int(on)))
+
+    def debug_read(self, name: str) -> np.ndarray:
+        shape = (C.c_int64 * 3)()
+        _check(self.lib.wx_debug_read(self._h, name.encode(), None, 0, shape))
+        out = np.empty((shape[0], shape[1], shape[2]), dtype=np.float32)
+        _check(self.lib.wx_debug_read(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, shape))
+        return out
+
+    def profile(self, on: bool) -> None:
+        _check(self.lib.wx_profile(self._h, int(on)))
+
+    def profile_reset(self) -> None:
+        _check(self.lib.wx_profile_reset(self._h))
+
+    def profile_read(self):
+        arr = (wx_kernel_stat * 64)()
+        n = C.c_int()
+        _check(self.lib.wx_profile_read(self._h, arr, 64, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops,
+                     bytes=arr[i].bytes) for i in range(n.value)]
