@@ -217,17 +217,21 @@ class WXEngine:
         _check(self.lib.wx_forward(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), b, self._stream()))
         return out
 
-    def step(self, x, frc=None, want_y=True, want_phys=True, want_next=True):
-        """One rollout iteration. Returns (y, y_phys, x_next); entries are None when not requested."""
+    def step(self, x, frc=None, want_y=True, want_phys=True, want_next=True, y_out=None, phys_out=None, next_out=None):
+        """One rollout iteration. Returns (y, y_phys, x_next); entries are None when not requested.
+        Pre-allocated outputs may be passed (y_out / phys_out / next_out) to keep the loop allocation-free."""
         import torch
         self._chk_in(x, "x")
         cfg = self.cfg
         oh, ow = cfg.out_hw
-        y = torch.empty((1, cfg.base_output_channels, 1, oh, ow), dtype=torch.float32, device=x.device) if want_y else None
-        yp = torch.empty((1, cfg.base_output_channels, oh, ow), dtype=torch.float32, device=x.device) if want_phys else None
-        xn = torch.empty_like(x) if want_next else None
-        if frc is not None:
-            self._chk_in(frc, "frc")
+        y = y_out if y_out is not None else (
+            torch.empty((1, cfg.base_output_channels, 1, oh, ow), dtype=torch.float32, device=x.device) if want_y else None)
+        yp = phys_out if phys_out is not None else (
+            torch.empty((1, cfg.base_output_channels, oh, ow), dtype=torch.float32, device=x.device) if want_phys else None)
+        xn = next_out if next_out is not None else (torch.empty_like(x) if want_next else None)
+        for t, name in ((y, "y_out"), (yp, "phys_out"), (xn, "next_out"), (frc, "frc")):
+            if t is not None:
+                self._chk_in(t, name)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         _check(self.lib.wx_step(self._h, p(x), p(frc), p(y), p(yp), p(xn), self._stream()))
         return y, yp, xn

@@ -1,0 +1,169 @@
+"""Host-side mirror of the reference model interface for the hot path.
+
+`WXFormerHIP` takes the same constructor kwargs as the reference
+`credit.models.crossformer.CrossFormer` (credit/models/crossformer.py:372-401), exposes a
+state dict with the reference's key names (so reference checkpoints load unchanged,
+credit/models/base_model.py:57-87), and implements `forward(x)` by calling the HIP engine
+through the C ABI.  When the reference package is importable it subclasses
+`credit.models.base_model.BaseModel`, so it can be registered with
+`credit.models.register_model("crossformer_hip")` and selected by `model.type` in the YAML
+(credit/models/__init__.py:128-161) — see INTEGRATION.md.
+
+There is no CPU fallback: constructing the engine without the HIP library or a GPU raises.
+"""
+from __future__ import annotations
+
+import copy
+import logging
+import os
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from .config import WXConfig
+from .engine import WXEngine, WXEngineError
+
+logger = logging.getLogger(__name__)
+
+try:  # drop-in: be a real BaseModel when the reference is installed
+    from credit.models.base_model import BaseModel as _Base  # type: ignore
+except Exception:  # noqa: BLE001 - any import problem means "reference not installed"
+    _Base = nn.Module
+
+
+def _mangle(key: str) -> str:
+    return key.replace(".", "::")
+
+
+class WXFormerHIP(_Base):
+    """CrossFormer forward on MI355X. Same kwargs as the reference class; extra kwarg `precision`."""
+
+    def __init__(self, precision: str = "bf16", **model_conf):
+        super().__init__()
+        model_conf = copy.deepcopy(model_conf)
+        self.cfg = WXConfig.from_model_conf(model_conf)
+        self.precision = precision
+        cfg = self.cfg
+        # attributes the reference's callers read (SURVEY.md §8(b) "Constructor")
+        self.image_height, self.image_width = cfg.image_height, cfg.image_width
+        self.frames, self.output_frames = cfg.frames, cfg.output_frames
+        self.channels, self.levels, self.surface_channels = cfg.channels, cfg.levels, cfg.surface_channels
+        self.use_padding, self.use_interp = cfg.pad_activate, cfg.interp
+        self.use_spectral_norm = cfg.use_spectral_norm
+        self.use_post_block = bool(cfg.post_conf.get("activate", False))
+        self._spec = cfg.state_spec()
+        self._store = nn.ParameterDict()
+        for key, shape in self._spec.items():
+            self._store[_mangle(key)] = nn.Parameter(torch.zeros(shape, dtype=torch.float32), requires_grad=False)
+        self._engine: Optional[WXEngine] = None
+        self._dirty = True
+        self._denorm = None
+        self._tracer = self._tracer_from_post_conf(cfg.post_conf)
+
+    # ---- post block (in-model tracer fixer only; other fixers are rejected loudly) ----------------
+    @staticmethod
+    def _tracer_from_post_conf(post_conf: Dict):
+        if not post_conf or not post_conf.get("activate", False):
+            return None
+        for name in ("skebs", "global_mass_fixer", "global_water_fixer", "global_energy_fixer",
+                     "global_energy_fixer_updown"):
+            sub = post_conf.get(name) or {}
+            if sub.get("activate", False) and not sub.get("activate_outside_model", False):
+                raise ValueError(f"post_conf.{name} inside the model is not implemented by the HIP engine")
+        tf = post_conf.get("tracer_fixer") or {}
+        if not tf.get("activate", False):
+            return None
+        if "tracer_inds" not in tf:
+            raise ValueError("post_conf.tracer_fixer.tracer_inds missing (the reference's parser injects it)")
+        return dict(inds=list(tf["tracer_inds"]), thres=list(tf["tracer_thres"]),
+                    thres_max=tf.get("tracer_thres_max"), denorm=bool(tf.get("denorm", False)))
+
+    def set_denorm(self, mean, std):
+        """Per-output-channel statistics (what the reference reads from its scaler files)."""
+        self._denorm = (np.asarray(mean, dtype=np.float32).ravel(), np.asarray(std, dtype=np.float32).ravel())
+        self._dirty = True
+
+    # ---- state dict with reference key names -------------------------------------------------------
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False, **kwargs):
+        out = OrderedDict() if destination is None else destination
+        for key in self._spec:
+            p = self._store[_mangle(key)]
+            out[prefix + key] = p if keep_vars else p.detach()
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        missing, unexpected = [], []
+        for key in self._spec:
+            if key not in state_dict:
+                missing.append(key)
+                continue
+            src = state_dict[key]
+            src = src.detach() if isinstance(src, torch.Tensor) else torch.as_tensor(np.asarray(src))
+            dst = self._store[_mangle(key)]
+            if src.numel() != dst.numel():
+                raise RuntimeError(f"size mismatch for {key}: checkpoint {tuple(src.shape)} vs model {tuple(dst.shape)}")
+            with torch.no_grad():
+                dst.copy_(src.reshape(dst.shape).to(dst.dtype))
+        for key in state_dict:
+            if key not in self._spec:
+                unexpected.append(key)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+        self._dirty = True
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    @classmethod
+    def load_model(cls, conf):
+        """Mirror of BaseModel.load_model (credit/models/base_model.py:57-87)."""
+        conf = copy.deepcopy(conf)
+        save_loc = os.path.expandvars(conf["save_loc"])
+        ckpt = os.path.join(save_loc, "model_checkpoint.pt")
+        if not os.path.isfile(ckpt):
+            ckpt = os.path.join(save_loc, "checkpoint.pt")
+        if not os.path.isfile(ckpt):
+            raise ValueError("No saved checkpoint exists. You must train a model first. Exiting.")
+        checkpoint = torch.load(ckpt, map_location="cpu")
+        conf["model"].pop("type", None)
+        model = cls(**conf["model"])
+        sd = checkpoint["model_state_dict"] if "model_state_dict" in checkpoint else checkpoint
+        model.load_state_dict(sd, strict=False)
+        return model
+
+    # ---- engine ---------------------------------------------------------------------------------------
+    def _sync_engine(self, device: torch.device):
+        if self._engine is None:
+            self._engine = WXEngine(self.cfg, self.precision, device.index or 0)
+            self._dirty = True
+        if self._dirty:
+            self._engine.load_state_dict({k: self._store[_mangle(k)].detach().cpu().numpy() for k in self._spec})
+            self._engine.finalize()
+            if self._denorm is not None:
+                self._engine.set_denorm(*self._denorm)
+            if self._tracer is not None:
+                if self._tracer["denorm"] and self._denorm is None:
+                    raise WXEngineError("tracer_fixer.denorm is True: call set_denorm(mean, std) first")
+                self._engine.set_tracer_fixer(self._tracer["inds"], self._tracer["thres"], self._tracer["thres_max"],
+                                              self._tracer["denorm"])
+            self._dirty = False
+        return self._engine
+
+    @property
+    def engine(self) -> WXEngine:
+        if self._engine is None:
+            raise WXEngineError("engine not built yet: call the model once on a GPU tensor")
+        return self._engine
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise WXEngineError("WXFormerHIP runs only on the GPU (no CPU fallback); move the input to cuda")
+        eng = self._sync_engine(x.device)
+        return eng.forward(x.contiguous().float())
+
+
+def register(model_type: str = "crossformer_hip"):
+    """Register with the reference's registry (credit.models.register_model) when it is importable."""
+    from credit.models import register_model  # type: ignore
+    return register_model(model_type, "Loading the MI355X-native CrossFormer engine ...")(WXFormerHIP)
