@@ -301,6 +301,9 @@ class Engine : public EngineBase {
     while (f_host.size() % 4) f_host.push_back(0.f);
     const int64_t off = (int64_t)f_host.size();
     f_host.insert(f_host.end(), v.begin(), v.end());
+    // pad every block to a multiple of 128 floats: GEMM epilogues read bias/colsum as whole float4 vectors
+    // for a full 128-channel tile even when the layer has fewer channels
+    while ((f_host.size() - off) % 128) f_host.push_back(0.f);
     return off;
   }
   int64_t push_w(const std::vector<double>& rows, int n, int64_t k) {
@@ -531,6 +534,9 @@ class Engine : public EngineBase {
   T* dtmp[3] = {nullptr, nullptr, nullptr};  // decoder temporaries
   T* dec = nullptr;          // up_block4 output [Hd][Wd][ld_dec]
   float2* rowstat = nullptr;
+  char* zero_page = nullptr;
+  bool use_dma = true;
+  int dbg_flags = 0;
   double* gn_acc = nullptr;
   float *gn_scale = nullptr, *gn_shift = nullptr;
   float *d_mean = nullptr, *d_std = nullptr, *d_lo = nullptr, *d_hi = nullptr;
@@ -560,6 +566,10 @@ class Engine : public EngineBase {
     dec = (T*)dalloc((int64_t)Hd * Wd * ld_dec * sizeof(T));
     WX_HIP(hipMemset(dec, 0, (int64_t)Hd * Wd * ld_dec * sizeof(T)));
     rowstat = (float2*)dalloc(max_hw * sizeof(float2));
+    zero_page = (char*)dalloc(256);
+    WX_HIP(hipMemset(zero_page, 0, 256));
+    if (const char* e = getenv("WX_NO_DMA")) use_dma = !(e[0] == '1');
+    if (const char* e = getenv("WX_DBG")) dbg_flags = atoi(e);
     const int cmax = cfg.dim[3];
     gn_acc = (double*)dalloc(2 * cmax * sizeof(double));
     gn_scale = (float*)dalloc(cmax * sizeof(float));
@@ -609,14 +619,15 @@ class Engine : public EngineBase {
   }
 
   // ------------------------------------------------------------------ profiling + debug
-  bool prof_on = false;
+  bool prof_on = false, detail_on = false;
   struct Pending { std::string name; double flops, bytes; int ev; };
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   std::vector<Pending> pending;
   std::map<std::string, KernelStatAcc> stats;
   hipStream_t cur_stream = nullptr;
+  int cur_stage = -1;   // appended to kernel-class names while profiling ("gemm_ff1.s2")
 
-  void profile(int on) override { prof_on = on != 0; }
+  void profile(int on) override { prof_on = on != 0; detail_on = on > 1; }
   void profile_reset() override { drain(); stats.clear(); }
   void drain() {
     if (pending.empty()) return;
@@ -655,7 +666,9 @@ class Engine : public EngineBase {
     WX_HIP(hipEventRecord(ev_pool[idx].first, cur_stream));
     fn();
     WX_HIP(hipEventRecord(ev_pool[idx].second, cur_stream));
-    pending.push_back({name, flops, bytes, idx});
+    std::string nm(name);
+    if (detail_on && cur_stage >= 0) nm += ".s" + std::to_string(cur_stage);
+    pending.push_back({nm, flops, bytes, idx});
   }
 
   bool dbg_on = false;
@@ -700,11 +713,11 @@ class Engine : public EngineBase {
     p.rowstat = rs; p.colsum = (rs && w.colsum >= 0) ? f_dev + w.colsum : nullptr;
     if (rs && w.colsum < 0) throw StateError("LayerNorm-folded GEMM without column sums");
     p.act = act; p.res = res; p.res_ld = res_ld; p.out = out; p.out_ld = out_ld;
-    p.out_mode = out_mode; p.cout = cout; p.py = py; p.px = px;
+    p.out_mode = out_mode; p.cout = cout; p.py = py; p.px = px; p.dbg = dbg_flags;
     const double m = (double)out_h * out_w;
     const double flops = 2.0 * m * w.n * w.kh * w.kw * w.cin_true;
     const double bytes = (m * w.n * (res ? 2.0 : 1.0) + (double)in_h * in_w * w.cin_true + (double)w.n * w.kh * w.kw * w.cin) * sizeof(T);
-    timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, cur_stream); });
+    timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream); });
   }
   void ln_stats(const T* x, int64_t ld, int c, int m) {
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -786,6 +799,7 @@ class Engine : public EngineBase {
     }
     // encoder
     for (int s = 0; s < 4; ++s) {
+      cur_stage = s;
       const StageL& st = stages[s];
       T* x = stream_ptr(s);
       const int64_t ld = stream_ld(s);
@@ -813,6 +827,7 @@ class Engine : public EngineBase {
     }
     // decoder
     for (int i = 0; i < 3; ++i) {
+      cur_stage = 4 + i;
       const UpL& u = ups[i];
       const int si = 3 - i;             // input stage map
       const int so = 2 - i;             // output stage map
@@ -827,6 +842,7 @@ class Engine : public EngineBase {
       group_norm_silu(ta, u.cout, mo, u.g2, u.b2, scut, u.cout, cat[so], 2 * cfg.dim[so]);
       capture("up_block" + std::to_string(i + 1), cat[so], sh[so], sw[so], u.cout, 2 * cfg.dim[so], sw[so]);
     }
+    cur_stage = 7;
     for (int q = 0; q < 4; ++q) {
       const int py = q >> 1, px = q & 1;
       gemm("gemm_convT4", up4[q], cat[0], sh[0], sw[0], 2 * cfg.dim[0], 1, 1 - py, 1 - px, sh[0], sw[0], dec, ld_dec, nullptr, 0,

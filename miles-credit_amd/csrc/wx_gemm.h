@@ -44,6 +44,7 @@ struct ConvGemmParams {
                        // 2: parity conv: pixel (2oy+py, 2ox+px), channel n
   int cout;            // mode 1: channels per sub-pixel
   int py, px;          // mode 2
+  int dbg;             // perf-experiment switches (0 in production): 1 skip global stores, 2 skip act, 4 skip K loop, 8 skip residual
 };
 
 template <typename T>
@@ -279,6 +280,261 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_gemm_kernel(const 
   }
 }
 
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to lds_dst + lane*16 (lds_dst wave-uniform).
+// Issued from inline asm on purpose: hipcc (ROCm 7.2) otherwise treats the pending DMA as an LDS write that
+// may alias and emits `s_waitcnt vmcnt(0)` before the first ds_read of every K step, serialising the pipeline.
+// The caller owns the wait: `s_waitcnt vmcnt(0)` + barrier before the staged tile is read.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, const char* lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(dst)
+      : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------------------
+// v2: the same implicit GEMM for K rows of 128 bytes (cin*sizeof(T) % 128 == 0) with
+//   * LDS-DMA staging (global_load_lds_dwordx4: HBM/L2 -> LDS, no VGPR round trip, no ds_write pass),
+//   * un-padded 128-byte LDS rows with the 16-byte slots XOR-swizzled by (row>>1)&7 -- applied on the
+//     per-lane SOURCE address (the DMA destination is lane-linear) and again on the fragment read, which
+//     makes every ds_read_b128 lane group hit 16 distinct slots of the 256-byte bank window,
+//   * one barrier per K step: the DMA of step t+1 is issued before the MFMAs of step t and waited for
+//     (vmcnt(0)) after them,
+//   * epilogue through LDS (fp32 tile) so residual loads and output stores are whole 128/256-byte rows,
+//   * XCD-aware block -> tile mapping: the 8 XCDs get contiguous runs of tiles, so the N-tiles that
+//     share an activation row block hit the same L2.
+// Out-of-image taps / rows beyond M or n_alloc read a zeroed 256-byte page instead of branching.
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmParams p, const char* __restrict__ zero_page) {
+  constexpr int BM = 128;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int BKE = 128 / (int)sizeof(T);
+  constexpr int WN = BN / 2;           // 2x2 waves, wave tile 64 pixels x WN channels
+  constexpr int FM = 4, FN = WN / 16;
+  constexpr int A_I = BM / 32;         // DMA wave-instructions per wave for the activation tile (8 rows each)
+  constexpr int B_I = BN / 32;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int CROW = BN * 4 + 16;    // fp32 epilogue tile row stride (bytes)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int li = lane & 15, g = lane >> 4;
+
+  const int M = p.out_h * p.out_w;
+  const int n_tiles = (p.n + BN - 1) / BN;
+  // XCD-aware remap (bijective for any grid size)
+  int logical;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, idx = b >> 3, q = nblk >> 3, r = nblk & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = logical % n_tiles, tile_m = logical / n_tiles;
+  const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+
+  const int cchunks = p.cin / BKE;
+  const int nk = p.kh * p.kw * cchunks;
+  const int64_t ktot = (int64_t)p.kh * p.kw * p.cin;
+  const char* __restrict__ in = reinterpret_cast<const char*>(p.in);
+  const char* __restrict__ wt = reinterpret_cast<const char*>(p.wt);
+
+  // ---- per-lane DMA coordinates ---------------------------------------------------------------
+  const int lrow = lane >> 3;                       // row within the 8-row group of one DMA instruction
+  int a_iy0[A_I], a_ix0[A_I];
+  bool a_ok[A_I];
+  int a_piece[A_I];
+#pragma unroll
+  for (int i = 0; i < A_I; ++i) {
+    const int row = (i * 4 + wave) * 8 + lrow;
+    const int m = m_blk + row;
+    a_ok[i] = m < M;
+    const int oy = m / p.out_w, ox = m - oy * p.out_w;
+    a_iy0[i] = oy * p.stride - p.pad_y;
+    a_ix0[i] = ox * p.stride - p.pad_x;
+    a_piece[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 16;  // source piece (bytes) for this lane's LDS slot
+  }
+  const char* b_src[B_I];
+#pragma unroll
+  for (int i = 0; i < B_I; ++i) {
+    const int row = (i * 4 + wave) * 8 + lrow;
+    const int n = n_blk + row;
+    const int piece = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+    b_src[i] = (n < p.n_alloc) ? wt + ((int64_t)n * ktot) * (int64_t)sizeof(T) + piece : nullptr;
+  }
+  const char* zsrc = zero_page + (lane & 7) * 16;
+
+  int ky = 0, kx = 0, cc = 0;
+  auto issue = [&](char* stage, int ks) {
+#pragma unroll
+    for (int i = 0; i < A_I; ++i) {
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+      const bool ok = a_ok[i] && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+      const char* src = ok ? in + (((int64_t)iy * p.in_w + ix) * p.in_ld + cc * BKE) * (int64_t)sizeof(T) + a_piece[i] : zsrc;
+      lds_dma16(src, stage + (i * 4 + wave) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < B_I; ++i) {
+      const char* src = b_src[i] ? b_src[i] + (int64_t)ks * 128 : zsrc;
+      lds_dma16(src, stage + BM * 128 + (i * 4 + wave) * 1024);
+    }
+    if (++cc == cchunks) {
+      cc = 0;
+      if (++kx == p.kw) { kx = 0; ++ky; }
+    }
+  };
+
+  f32x4_t acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int sw = li >> 1;  // (row>>1)&7 for every fragment row this lane reads (fragment bases are multiples of 16)
+  const int x_base = (wm * 64 + li) * 128;
+  const int w_base = BM * 128 + (wn * WN + li) * 128;
+  const int off0 = ((0 + g) ^ sw) * 16, off1 = ((4 + g) ^ sw) * 16;
+
+  issue(smem, 0);
+  dma_wait_all();
+  __syncthreads();
+  const int nk_run = (p.dbg & 4) ? 0 : nk;
+  for (int ks = 0; ks < nk_run; ++ks) {
+    const char* cur = smem + (ks & 1) * STAGE;
+    if (ks + 1 < nk) issue(smem + ((ks + 1) & 1) * STAGE, ks + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int off = s ? off1 : off0;
+      uint4 xf[FM], wf[FN];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const uint4*>(cur + x_base + b * 2048 + off);
+#pragma unroll
+      for (int a = 0; a < FN; ++a) wf[a] = *reinterpret_cast<const uint4*>(cur + w_base + a * 2048 + off);
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<T>(wf[a], xf[b], acc[a][b]);
+    }
+    dma_wait_all();   // step ks+1 has landed (issued before this step's MFMAs)
+    __syncthreads();  // ... for every wave, and everyone is done reading `cur`
+  }
+
+  // ---- epilogue: registers -> fp32 LDS tile -> coalesced rows ----------------------------------
+  // bias / colsum are padded to a multiple of 128 floats by the host, so whole-vector loads are in bounds;
+  // loading them once per lane (not per element behind a branch) keeps the epilogue off the L2 latency path.
+  float4 bias4[FN], cs4[FN];
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    const int n0 = n_blk + wn * WN + a * 16 + g * 4;
+    bias4[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    cs4[a] = p.rowstat ? *reinterpret_cast<const float4*>(p.colsum + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const bool do_act = (p.act == 1) && !(p.dbg & 2);
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int ml = wm * 64 + b * 16 + li;
+    const int m = m_blk + ml;
+    float mean = 0.f, rstd = 1.f;
+    if (p.rowstat && m < M) {
+      const float2 st = p.rowstat[m];
+      mean = st.x;
+      rstd = st.y;
+    }
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const int nl = wn * WN + a * 16 + g * 4;
+      float v[4];
+      v[0] = rstd * (acc[a][b][0] - mean * cs4[a].x) + bias4[a].x;
+      v[1] = rstd * (acc[a][b][1] - mean * cs4[a].y) + bias4[a].y;
+      v[2] = rstd * (acc[a][b][2] - mean * cs4[a].z) + bias4[a].z;
+      v[3] = rstd * (acc[a][b][3] - mean * cs4[a].w) + bias4[a].w;
+      if (do_act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      }
+      *reinterpret_cast<float4*>(smem + ml * CROW + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  __syncthreads();
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+  constexpr int OPR = BN / 8;  // 8-channel groups per row
+#pragma unroll 4
+  for (int idx = tid; idx < BM * OPR; idx += 256) {
+    const int ml = idx / OPR, nl = (idx - ml * OPR) * 8;
+    const int m = m_blk + ml, n0 = n_blk + nl;
+    if (m >= M || n0 >= p.n) continue;
+    const float4 t0 = *reinterpret_cast<const float4*>(smem + ml * CROW + nl * 4);
+    const float4 t1 = *reinterpret_cast<const float4*>(smem + ml * CROW + nl * 4 + 16);
+    float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    int64_t pix;
+    int ch;
+    if (p.out_mode == 0) {
+      pix = m;
+      ch = n0;
+    } else {
+      const int oy = m / p.out_w, ox = m - oy * p.out_w;
+      if (p.out_mode == 1) {
+        const int q = n0 / p.cout;   // cout % 8 == 0 (host-checked): the 8 channels share one sub-pixel
+        ch = n0 - q * p.cout;
+        pix = (int64_t)(2 * oy + (q >> 1)) * (2 * p.out_w) + 2 * ox + (q & 1);
+      } else {
+        pix = (int64_t)(2 * oy + p.py) * (2 * p.out_w) + 2 * ox + p.px;
+        ch = n0;
+      }
+    }
+    if (n0 + 7 < p.n) {
+      if (res && !(p.dbg & 8)) {
+        float rv[8];
+        if constexpr (sizeof(T) == 2) {
+          unpack16<T>(*reinterpret_cast<const uint4*>(res + pix * p.res_ld + ch), rv);
+        } else {
+          unpack16<T>(*reinterpret_cast<const uint4*>(res + pix * p.res_ld + ch), rv);
+          unpack16<T>(*reinterpret_cast<const uint4*>(res + pix * p.res_ld + ch + 4), rv + 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += rv[r];
+      }
+      if (!(p.dbg & 1) || v[0] == 12345.678f) {
+        if constexpr (sizeof(T) == 2) {
+          *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch) = pack16<T>(v);
+        } else {
+          *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch) = pack16<T>(v);
+          *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch + 4) = pack16<T>(v + 4);
+        }
+      }
+    } else {
+      for (int r = 0; r < 8 && n0 + r < p.n; ++r) {
+        float t = v[r];
+        if (res) t += Elem<T>::to_f(res[pix * p.res_ld + ch + r]);
+        out[pix * p.out_ld + ch + r] = Elem<T>::from_f(t);
+      }
+    }
+  }
+}
+
+template <typename T, int BN>
+inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
+  constexpr int STAGES = 2 * (128 + BN) * 128;
+  constexpr int CT = 128 * (BN * 4 + 16);
+  constexpr int LDS = STAGES > CT ? STAGES : CT;
+  auto kern = conv_gemm_dma_kernel<T, BN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
+  }
+  const int M = p.out_h * p.out_w;
+  const int64_t blocks = (int64_t)cdiv(M, 128) * cdiv(p.n, BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
+  WX_HIP(hipGetLastError());
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB>
 inline void launch_conv_gemm_cfg(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -308,9 +564,13 @@ inline void launch_conv_gemm_kb(const ConvGemmParams& p, hipStream_t stream) {
 }
 
 template <typename T>
-inline void launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
+inline void launch_conv_gemm(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
   const int row_bytes = p.cin * (int)sizeof(T);
-  if (row_bytes % 128 == 0)
+  if (row_bytes % 128 == 0 && p.n >= 96 && zero_page)
+    launch_conv_gemm_dma<T, 128>(p, zero_page, stream);
+  else if (row_bytes % 128 == 0 && p.n >= 48 && zero_page)
+    launch_conv_gemm_dma<T, 64>(p, zero_page, stream);
+  else if (row_bytes % 128 == 0)
     launch_conv_gemm_kb<T, 128>(p, stream);
   else if (row_bytes % 64 == 0)
     launch_conv_gemm_kb<T, 64>(p, stream);

@@ -247,15 +247,16 @@ class WXEngine:
         _check(self.lib.wx_debug_read(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, shape))
         return out
 
-    def profile(self, on: bool) -> None:
+    def profile(self, on) -> None:
+        """0 off, 1 per kernel class, 2 per kernel class and stage ("gemm_ff1.s2")."""
         _check(self.lib.wx_profile(self._h, int(on)))
 
     def profile_reset(self) -> None:
         _check(self.lib.wx_profile_reset(self._h))
 
     def profile_read(self):
-        arr = (wx_kernel_stat * 64)()
+        arr = (wx_kernel_stat * 256)()
         n = C.c_int()
-        _check(self.lib.wx_profile_read(self._h, arr, 64, C.byref(n)))
+        _check(self.lib.wx_profile_read(self._h, arr, 256, C.byref(n)))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops,
                      bytes=arr[i].bytes) for i in range(n.value)]

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--golden", action="store_true")
+    ap.add_argument("--detail", action="store_true")
     args = ap.parse_args()
     cfg = named_config(args.config)
     t = time.time()
@@ -51,7 +52,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.time() - t) / args.steps
     print(f"[{args.config} {args.precision}] {dt * 1e3:.2f} ms/forward")
-    eng.profile(True)
+    eng.profile(2 if args.detail else 1)
     eng.profile_reset()
     eng.forward(x, out=y)
     rows = eng.profile_read()
@@ -59,7 +60,7 @@ def main():
     for r in sorted(rows, key=lambda r: -r["ms"]):
         tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0
         gb = r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0
-        print(f"  {r['name']:14s} n={r['launches']:4d} {r['ms']:9.3f} ms {100 * r['ms'] / tot:5.1f}%  {tf:8.1f} TF/s {gb:8.0f} GB/s")
+        print(f"  {r['name']:18s} n={r['launches']:4d} {r['ms']:9.3f} ms {100 * r['ms'] / tot:5.1f}%  {tf:8.1f} TF/s {gb:8.0f} GB/s")
     print(f"  total (event sum) {tot:.2f} ms")
 
 
