@@ -17,6 +17,7 @@
 #include "wx_attn.h"
 #include "wx_common.h"
 #include "wx_elem.h"
+#include "wx_embed.h"
 #include "wx_gemm.h"
 
 namespace wx {
@@ -45,7 +46,8 @@ struct ConvW {          // one repacked GEMM operand in the weight arena
 struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1; int wsz = 0, kind = 0; };
 struct FFL { ConvW w1, w2; };
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
-struct StageL { std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<BlockL> blocks; };
+struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmbed branch (wx_embed.h)
+struct StageL { std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks; };
 struct UpL { ConvW convt, c1, c2; int64_t g1 = -1, b1 = -1, g2 = -1, b2 = -1; int cin = 0, cout = 0; };
 
 struct KernelStatAcc { int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
@@ -349,6 +351,32 @@ class Engine : public EngineBase {
     if (has_bias || ln_b) cw.bias = push_f(bias);
     return cw;
   }
+  // Stage-0 large-kernel branch for embed_patch_kernel: [chunk][ky][kx/4][tap g][out 16][CC channels]
+  PatchW make_patch(const std::string& p, int n, int cin, int cpad, int k) {
+    const std::vector<double> w = folded(p, false);
+    constexpr int CC = 16 / (int)sizeof(T);
+    const int chunks = cpad / CC, k4n = k / 4;
+    std::vector<double> rows((size_t)chunks * k * k4n * 64 * CC, 0.0);
+    for (int ch = 0; ch < chunks; ++ch)
+      for (int ky = 0; ky < k; ++ky)
+        for (int k4 = 0; k4 < k4n; ++k4)
+          for (int g = 0; g < 4; ++g)
+            for (int o = 0; o < n; ++o)
+              for (int e = 0; e < CC; ++e) {
+                const int c = ch * CC + e;
+                if (c >= cin) continue;
+                rows[((((size_t)ch * k + ky) * k4n + k4) * 64 + g * 16 + o) * CC + e] =
+                    w[(((int64_t)o * cin + c) * k + ky) * k + (k4 * 4 + g)];
+              }
+    PatchW pw;
+    pw.n = n;
+    pw.wt = push_w(rows, 1, (int64_t)rows.size());
+    std::vector<float> bias(16, 0.f);
+    const HostTensor& b = need(p + ".bias");
+    for (int o = 0; o < n; ++o) bias[o] = b.data[o];
+    pw.bias = push_f(bias);
+    return pw;
+  }
   // ConvTranspose2d k2 s2: W[ci][co][dy][dx] -> rows n = (dy*2+dx)*cout + co, K = ci; bias expanded x4
   ConvW make_convt2(const std::string& p, int cin, int cout) {
     const std::vector<double> w = folded(p, true);
@@ -475,8 +503,10 @@ class Engine : public EngineBase {
       for (size_t b = 0; b < ks.size(); ++b) {
         const int co = (b + 1 < ks.size()) ? (int)(cout / (1 << (b + 1))) : cout - acc;
         acc += co;
-        st.embed.push_back(make_conv("layers." + std::to_string(s) + ".0.convs." + std::to_string(b), 0, co, cin, cpad,
-                                     ks[b], ks[b], true, nullptr, nullptr));
+        const std::string bp = "layers." + std::to_string(s) + ".0.convs." + std::to_string(b);
+        const bool patch_ok = s == 0 && cfg.embed_strides[0] == 2 && (ks[b] == 16 || ks[b] == 32) && co <= 16 && co % 4 == 0;
+        st.patch.push_back(patch_ok ? make_patch(bp, co, cin, cpad, ks[b]) : PatchW());
+        st.embed.push_back(make_conv(bp, 0, co, cin, cpad, ks[b], ks[b], true, nullptr, nullptr));
         st.embed_k.push_back(ks[b]);
       }
       for (int d = 0; d < cfg.depth[s]; ++d) {
@@ -537,6 +567,8 @@ class Engine : public EngineBase {
   char* zero_page = nullptr;
   bool use_dma = true;
   int dbg_flags = 0;
+  int gemm_cfg = 0;
+  bool use_patch = true;
   double* gn_acc = nullptr;
   float *gn_scale = nullptr, *gn_shift = nullptr;
   float *d_mean = nullptr, *d_std = nullptr, *d_lo = nullptr, *d_hi = nullptr;
@@ -570,6 +602,8 @@ class Engine : public EngineBase {
     WX_HIP(hipMemset(zero_page, 0, 256));
     if (const char* e = getenv("WX_NO_DMA")) use_dma = !(e[0] == '1');
     if (const char* e = getenv("WX_DBG")) dbg_flags = atoi(e);
+    if (const char* e = getenv("WX_GEMM_CFG")) gemm_cfg = atoi(e);
+    if (const char* e = getenv("WX_NO_PATCH")) use_patch = !(e[0] == '1');
     const int cmax = cfg.dim[3];
     gn_acc = (double*)dalloc(2 * cmax * sizeof(double));
     gn_scale = (float*)dalloc(cmax * sizeof(float));
@@ -717,7 +751,7 @@ class Engine : public EngineBase {
     const double m = (double)out_h * out_w;
     const double flops = 2.0 * m * w.n * w.kh * w.kw * w.cin_true;
     const double bytes = (m * w.n * (res ? 2.0 : 1.0) + (double)in_h * in_w * w.cin_true + (double)w.n * w.kh * w.kw * w.cin) * sizeof(T);
-    timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream); });
+    timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream, gemm_cfg); });
   }
   void ln_stats(const T* x, int64_t ld, int c, int m) {
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -806,7 +840,17 @@ class Engine : public EngineBase {
       int choff = 0;
       for (size_t b = 0; b < st.embed.size(); ++b) {
         const int k = st.embed_k[b], stv = cfg.embed_strides[s], pd = (k - stv) / 2;
-        if (s == 0)
+        if (s == 0 && st.patch[b].wt >= 0 && use_patch) {
+          EmbedPatchParams ep;
+          ep.xin = xin; ep.Hb = Hp + 2 * halo; ep.Wb = Wp + 2 * halo; ep.cpad = cpad0; ep.org = halo - pd;
+          ep.wt = wt_dev + st.patch[b].wt; ep.bias = f_dev + st.patch[b].bias;
+          ep.out = x + choff; ep.out_ld = ld; ep.out_h = sh[0]; ep.out_w = sw[0]; ep.n = st.patch[b].n; ep.dbg = dbg_flags;
+          const double fl = 2.0 * sh[0] * sw[0] * st.patch[b].n * k * k * C_in;
+          timed(k == 32 ? "embed_patch32" : "embed_patch16", fl, (double)(Hp * Wp) * cpad0 * sizeof(T) + (double)sh[0] * sw[0] * st.patch[b].n * sizeof(T), [&] {
+            if (k == 32) launch_embed_patch<T, 32>(ep, zero_page, cur_stream);
+            else launch_embed_patch<T, 16>(ep, zero_page, cur_stream);
+          });
+        } else if (s == 0)
           gemm("gemm_embed", st.embed[b], xin, Hp + 2 * halo, Wp + 2 * halo, cpad0, stv, pd - halo, pd - halo, sh[0], sw[0],
                x + choff, ld, nullptr, 0, nullptr, 0);
         else

@@ -298,28 +298,43 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const char* lds_dst)
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------
-// v2: the same implicit GEMM for K rows of 128 bytes (cin*sizeof(T) % 128 == 0) with
+// The fast path: the same implicit GEMM with
 //   * LDS-DMA staging (global_load_lds_dwordx4: HBM/L2 -> LDS, no VGPR round trip, no ds_write pass),
-//   * un-padded 128-byte LDS rows with the 16-byte slots XOR-swizzled by (row>>1)&7 -- applied on the
-//     per-lane SOURCE address (the DMA destination is lane-linear) and again on the fragment read, which
-//     makes every ds_read_b128 lane group hit 16 distinct slots of the 256-byte bank window,
+//   * un-padded LDS rows of KB bytes whose 16-byte slots are XOR-swizzled -- applied on the per-lane SOURCE
+//     address (the DMA destination is lane-linear) and again on the fragment read -- so that every
+//     ds_read_b128 lane group hits 16 distinct slots of the 256-byte bank window
+//       KB = 128: slot ^= (row >> 1) & 7          KB = 64: slot ^= 3 * ((row >> 3) & 1)
 //   * one barrier per K step: the DMA of step t+1 is issued before the MFMAs of step t and waited for
 //     (vmcnt(0)) after them,
-//   * epilogue through LDS (fp32 tile) so residual loads and output stores are whole 128/256-byte rows,
+//   * epilogue through an LDS tile in the OUTPUT type: the residual tile is DMA'd into it, each lane adds its
+//     fp32 accumulators in place (single rounding), and the tile leaves as whole 16-byte pieces of full rows,
 //   * XCD-aware block -> tile mapping: the 8 XCDs get contiguous runs of tiles, so the N-tiles that
 //     share an activation row block hit the same L2.
+// KB = 64 halves the stage (2 x 16 KB) so that four workgroups fit per CU: the prologue/epilogue latency of one
+// tile hides under the main loops of three others -- the configuration for short-K layers (stages 0/1).
 // Out-of-image taps / rows beyond M or n_alloc read a zeroed 256-byte page instead of branching.
-template <typename T, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmParams p, const char* __restrict__ zero_page) {
+template <int KB>
+__device__ __forceinline__ int stage_swz(int row) {
+  return KB == 128 ? ((row >> 1) & 7) : (((row >> 3) & 1) * 3);
+}
+
+template <typename T, int BN, int KB>
+__global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void conv_gemm_dma_kernel(
+    const ConvGemmParams p, const char* __restrict__ zero_page) {
   constexpr int BM = 128;
-  constexpr int VEC = 16 / (int)sizeof(T);
-  constexpr int BKE = 128 / (int)sizeof(T);
-  constexpr int WN = BN / 2;           // 2x2 waves, wave tile 64 pixels x WN channels
+  constexpr int BKE = KB / (int)sizeof(T);
+  constexpr int PPR = KB / 16;          // 16-byte slots per staged row
+  constexpr int RPI = 64 / PPR;         // rows moved by one DMA wave-instruction
+  constexpr int SUBS = KB / 64;
+  constexpr int WN = BN / 2;            // 2x2 waves, wave tile 64 pixels x WN channels
   constexpr int FM = 4, FN = WN / 16;
-  constexpr int A_I = BM / 32;         // DMA wave-instructions per wave for the activation tile (8 rows each)
-  constexpr int B_I = BN / 32;
-  constexpr int STAGE = (BM + BN) * 128;
-  constexpr int CROW = BN * 4 + 16;    // fp32 epilogue tile row stride (bytes)
+  constexpr int A_I = BM / (4 * RPI);   // DMA instructions per wave per K step (activations / weights)
+  constexpr int B_I = BN / (4 * RPI);
+  constexpr int STAGE = (BM + BN) * KB;
+  constexpr int RB = BN * (int)sizeof(T);   // epilogue tile row bytes (un-padded, slot-swizzled)
+  constexpr int SPR = RB / 16;              // 16-byte slots per epilogue row
+  constexpr int C_RPI = 64 / SPR;           // epilogue rows per DMA instruction
+  static_assert(A_I >= 1 && B_I >= 1, "tile too small for the DMA layout");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -328,8 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmPar
 
   const int M = p.out_h * p.out_w;
   const int n_tiles = (p.n + BN - 1) / BN;
-  // XCD-aware remap (bijective for any grid size)
-  int logical;
+  int logical;  // XCD-aware remap (bijective for any grid size)
   {
     const int nblk = gridDim.x, b = blockIdx.x;
     const int xcd = b & 7, idx = b >> 3, q = nblk >> 3, r = nblk & 7;
@@ -345,29 +359,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmPar
   const char* __restrict__ wt = reinterpret_cast<const char*>(p.wt);
 
   // ---- per-lane DMA coordinates ---------------------------------------------------------------
-  const int lrow = lane >> 3;                       // row within the 8-row group of one DMA instruction
+  const int lrow = lane / PPR, lslot = lane % PPR;
   int a_iy0[A_I], a_ix0[A_I];
   bool a_ok[A_I];
   int a_piece[A_I];
 #pragma unroll
   for (int i = 0; i < A_I; ++i) {
-    const int row = (i * 4 + wave) * 8 + lrow;
+    const int row = (i * 4 + wave) * RPI + lrow;
     const int m = m_blk + row;
     a_ok[i] = m < M;
     const int oy = m / p.out_w, ox = m - oy * p.out_w;
     a_iy0[i] = oy * p.stride - p.pad_y;
     a_ix0[i] = ox * p.stride - p.pad_x;
-    a_piece[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 16;  // source piece (bytes) for this lane's LDS slot
+    a_piece[i] = (lslot ^ stage_swz<KB>(row)) * 16;  // source piece (bytes) feeding this lane's LDS slot
   }
   const char* b_src[B_I];
 #pragma unroll
   for (int i = 0; i < B_I; ++i) {
-    const int row = (i * 4 + wave) * 8 + lrow;
+    const int row = (i * 4 + wave) * RPI + lrow;
     const int n = n_blk + row;
-    const int piece = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+    const int piece = (lslot ^ stage_swz<KB>(row)) * 16;
     b_src[i] = (n < p.n_alloc) ? wt + ((int64_t)n * ktot) * (int64_t)sizeof(T) + piece : nullptr;
   }
-  const char* zsrc = zero_page + (lane & 7) * 16;
+  const char* zsrc = zero_page + lslot * 16;
 
   int ky = 0, kx = 0, cc = 0;
   auto issue = [&](char* stage, int ks) {
@@ -380,8 +394,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmPar
     }
 #pragma unroll
     for (int i = 0; i < B_I; ++i) {
-      const char* src = b_src[i] ? b_src[i] + (int64_t)ks * 128 : zsrc;
-      lds_dma16(src, stage + BM * 128 + (i * 4 + wave) * 1024);
+      const char* src = b_src[i] ? b_src[i] + (int64_t)ks * KB : zsrc;
+      lds_dma16(src, stage + BM * KB + (i * 4 + wave) * 1024);
     }
     if (++cc == cchunks) {
       cc = 0;
@@ -395,10 +409,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmPar
 #pragma unroll
     for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int sw = li >> 1;  // (row>>1)&7 for every fragment row this lane reads (fragment bases are multiples of 16)
-  const int x_base = (wm * 64 + li) * 128;
-  const int w_base = BM * 128 + (wn * WN + li) * 128;
-  const int off0 = ((0 + g) ^ sw) * 16, off1 = ((4 + g) ^ sw) * 16;
+  const int sw = stage_swz<KB>(li);  // fragment row bases are multiples of 16, so the swizzle depends on li only
+  const int x_base = (wm * 64 + li) * KB;
+  const int w_base = BM * KB + (wn * WN + li) * KB;
+  int soff[SUBS];
+#pragma unroll
+  for (int s = 0; s < SUBS; ++s) soff[s] = ((s * 4 + g) ^ sw) * 16;
 
   issue(smem, 0);
   dma_wait_all();
@@ -408,13 +424,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmPar
     const char* cur = smem + (ks & 1) * STAGE;
     if (ks + 1 < nk) issue(smem + ((ks + 1) & 1) * STAGE, ks + 1);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int off = s ? off1 : off0;
+    for (int s = 0; s < SUBS; ++s) {
       uint4 xf[FM], wf[FN];
 #pragma unroll
-      for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const uint4*>(cur + x_base + b * 2048 + off);
+      for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const uint4*>(cur + x_base + b * 16 * KB + soff[s]);
 #pragma unroll
-      for (int a = 0; a < FN; ++a) wf[a] = *reinterpret_cast<const uint4*>(cur + w_base + a * 2048 + off);
+      for (int a = 0; a < FN; ++a) wf[a] = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * KB + soff[s]);
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
@@ -424,7 +439,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmPar
     __syncthreads();  // ... for every wave, and everyone is done reading `cur`
   }
 
-  // ---- epilogue: registers -> fp32 LDS tile -> coalesced rows ----------------------------------
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // (1) residual tile -> LDS by DMA (same slot swizzle as the reads below): slot ^= row & (SPR-1)
+  const bool has_res = p.res != nullptr && !(p.dbg & 8);
+  if (has_res) {
+    const char* __restrict__ res = reinterpret_cast<const char*>(p.res);
+    const int crow = lane / SPR, cslot = lane % SPR;
+#pragma unroll
+    for (int i = 0; i < BM / (4 * C_RPI); ++i) {
+      const int row = (i * 4 + wave) * C_RPI + crow;
+      const int m = m_blk + row;
+      const int piece = cslot ^ (row & (SPR - 1));
+      const bool ok = m < M && n_blk + piece * (16 / (int)sizeof(T)) < p.n;
+      const char* src = ok ? res + ((int64_t)m * p.res_ld + n_blk) * (int64_t)sizeof(T) + piece * 16 : zero_page;
+      lds_dma16(src, smem + (i * 4 + wave) * 1024);
+    }
+  }
   // bias / colsum are padded to a multiple of 128 floats by the host, so whole-vector loads are in bounds;
   // loading them once per lane (not per element behind a branch) keeps the epilogue off the L2 latency path.
   float4 bias4[FN], cs4[FN];
@@ -434,17 +464,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmPar
     bias4[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
     cs4[a] = p.rowstat ? *reinterpret_cast<const float4*>(p.colsum + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float2 st[FM];
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int m = m_blk + wm * 64 + b * 16 + li;
+    st[b] = (p.rowstat && m < M) ? p.rowstat[m] : make_float2(0.f, 1.f);
+  }
+  if (has_res) {
+    dma_wait_all();
+    __syncthreads();
+  }
   const bool do_act = (p.act == 1) && !(p.dbg & 2);
+  // (2) accumulators (+LayerNorm fold, bias, GELU, residual) -> output type, in place in the LDS tile
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
     const int ml = wm * 64 + b * 16 + li;
-    const int m = m_blk + ml;
-    float mean = 0.f, rstd = 1.f;
-    if (p.rowstat && m < M) {
-      const float2 st = p.rowstat[m];
-      mean = st.x;
-      rstd = st.y;
-    }
+    const float mean = st[b].x, rstd = st[b].y;
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
       const int nl = wn * WN + a * 16 + g * 4;
@@ -453,25 +488,31 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmPar
       v[1] = rstd * (acc[a][b][1] - mean * cs4[a].y) + bias4[a].y;
       v[2] = rstd * (acc[a][b][2] - mean * cs4[a].z) + bias4[a].z;
       v[3] = rstd * (acc[a][b][3] - mean * cs4[a].w) + bias4[a].w;
-      if (do_act) {
+      if (do_act) {  // libm erff: an Abramowitz-Stegun rcp+exp variant measured 10-15 % SLOWER per FF1 launch (A/B, round 1)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
       }
-      *reinterpret_cast<float4*>(smem + ml * CROW + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      const int byte = nl * (int)sizeof(T);
+      T* cp = reinterpret_cast<T*>(smem + ml * RB + (((byte >> 4) ^ (ml & (SPR - 1))) << 4) + (byte & 15));
+      if (has_res) {
+        float rv[4];
+        load4<T>(cp, rv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+      }
+      store4<T>(cp, v);
     }
   }
   __syncthreads();
+  // (3) whole 16-byte pieces of full rows -> global
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
-  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
-  constexpr int OPR = BN / 8;  // 8-channel groups per row
+  constexpr int EPV = 16 / (int)sizeof(T);  // elements per piece
 #pragma unroll 4
-  for (int idx = tid; idx < BM * OPR; idx += 256) {
-    const int ml = idx / OPR, nl = (idx - ml * OPR) * 8;
-    const int m = m_blk + ml, n0 = n_blk + nl;
+  for (int idx = tid; idx < BM * SPR; idx += 256) {
+    const int ml = idx / SPR, sl = idx - ml * SPR;
+    const int m = m_blk + ml, n0 = n_blk + sl * EPV;
     if (m >= M || n0 >= p.n) continue;
-    const float4 t0 = *reinterpret_cast<const float4*>(smem + ml * CROW + nl * 4);
-    const float4 t1 = *reinterpret_cast<const float4*>(smem + ml * CROW + nl * 4 + 16);
-    float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    const uint4 piece = *reinterpret_cast<const uint4*>(smem + ml * RB + ((sl ^ (ml & (SPR - 1))) << 4));
     int64_t pix;
     int ch;
     if (p.out_mode == 0) {
@@ -480,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmPar
     } else {
       const int oy = m / p.out_w, ox = m - oy * p.out_w;
       if (p.out_mode == 1) {
-        const int q = n0 / p.cout;   // cout % 8 == 0 (host-checked): the 8 channels share one sub-pixel
+        const int q = n0 / p.cout;   // cout % 8 == 0 (host-checked): one piece never straddles two sub-pixels
         ch = n0 - q * p.cout;
         pix = (int64_t)(2 * oy + (q >> 1)) * (2 * p.out_w) + 2 * ox + (q & 1);
       } else {
@@ -488,42 +529,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(const ConvGemmPar
         ch = n0;
       }
     }
-    if (n0 + 7 < p.n) {
-      if (res && !(p.dbg & 8)) {
-        float rv[8];
-        if constexpr (sizeof(T) == 2) {
-          unpack16<T>(*reinterpret_cast<const uint4*>(res + pix * p.res_ld + ch), rv);
-        } else {
-          unpack16<T>(*reinterpret_cast<const uint4*>(res + pix * p.res_ld + ch), rv);
-          unpack16<T>(*reinterpret_cast<const uint4*>(res + pix * p.res_ld + ch + 4), rv + 4);
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += rv[r];
-      }
-      if (!(p.dbg & 1) || v[0] == 12345.678f) {
-        if constexpr (sizeof(T) == 2) {
-          *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch) = pack16<T>(v);
-        } else {
-          *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch) = pack16<T>(v);
-          *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch + 4) = pack16<T>(v + 4);
-        }
-      }
+    if (n0 + EPV <= p.n) {
+      if (!(p.dbg & 1) || piece.x == 0x12345678u) *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch) = piece;
     } else {
-      for (int r = 0; r < 8 && n0 + r < p.n; ++r) {
-        float t = v[r];
-        if (res) t += Elem<T>::to_f(res[pix * p.res_ld + ch + r]);
-        out[pix * p.out_ld + ch + r] = Elem<T>::from_f(t);
+      const uint32_t w[4] = {piece.x, piece.y, piece.z, piece.w};
+#pragma unroll
+      for (int r = 0; r < EPV; ++r) {  // constant indices only: keeps `piece` out of scratch
+        if (n0 + r < p.n) {
+          if constexpr (sizeof(T) == 2) out[pix * p.out_ld + ch + r] = (T)((w[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
+          else out[pix * p.out_ld + ch + r] = __builtin_bit_cast(T, w[r]);
+        }
       }
     }
   }
 }
 
-template <typename T, int BN>
+template <typename T, int BN, int KB>
 inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
-  constexpr int STAGES = 2 * (128 + BN) * 128;
-  constexpr int CT = 128 * (BN * 4 + 16);
+  constexpr int STAGES = 2 * (128 + BN) * KB;
+  constexpr int CT = 128 * BN * (int)sizeof(T);
   constexpr int LDS = STAGES > CT ? STAGES : CT;
-  auto kern = conv_gemm_dma_kernel<T, BN>;
+  auto kern = conv_gemm_dma_kernel<T, BN, KB>;
   static bool attr_done = false;
   if (!attr_done) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -563,14 +589,31 @@ inline void launch_conv_gemm_kb(const ConvGemmParams& p, hipStream_t stream) {
     launch_conv_gemm_cfg<T, 256, 16, 4, 1, KB>(p, stream);
 }
 
+// gemm_cfg: 0 = automatic, 1 = force KB 128 (2 workgroups/CU), 2 = force KB 64 (4 workgroups/CU)
 template <typename T>
-inline void launch_conv_gemm(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
+inline void launch_conv_gemm(const ConvGemmParams& p, const void* zero_page, hipStream_t stream, int gemm_cfg = 0) {
   const int row_bytes = p.cin * (int)sizeof(T);
-  if (row_bytes % 128 == 0 && p.n >= 96 && zero_page)
-    launch_conv_gemm_dma<T, 128>(p, zero_page, stream);
-  else if (row_bytes % 128 == 0 && p.n >= 48 && zero_page)
-    launch_conv_gemm_dma<T, 64>(p, zero_page, stream);
-  else if (row_bytes % 128 == 0)
+  const bool dma_ok = zero_page != nullptr && p.n >= 48 && row_bytes % 64 == 0 &&
+                      (p.res == nullptr || p.out_mode == 0) && (p.out_mode != 1 || p.cout % 8 == 0);
+  if (dma_ok) {
+    const int64_t ktot_bytes = (int64_t)p.kh * p.kw * row_bytes;
+    // four resident workgroups per CU (KB 64) win whenever there are enough tiles to fill them; with fewer tiles
+    // than 2 x 256 slots the longer K step (KB 128, fewer barriers) is faster (measured on the stage-3 shapes)
+    const int64_t tiles = (int64_t)cdiv(p.out_h * p.out_w, 128) * cdiv(p.n, p.n >= 96 ? 128 : 64);
+    (void)ktot_bytes;
+    bool kb64 = row_bytes % 128 != 0 || tiles >= 512;
+    if (gemm_cfg == 1 && row_bytes % 128 == 0) kb64 = false;
+    if (gemm_cfg == 2) kb64 = true;
+    if (p.n >= 96) {
+      if (kb64) launch_conv_gemm_dma<T, 128, 64>(p, zero_page, stream);
+      else launch_conv_gemm_dma<T, 128, 128>(p, zero_page, stream);
+    } else {
+      if (kb64) launch_conv_gemm_dma<T, 64, 64>(p, zero_page, stream);
+      else launch_conv_gemm_dma<T, 64, 128>(p, zero_page, stream);
+    }
+    return;
+  }
+  if (row_bytes % 128 == 0)
     launch_conv_gemm_kb<T, 128>(p, stream);
   else if (row_bytes % 64 == 0)
     launch_conv_gemm_kb<T, 64>(p, stream);
