@@ -1,19 +1,24 @@
-// Stage-0 CrossEmbed large-kernel branches (k = 16, 32; stride 2) as an LDS-patch convolution.
-// Reference: credit/models/crossformer.py:128-152 (CrossEmbedLayer) with kernel sizes (4, 8, 16, 32).
+// Stage-0 CrossEmbed (stride 2, kernels 8 / 16 / 32) as ONE LDS-patch convolution.
+// Reference: credit/models/crossformer.py:128-152 (CrossEmbedLayer) with kernel sizes (4, 8, 16, 32): every branch
+// is centred on the same input window (padding (k-2)/2), so the k=16 and k=8 kernels live inside the k=32 window
+// at tap offsets 8 and 12.
 //
 // The k=32 branch alone is 629 of the model's 5 548 GFLOP with only 16 output channels: as an implicit GEMM
 // (M = 320 000 pixels, N = 16, K = 61 440) every 128-byte activation row is re-fetched from L2 for each of the
 // 1 024 taps, so the generic kernel is L2-bandwidth bound (~170 TFLOP/s).  Here one workgroup stages the
-// (2*TH+k-2) x (2*TW+k-2) input patch of a TH x TW output tile into LDS ONCE per 16-byte channel chunk (LDS-DMA,
-// one pixel = one 16-byte slot, patch row-major = lane-linear) and slides all k*k taps over it:
+// (2*TH+30) x (2*TW+30) input patch of a TH x TW output tile into LDS ONCE per 16-byte channel chunk (LDS-DMA,
+// one pixel = one 16-byte slot, patch row-major = lane-linear) and slides all 32x32 taps over it:
 //   MFMA B operand (activations): lane (pixel li, k-slot g) reads the 16 bytes of patch pixel
 //        (2*oy + ky, 2*ox + kx + g)  ->  one MFMA contracts 4 horizontally adjacent taps x 8 channels (bf16)
 //        (fp32: 4 taps x 4 channels through four 16x16x4 MFMAs); the 64 lanes of a fragment read one
-//        contiguous ~1 KB span of the patch row: conflict-free ds_read_b128 with no padding or swizzle.
-//   MFMA A operand (weights): host-repacked [chunk][ky][kx/4][16 out][4 taps][16 B] so each step's fragment is
-//        one coalesced 1 KB load per wave, software-prefetched one step ahead.
-// Global/L2 traffic drops to the patch itself (arithmetic intensity ~700 FLOP/B); the kernel is bounded by the
-// LDS fragment reads (8 x 1 KB per 8 MFMAs per wave) and the MFMA pipe.
+//        contiguous ~0.5 KB span of the patch row: conflict-free ds_read_b128 with no padding or swizzle.
+//   MFMA A operand (weights): host-repacked per branch as [chunk][ky][kx/4][tap g][out][16 B]: each step's
+//        fragment is one coalesced 1 KB load per wave, prefetched a whole kernel row ahead (a single step --
+//        8 MFMAs, ~130 cycles -- is far shorter than an L2 round trip).
+// The activation fragment is the expensive operand (1 KB of LDS read per MFMA when N = 16), so the smaller
+// branches ride along: inside the central 16x16 (8x8) taps the same fragment also feeds the k=16 (k=8) weights,
+// adding their 236 GFLOP without a single extra LDS read.  Global/L2 traffic is the patch itself
+// (arithmetic intensity ~700 FLOP/B).
 #pragma once
 #include "wx_common.h"
 #include "wx_gemm.h"
@@ -23,24 +28,29 @@ namespace wx {
 struct EmbedPatchParams {
   const void* xin;     // packed input [(Hb)][(Wb)][cpad] (halo included), element type T
   int Hb, Wb, cpad;    // buffer dims in pixels / channels
-  int org;             // halo - (k-2)/2 : buffer offset of the conv window origin
-  const void* wt;      // [chunks][k][k/4][16][4][16 bytes]
-  const float* bias;   // [16] (padded)
-  void* out;           // stage-0 stream (already offset to this branch's first channel)
+  int org;             // halo - 15 : buffer offset of the 32x32 window origin
+  const void* wt32;    // [chunks][32][8][64 lanes] x 16 B
+  const void* wt16;    // [chunks][16][4][64 lanes] x 16 B   (or nullptr: branch not fused)
+  const void* wt8;     // [chunks][8][2][2 frags][64 lanes] x 16 B   (or nullptr)
+  const float* bias32; // [16] (zero padded)
+  const float* bias16; // [16]
+  const float* bias8;  // [32]
+  void* out32;         // stage-0 stream, already offset to each branch's first channel
+  void* out16;
+  void* out8;
   int64_t out_ld;
   int out_h, out_w;
-  int dbg;             // perf experiments: 16 skip patch staging after the first chunk, 32 skip the tap loop
-  int n;               // real output channels of the branch (<= 16, multiple of 4); weight rows >= n are zero
+  int n32, n16, n8;    // real channels per branch (multiples of 4; <= 16, 16, 32)
+  int dbg;
 };
 
-template <typename T, int KS>
+template <typename T>
 __global__ __launch_bounds__(256, 1) void embed_patch_kernel(const EmbedPatchParams p, const char* __restrict__ zero_page) {
-  constexpr int TH = 16, TW = 32;
+  constexpr int KS = 32, TH = 16, TW = 32;
   constexpr int PH = 2 * TH + KS - 2, PW = 2 * TW + KS - 2;
   constexpr int NPIX = PH * PW;
   constexpr int NPIX_PAD = ((NPIX + 255) / 256) * 256;
   constexpr int CC = 16 / (int)sizeof(T);        // channels per chunk
-  constexpr int KX4 = KS / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NPIX_PAD][16 B]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -51,7 +61,10 @@ __global__ __launch_bounds__(256, 1) void embed_patch_kernel(const EmbedPatchPar
   const int by0 = 2 * oy0 + p.org, bx0 = 2 * ox0 + p.org;  // patch origin in buffer coordinates
   const int chunks = p.cpad / CC;
   const char* __restrict__ xin = reinterpret_cast<const char*>(p.xin);
-  const uint4* __restrict__ wt = reinterpret_cast<const uint4*>(p.wt);
+  const uint4* __restrict__ wt32 = reinterpret_cast<const uint4*>(p.wt32);
+  const uint4* __restrict__ wt16 = reinterpret_cast<const uint4*>(p.wt16);
+  const uint4* __restrict__ wt8 = reinterpret_cast<const uint4*>(p.wt8);
+  const bool f16 = wt16 != nullptr, f8 = wt8 != nullptr;
   const int64_t pix_bytes = (int64_t)p.cpad * (int64_t)sizeof(T);
 
   // fragment f of this wave: output row 4*wave + f/2, cols (f&1)*16 + li
@@ -61,68 +74,131 @@ __global__ __launch_bounds__(256, 1) void embed_patch_kernel(const EmbedPatchPar
     const int r = 4 * wave + (f >> 1), c = (f & 1) * 16 + li;
     fbase[f] = ((2 * r) * PW + 2 * c + g) * 16;
   }
-  f32x4_t acc[8];
+  f32x4_t a32[8], a16[8], a8[2][8];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < 8; ++f) {
+    a32[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    a16[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    a8[0][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    a8[1][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
 
-  const int steps = KS * KX4;  // per chunk
   for (int ch = 0; ch < chunks; ++ch) {
     // ---- stage the patch for this channel chunk (LDS-DMA, one pixel per lane) --------------------
     if (!(p.dbg & 16) || ch == 0)
-    for (int it = 0; it < NPIX_PAD / 256; ++it) {
-      const int idx = it * 256 + wave * 64 + lane;
-      const int py = idx / PW, px = idx - py * PW;
-      const int by = by0 + py, bx = bx0 + px;
-      const bool ok = idx < NPIX && by >= 0 && by < p.Hb && bx >= 0 && bx < p.Wb;
-      const char* src = ok ? xin + ((int64_t)by * p.Wb + bx) * pix_bytes + ch * 16 : zero_page;
-      lds_dma16(src, smem + (it * 256 + wave * 64) * 16);
-    }
+      for (int it = 0; it < NPIX_PAD / 256; ++it) {
+        const int idx = it * 256 + wave * 64 + lane;
+        const int py = idx / PW, px = idx - py * PW;
+        const int by = by0 + py, bx = bx0 + px;
+        const bool ok = idx < NPIX && by >= 0 && by < p.Hb && bx >= 0 && bx < p.Wb;
+        const char* src = ok ? xin + ((int64_t)by * p.Wb + bx) * pix_bytes + ch * 16 : zero_page;
+        lds_dma16(src, smem + (it * 256 + wave * 64) * 16);
+      }
     dma_wait_all();
     __syncthreads();
-    // ---- slide the taps.  Weight fragments are prefetched a whole kernel row (KX4 steps) ahead: one step
-    // (8 MFMAs ~ 130 cycles) is far shorter than an L2 round trip, so a 1-step prefetch stalls every step.
-    const uint4* wp = wt + (int64_t)ch * steps * 64 + lane;
-    uint4 wrow[KX4];
+    // ---- slide the taps ----------------------------------------------------------------------------
+    const uint4* w32 = wt32 + (int64_t)ch * (32 * 8) * 64 + lane;
+    const uint4* w16 = f16 ? wt16 + (int64_t)ch * (16 * 4) * 64 + lane : nullptr;
+    const uint4* w8 = f8 ? wt8 + (int64_t)ch * (8 * 2 * 2) * 64 + lane : nullptr;
+    uint4 r32[8];
 #pragma unroll
-    for (int k4 = 0; k4 < KX4; ++k4) wrow[k4] = wp[k4 * 64];
-    for (int ky = 0; ky < ((p.dbg & 32) ? 1 : KS); ++ky) {
-      uint4 wnext[KX4];
-      const uint4* wn = wp + (int64_t)(ky + 1 < KS ? ky + 1 : ky) * KX4 * 64;
+    for (int k4 = 0; k4 < 8; ++k4) r32[k4] = w32[k4 * 64];
+    const int ky_end = (p.dbg & 32) ? 1 : KS;
+    for (int ky = 0; ky < ky_end; ++ky) {
+      uint4 n32[8];
+      const uint4* wn = w32 + (int64_t)(ky + 1 < KS ? ky + 1 : ky) * 8 * 64;
 #pragma unroll
-      for (int k4 = 0; k4 < KX4; ++k4) wnext[k4] = wn[k4 * 64];
+      for (int k4 = 0; k4 < 8; ++k4) n32[k4] = wn[k4 * 64];
+      const bool in16 = f16 && ky >= 8 && ky < 24;
+      const bool in8 = f8 && ky >= 12 && ky < 20;
+      uint4 r16[4], r8[2][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r16[j] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) r8[j][0] = r8[j][1] = make_uint4(0u, 0u, 0u, 0u);
+      if (in16) {
+        const uint4* q = w16 + (int64_t)(ky - 8) * 4 * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r16[j] = q[j * 64];
+      }
+      if (in8) {
+        const uint4* q = w8 + (int64_t)(ky - 12) * 4 * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          r8[j][0] = q[(j * 2 + 0) * 64];
+          r8[j][1] = q[(j * 2 + 1) * 64];
+        }
+      }
       const char* prow = smem + ky * PW * 16;
 #pragma unroll
-      for (int k4 = 0; k4 < KX4; ++k4) {
+      for (int k4 = 0; k4 < 8; ++k4) {
         uint4 xf[8];
 #pragma unroll
         for (int f = 0; f < 8; ++f) xf[f] = *reinterpret_cast<const uint4*>(prow + fbase[f] + k4 * 64);
 #pragma unroll
-        for (int f = 0; f < 8; ++f) acc[f] = mma_sub<T>(wrow[k4], xf[f], acc[f]);
+        for (int f = 0; f < 8; ++f) a32[f] = mma_sub<T>(r32[k4], xf[f], a32[f]);
+        if (k4 >= 2 && k4 < 6) {
+          if (in16) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) a16[f] = mma_sub<T>(r16[k4 - 2 < 0 ? 0 : (k4 - 2 > 3 ? 3 : k4 - 2)], xf[f], a16[f]);
+          }
+        }
+        if (k4 >= 3 && k4 < 5) {
+          if (in8) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+              a8[0][f] = mma_sub<T>(r8[k4 == 3 ? 0 : 1][0], xf[f], a8[0][f]);
+              a8[1][f] = mma_sub<T>(r8[k4 == 3 ? 0 : 1][1], xf[f], a8[1][f]);
+            }
+          }
+        }
       }
 #pragma unroll
-      for (int k4 = 0; k4 < KX4; ++k4) wrow[k4] = wnext[k4];
+      for (int k4 = 0; k4 < 8; ++k4) r32[k4] = n32[k4];
     }
     __syncthreads();  // everyone is done with the patch before the next chunk overwrites it
   }
 
   // ---- epilogue: + bias, 4 consecutive channels per lane ---------------------------------------------
-  T* __restrict__ out = reinterpret_cast<T*>(p.out);
-  const float4 b4 = *reinterpret_cast<const float4*>(p.bias + g * 4);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 b32 = *reinterpret_cast<const float4*>(p.bias32 + g * 4);
+  const float4 b16 = f16 ? *reinterpret_cast<const float4*>(p.bias16 + g * 4) : z4;
+  const float4 b8a = f8 ? *reinterpret_cast<const float4*>(p.bias8 + g * 4) : z4;
+  const float4 b8b = f8 ? *reinterpret_cast<const float4*>(p.bias8 + 16 + g * 4) : z4;
+  T* __restrict__ o32 = reinterpret_cast<T*>(p.out32);
+  T* __restrict__ o16 = reinterpret_cast<T*>(p.out16);
+  T* __restrict__ o8 = reinterpret_cast<T*>(p.out8);
 #pragma unroll
   for (int f = 0; f < 8; ++f) {
     const int oy = oy0 + 4 * wave + (f >> 1), ox = ox0 + (f & 1) * 16 + li;
-    if (oy < p.out_h && ox < p.out_w && g * 4 < p.n) {
-      float v[4] = {acc[f][0] + b4.x, acc[f][1] + b4.y, acc[f][2] + b4.z, acc[f][3] + b4.w};
-      store4<T>(out + ((int64_t)oy * p.out_w + ox) * p.out_ld + g * 4, v);
+    if (oy >= p.out_h || ox >= p.out_w) continue;
+    const int64_t pix = ((int64_t)oy * p.out_w + ox) * p.out_ld;
+    if (g * 4 < p.n32) {
+      float v[4] = {a32[f][0] + b32.x, a32[f][1] + b32.y, a32[f][2] + b32.z, a32[f][3] + b32.w};
+      store4<T>(o32 + pix + g * 4, v);
+    }
+    if (f16 && g * 4 < p.n16) {
+      float v[4] = {a16[f][0] + b16.x, a16[f][1] + b16.y, a16[f][2] + b16.z, a16[f][3] + b16.w};
+      store4<T>(o16 + pix + g * 4, v);
+    }
+    if (f8) {
+      if (g * 4 < p.n8) {
+        float v[4] = {a8[0][f][0] + b8a.x, a8[0][f][1] + b8a.y, a8[0][f][2] + b8a.z, a8[0][f][3] + b8a.w};
+        store4<T>(o8 + pix + g * 4, v);
+      }
+      if (16 + g * 4 < p.n8) {
+        float v[4] = {a8[1][f][0] + b8b.x, a8[1][f][1] + b8b.y, a8[1][f][2] + b8b.z, a8[1][f][3] + b8b.w};
+        store4<T>(o8 + pix + 16 + g * 4, v);
+      }
     }
   }
 }
 
-template <typename T, int KS>
+template <typename T>
 inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream) {
-  constexpr int PH = 2 * 16 + KS - 2, PW = 2 * 32 + KS - 2;
+  constexpr int PH = 2 * 16 + 30, PW = 2 * 32 + 30;
   constexpr int LDS = (((PH * PW) + 255) / 256) * 256 * 16;
-  auto kern = embed_patch_kernel<T, KS>;
+  auto kern = embed_patch_kernel<T>;
   static bool attr_done = false;
   if (!attr_done) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));

@@ -351,12 +351,12 @@ class Engine : public EngineBase {
     if (has_bias || ln_b) cw.bias = push_f(bias);
     return cw;
   }
-  // Stage-0 large-kernel branch for embed_patch_kernel: [chunk][ky][kx/4][tap g][out 16][CC channels]
+  // Stage-0 branch for embed_patch_kernel: [chunk][ky][kx/4][n-frag][tap g][out 16][CC channels]
   PatchW make_patch(const std::string& p, int n, int cin, int cpad, int k) {
     const std::vector<double> w = folded(p, false);
     constexpr int CC = 16 / (int)sizeof(T);
-    const int chunks = cpad / CC, k4n = k / 4;
-    std::vector<double> rows((size_t)chunks * k * k4n * 64 * CC, 0.0);
+    const int chunks = cpad / CC, k4n = k / 4, nfr = (k == 8) ? 2 : 1;  // fragment counts the kernel is built for
+    std::vector<double> rows((size_t)chunks * k * k4n * nfr * 64 * CC, 0.0);
     for (int ch = 0; ch < chunks; ++ch)
       for (int ky = 0; ky < k; ++ky)
         for (int k4 = 0; k4 < k4n; ++k4)
@@ -365,13 +365,13 @@ class Engine : public EngineBase {
               for (int e = 0; e < CC; ++e) {
                 const int c = ch * CC + e;
                 if (c >= cin) continue;
-                rows[((((size_t)ch * k + ky) * k4n + k4) * 64 + g * 16 + o) * CC + e] =
+                rows[(((((size_t)ch * k + ky) * k4n + k4) * nfr + o / 16) * 64 + g * 16 + (o % 16)) * CC + e] =
                     w[(((int64_t)o * cin + c) * k + ky) * k + (k4 * 4 + g)];
               }
     PatchW pw;
     pw.n = n;
     pw.wt = push_w(rows, 1, (int64_t)rows.size());
-    std::vector<float> bias(16, 0.f);
+    std::vector<float> bias(32, 0.f);
     const HostTensor& b = need(p + ".bias");
     for (int o = 0; o < n; ++o) bias[o] = b.data[o];
     pw.bias = push_f(bias);
@@ -504,7 +504,8 @@ class Engine : public EngineBase {
         const int co = (b + 1 < ks.size()) ? (int)(cout / (1 << (b + 1))) : cout - acc;
         acc += co;
         const std::string bp = "layers." + std::to_string(s) + ".0.convs." + std::to_string(b);
-        const bool patch_ok = s == 0 && cfg.embed_strides[0] == 2 && (ks[b] == 16 || ks[b] == 32) && co <= 16 && co % 4 == 0;
+        const bool patch_ok = s == 0 && cfg.embed_strides[0] == 2 && co % 4 == 0 && ks.back() == 32 &&
+                              ((ks[b] == 32 && co <= 16) || (ks[b] == 16 && co <= 16) || (ks[b] == 8 && co <= 32));
         st.patch.push_back(patch_ok ? make_patch(bp, co, cin, cpad, ks[b]) : PatchW());
         st.embed.push_back(make_conv(bp, 0, co, cin, cpad, ks[b], ks[b], true, nullptr, nullptr));
         st.embed_k.push_back(ks[b]);
@@ -840,15 +841,27 @@ class Engine : public EngineBase {
       int choff = 0;
       for (size_t b = 0; b < st.embed.size(); ++b) {
         const int k = st.embed_k[b], stv = cfg.embed_strides[s], pd = (k - stv) / 2;
-        if (s == 0 && st.patch[b].wt >= 0 && use_patch) {
+        if (s == 0 && st.patch[b].wt >= 0 && use_patch && st.embed_k.back() == 32 && st.patch.back().wt >= 0) {
+          if (k != 32) { choff += st.embed[b].n; continue; }  // rides along in the fused launch issued with k = 32
           EmbedPatchParams ep;
-          ep.xin = xin; ep.Hb = Hp + 2 * halo; ep.Wb = Wp + 2 * halo; ep.cpad = cpad0; ep.org = halo - pd;
-          ep.wt = wt_dev + st.patch[b].wt; ep.bias = f_dev + st.patch[b].bias;
-          ep.out = x + choff; ep.out_ld = ld; ep.out_h = sh[0]; ep.out_w = sw[0]; ep.n = st.patch[b].n; ep.dbg = dbg_flags;
-          const double fl = 2.0 * sh[0] * sw[0] * st.patch[b].n * k * k * C_in;
-          timed(k == 32 ? "embed_patch32" : "embed_patch16", fl, (double)(Hp * Wp) * cpad0 * sizeof(T) + (double)sh[0] * sw[0] * st.patch[b].n * sizeof(T), [&] {
-            if (k == 32) launch_embed_patch<T, 32>(ep, zero_page, cur_stream);
-            else launch_embed_patch<T, 16>(ep, zero_page, cur_stream);
+          std::memset(&ep, 0, sizeof(ep));
+          ep.xin = xin; ep.Hb = Hp + 2 * halo; ep.Wb = Wp + 2 * halo; ep.cpad = cpad0; ep.org = halo - 15;
+          ep.out_ld = ld; ep.out_h = sh[0]; ep.out_w = sw[0]; ep.dbg = dbg_flags;
+          double fl = 0.0;
+          int off = 0;
+          for (size_t j = 0; j < st.embed.size(); ++j) {
+            const PatchW& pw = st.patch[j];
+            const int kj = st.embed_k[j];
+            if (pw.wt >= 0) {
+              fl += 2.0 * sh[0] * sw[0] * pw.n * kj * kj * C_in;
+              if (kj == 32) { ep.wt32 = wt_dev + pw.wt; ep.bias32 = f_dev + pw.bias; ep.out32 = x + off; ep.n32 = pw.n; }
+              if (kj == 16) { ep.wt16 = wt_dev + pw.wt; ep.bias16 = f_dev + pw.bias; ep.out16 = x + off; ep.n16 = pw.n; }
+              if (kj == 8) { ep.wt8 = wt_dev + pw.wt; ep.bias8 = f_dev + pw.bias; ep.out8 = x + off; ep.n8 = pw.n; }
+            }
+            off += st.embed[j].n;
+          }
+          timed("embed_patch", fl, (double)(Hp * Wp) * cpad0 * sizeof(T) + (double)sh[0] * sw[0] * 64 * sizeof(T), [&] {
+            launch_embed_patch<T>(ep, zero_page, cur_stream);
           });
         } else if (s == 0)
           gemm("gemm_embed", st.embed[b], xin, Hp + 2 * halo, Wp + 2 * halo, cpad0, stv, pd - halo, pd - halo, sh[0], sw[0],
