@@ -569,6 +569,9 @@ class Engine : public EngineBase {
   bool use_dma = true;
   int dbg_flags = 0;
   int gemm_cfg = 0;
+  bool fuse_ln = true;
+  float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
+  int stat_tiles_ready = 0;     // > 0: `statpart` holds partials of the current stream contents (that many per row)
   bool use_patch = true;
   double* gn_acc = nullptr;
   float *gn_scale = nullptr, *gn_shift = nullptr;
@@ -599,11 +602,13 @@ class Engine : public EngineBase {
     dec = (T*)dalloc((int64_t)Hd * Wd * ld_dec * sizeof(T));
     WX_HIP(hipMemset(dec, 0, (int64_t)Hd * Wd * ld_dec * sizeof(T)));
     rowstat = (float2*)dalloc(max_hw * sizeof(float2));
+    statpart = (float2*)dalloc(max_hw * 8 * sizeof(float2));
     zero_page = (char*)dalloc(256);
     WX_HIP(hipMemset(zero_page, 0, 256));
     if (const char* e = getenv("WX_NO_DMA")) use_dma = !(e[0] == '1');
     if (const char* e = getenv("WX_DBG")) dbg_flags = atoi(e);
     if (const char* e = getenv("WX_GEMM_CFG")) gemm_cfg = atoi(e);
+    if (const char* e = getenv("WX_NO_LNFUSE")) fuse_ln = !(e[0] == '1');
     if (const char* e = getenv("WX_NO_PATCH")) use_patch = !(e[0] == '1');
     const int cmax = cfg.dim[3];
     gn_acc = (double*)dalloc(2 * cmax * sizeof(double));
@@ -736,23 +741,32 @@ class Engine : public EngineBase {
   }
 
   // ------------------------------------------------------------------ launch helpers
-  void gemm(const char* cls, const ConvW& w, const T* in, int in_h, int in_w, int64_t in_ld, int stride, int pad_y,
+  // returns true when the launch also produced LayerNorm partials for its output rows (want_stats)
+  bool gemm(const char* cls, const ConvW& w, const T* in, int in_h, int in_w, int64_t in_ld, int stride, int pad_y,
             int pad_x, int out_h, int out_w, T* out, int64_t out_ld, const float2* rs, int act, const T* res,
-            int64_t res_ld, int out_mode = 0, int cout = 0, int py = 0, int px = 0) {
+            int64_t res_ld, int out_mode = 0, int cout = 0, int py = 0, int px = 0, bool want_stats = false) {
     ConvGemmParams p;
+    std::memset(&p, 0, sizeof(p));
     p.in = in; p.in_h = in_h; p.in_w = in_w; p.in_ld = in_ld; p.cin = w.cin;
     p.kh = w.kh; p.kw = w.kw; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
     p.out_h = out_h; p.out_w = out_w;
     p.wt = wt_dev + w.wt; p.n = w.n; p.n_alloc = w.n;
     p.bias = w.bias >= 0 ? f_dev + w.bias : nullptr;
     p.rowstat = rs; p.colsum = (rs && w.colsum >= 0) ? f_dev + w.colsum : nullptr;
+    p.stat_tiles = rs ? stat_tiles_ready : 0; p.stat_inv_c = 1.0f / (float)w.cin_true; p.stat_out = nullptr;
     if (rs && w.colsum < 0) throw StateError("LayerNorm-folded GEMM without column sums");
     p.act = act; p.res = res; p.res_ld = res_ld; p.out = out; p.out_ld = out_ld;
     p.out_mode = out_mode; p.cout = cout; p.py = py; p.px = px; p.dbg = dbg_flags;
     const double m = (double)out_h * out_w;
     const double flops = 2.0 * m * w.n * w.kh * w.kw * w.cin_true;
     const double bytes = (m * w.n * (res ? 2.0 : 1.0) + (double)in_h * in_w * w.cin_true + (double)w.n * w.kh * w.kw * w.cin) * sizeof(T);
+    bool made_stats = false;
+    if (want_stats && fuse_ln && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr)) {
+      p.stat_out = statpart;
+      made_stats = true;
+    }
     timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream, gemm_cfg); });
+    return made_stats;
   }
   void ln_stats(const T* x, int64_t ld, int c, int m) {
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -765,15 +779,22 @@ class Engine : public EngineBase {
       WX_HIP(hipGetLastError());
     });
   }
+  // LayerNorm statistics of the stream: either the partials the last producing GEMM left (stat_tiles_ready > 0)
+  // or a fresh two-pass ln_stats launch (stage entry, slow-path producers).
+  const float2* stream_stats(const T* x, int64_t ld, int c, int m) {
+    if (stat_tiles_ready > 0) return statpart;
+    ln_stats(x, ld, c, m);
+    return rowstat;
+  }
   void attention(const AttnL& a, int s, const std::string& dbg_name) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
     const int64_t ld = stream_ld(s);
-    ln_stats(x, ld, c, m);
+    const float2* rs = stream_stats(x, ld, c, m);
     if (a.wsz == 1) {
-      gemm("gemm_qkv", a.vonly, x, h, w, ld, 1, 0, 0, h, w, attn_o, c, rowstat, 0, nullptr, 0);
+      gemm("gemm_qkv", a.vonly, x, h, w, ld, 1, 0, 0, h, w, attn_o, c, rs, 0, nullptr, 0);
     } else {
-      gemm("gemm_qkv", a.qkv, x, h, w, ld, 1, 0, 0, h, w, scratch, 3 * c, rowstat, 0, nullptr, 0);
+      gemm("gemm_qkv", a.qkv, x, h, w, ld, 1, 0, 0, h, w, scratch, 3 * c, rs, 0, nullptr, 0);
       AttnParams p;
       p.qkv = scratch; p.ld_qkv = 3 * c; p.out = attn_o; p.ld_out = c; p.bias = f_dev + a.bias_tab;
       p.H = h; p.W = w; p.C = c; p.heads = c / 32; p.wsz = a.wsz; p.kind = a.kind;
@@ -783,16 +804,18 @@ class Engine : public EngineBase {
       capture(dbg_name + ".qkv", scratch, h, w, 3 * c, 3 * c, w);
     }
     capture(dbg_name + ".attn", attn_o, h, w, c, c, w);
-    gemm("gemm_out", a.out, attn_o, h, w, c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld);
+    const bool st = gemm("gemm_out", a.out, attn_o, h, w, c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld, 0, 0, 0, 0, true);
+    stat_tiles_ready = st ? conv_gemm_n_tiles(c) : 0;
     capture(dbg_name, x, h, w, c, ld, w);
   }
   void feedforward(const FFL& f, int s, const std::string& dbg_name) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
     const int64_t ld = stream_ld(s);
-    ln_stats(x, ld, c, m);
-    gemm("gemm_ff1", f.w1, x, h, w, ld, 1, 0, 0, h, w, scratch, 4 * c, rowstat, 1, nullptr, 0);
-    gemm("gemm_ff2", f.w2, scratch, h, w, 4 * c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld);
+    const float2* rs = stream_stats(x, ld, c, m);
+    gemm("gemm_ff1", f.w1, x, h, w, ld, 1, 0, 0, h, w, scratch, 4 * c, rs, 1, nullptr, 0);
+    const bool st = gemm("gemm_ff2", f.w2, scratch, h, w, 4 * c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld, 0, 0, 0, 0, true);
+    stat_tiles_ready = st ? conv_gemm_n_tiles(c) : 0;
     capture(dbg_name, x, h, w, c, ld, w);
   }
   void group_norm_silu(const T* x, int c, int64_t m, int64_t g_off, int64_t b_off, const T* res, int64_t res_ld, T* out,
@@ -835,6 +858,7 @@ class Engine : public EngineBase {
     // encoder
     for (int s = 0; s < 4; ++s) {
       cur_stage = s;
+      stat_tiles_ready = 0;  // the CrossEmbed output has no partials yet
       const StageL& st = stages[s];
       T* x = stream_ptr(s);
       const int64_t ld = stream_ld(s);
@@ -883,6 +907,7 @@ class Engine : public EngineBase {
       capture(sp + ".1", x, sh[s], sw[s], cfg.dim[s], ld, sw[s]);
     }
     // decoder
+    stat_tiles_ready = 0;
     for (int i = 0; i < 3; ++i) {
       cur_stage = 4 + i;
       const UpL& u = ups[i];

@@ -32,7 +32,11 @@ struct ConvGemmParams {
   int n;               // logical output channels
   int n_alloc;         // rows present in wt (rows >= n are zero)
   const float* bias;   // [n] or nullptr
-  const float2* rowstat;  // [M] (mean, rstd) of the input pixel, or nullptr  (LayerNorm fold)
+  const float2* rowstat;  // LayerNorm fold: [M] (mean, rstd) of the input pixel when stat_tiles == 0, else
+                          // [M][stat_tiles] partial (sum, sum of squares) written by the producing GEMM; or nullptr
+  int stat_tiles;         // number of partials per row in `rowstat` (0 = final statistics)
+  float stat_inv_c;       // 1 / channels, with stat_tiles > 0
+  float2* stat_out;       // [M][n_tiles] partial (sum, sum sq) of THIS launch's output rows (fast path only), or nullptr
   const float* colsum;    // [n] sum_c wt[n][c] (with rowstat)
   int act;             // 0 none, 1 exact GELU
   const void* res;     // residual added after activation (indexed like out), or nullptr
@@ -46,6 +50,19 @@ struct ConvGemmParams {
   int py, px;          // mode 2
   int dbg;             // perf-experiment switches (0 in production): 1 skip global stores, 2 skip act, 4 skip K loop, 8 skip residual
 };
+
+__device__ inline float2 row_stats(const ConvGemmParams& p, int m) {
+  if (p.stat_tiles == 0) return p.rowstat[m];
+  float s = 0.f, q = 0.f;
+  for (int t = 0; t < p.stat_tiles; ++t) {  // fixed order: deterministic
+    const float2 v = p.rowstat[(int64_t)m * p.stat_tiles + t];
+    s += v.x;
+    q += v.y;
+  }
+  const float mean = s * p.stat_inv_c;
+  const float var = fmaxf(q * p.stat_inv_c - mean * mean, 0.f);
+  return make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+}
 
 template <typename T>
 __device__ inline f32x4_t mma_sub(const uint4& a, const uint4& b, f32x4_t acc);
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_gemm_kernel(const 
     if (m >= M) continue;
     float mean = 0.f, rstd = 1.f;
     if (p.rowstat) {
-      const float2 st = p.rowstat[m];
+      const float2 st = row_stats(p, m);
       mean = st.x;
       rstd = st.y;
     }
@@ -468,7 +485,7 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void con
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
     const int m = m_blk + wm * 64 + b * 16 + li;
-    st[b] = (p.rowstat && m < M) ? p.rowstat[m] : make_float2(0.f, 1.f);
+    st[b] = (p.rowstat && m < M) ? row_stats(p, m) : make_float2(0.f, 1.f);
   }
   if (has_res) {
     dma_wait_all();
@@ -504,15 +521,28 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void con
     }
   }
   __syncthreads();
-  // (3) whole 16-byte pieces of full rows -> global
+  // (3) whole 16-byte pieces of full rows -> global; optionally the per-row (sum, sum sq) of this tile's
+  //     channels for the next LayerNorm (taken from the ROUNDED values the consumer will read)
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
   constexpr int EPV = 16 / (int)sizeof(T);  // elements per piece
 #pragma unroll 4
   for (int idx = tid; idx < BM * SPR; idx += 256) {
     const int ml = idx / SPR, sl = idx - ml * SPR;
     const int m = m_blk + ml, n0 = n_blk + sl * EPV;
-    if (m >= M || n0 >= p.n) continue;
+    const bool valid = m < M && n0 < p.n;
     const uint4 piece = *reinterpret_cast<const uint4*>(smem + ml * RB + ((sl ^ (ml & (SPR - 1))) << 4));
+    if (p.stat_out) {
+      float f[EPV], s1 = 0.f, s2 = 0.f;
+      unpack16<T>(piece, f);
+      if (valid && n0 + EPV <= p.n) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { s1 += f[e]; s2 += f[e] * f[e]; }
+      }
+#pragma unroll
+      for (int o = 1; o < SPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      if (sl == 0 && m < M) p.stat_out[(int64_t)m * n_tiles + tile_n] = make_float2(s1, s2);
+    }
+    if (!valid) continue;
     int64_t pix;
     int ch;
     if (p.out_mode == 0) {
@@ -589,12 +619,21 @@ inline void launch_conv_gemm_kb(const ConvGemmParams& p, hipStream_t stream) {
     launch_conv_gemm_cfg<T, 256, 16, 4, 1, KB>(p, stream);
 }
 
+// Does this launch take the fast (LDS-DMA) path?  (The engine needs to know: only that path emits LN partials.)
+template <typename T>
+inline bool conv_gemm_is_dma(const ConvGemmParams& p, const void* zero_page) {
+  const int row_bytes = p.cin * (int)sizeof(T);
+  return zero_page != nullptr && p.n >= 48 && row_bytes % 64 == 0 && (p.res == nullptr || p.out_mode == 0) &&
+         (p.out_mode != 1 || p.cout % 8 == 0);
+}
+inline int conv_gemm_n_tiles(int n) { return cdiv(n, n >= 96 ? 128 : 64); }
+
 // gemm_cfg: 0 = automatic, 1 = force KB 128 (2 workgroups/CU), 2 = force KB 64 (4 workgroups/CU)
 template <typename T>
 inline void launch_conv_gemm(const ConvGemmParams& p, const void* zero_page, hipStream_t stream, int gemm_cfg = 0) {
   const int row_bytes = p.cin * (int)sizeof(T);
-  const bool dma_ok = zero_page != nullptr && p.n >= 48 && row_bytes % 64 == 0 &&
-                      (p.res == nullptr || p.out_mode == 0) && (p.out_mode != 1 || p.cout % 8 == 0);
+  const bool dma_ok = conv_gemm_is_dma<T>(p, zero_page);
+  if (p.stat_out && !dma_ok) throw std::runtime_error("conv_gemm: stat_out requested on the slow path");
   if (dma_ok) {
     const int64_t ktot_bytes = (int64_t)p.kh * p.kw * row_bytes;
     // four resident workgroups per CU (KB 64) win whenever there are enough tiles to fill them; with fewer tiles
