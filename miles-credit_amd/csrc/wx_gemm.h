@@ -312,6 +312,18 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, const char* lds_dst)
       : "v"(gsrc), "s"(dst)
       : "memory");
 }
+// same, with the LDS byte address already in an SGPR (hoisted out of the K loop)
+__device__ __forceinline__ void lds_dma16_s(const void* gsrc, unsigned lds_dst_sgpr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst_sgpr)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_sgpr(const char* lds_ptr) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_ptr);
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------
@@ -335,7 +347,9 @@ __device__ __forceinline__ int stage_swz(int row) {
   return KB == 128 ? ((row >> 1) & 7) : (((row >> 3) & 1) * 3);
 }
 
-template <typename T, int BN, int KB>
+// ONE = 1x1 / stride 1 / no padding (every transformer GEMM): the per-lane source pointers are computed once and
+// a K step costs one 64-bit add per DMA instead of the full im2col address + bounds arithmetic.
+template <typename T, int BN, int KB, bool ONE>
 __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void conv_gemm_dma_kernel(
     const ConvGemmParams p, const char* __restrict__ zero_page) {
   constexpr int BM = 128;
@@ -399,24 +413,49 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void con
     b_src[i] = (n < p.n_alloc) ? wt + ((int64_t)n * ktot) * (int64_t)sizeof(T) + piece : nullptr;
   }
   const char* zsrc = zero_page + lslot * 16;
+  // LDS destinations of this wave's DMA instructions, as scalars (stage 0; stage 1 = + STAGE)
+  unsigned a_dst[A_I], b_dst[B_I];
+#pragma unroll
+  for (int i = 0; i < A_I; ++i) a_dst[i] = lds_addr_sgpr(smem + (i * 4 + wave) * 1024);
+#pragma unroll
+  for (int i = 0; i < B_I; ++i) b_dst[i] = lds_addr_sgpr(smem + BM * KB + (i * 4 + wave) * 1024);
+  // weights (and, for ONE, activations): base pointer + per-step stride; invalid rows read the zero page (stride 0)
+  int64_t b_step[B_I];
+#pragma unroll
+  for (int i = 0; i < B_I; ++i) {
+    b_step[i] = b_src[i] ? KB : 0;
+    if (!b_src[i]) b_src[i] = zsrc;
+  }
+  const char* a_src[A_I];
+  int64_t a_step[A_I];
+#pragma unroll
+  for (int i = 0; i < A_I; ++i) {
+    const bool ok = ONE && a_ok[i];  // ONE: iy0 = oy, ix0 = ox, always inside the image
+    a_src[i] = ok ? in + (((int64_t)a_iy0[i] * p.in_w + a_ix0[i]) * p.in_ld) * (int64_t)sizeof(T) + a_piece[i] : zsrc;
+    a_step[i] = ok ? KB : 0;
+  }
 
   int ky = 0, kx = 0, cc = 0;
-  auto issue = [&](char* stage, int ks) {
+  auto issue = [&](unsigned stage_off, int ks) {
 #pragma unroll
     for (int i = 0; i < A_I; ++i) {
-      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-      const bool ok = a_ok[i] && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-      const char* src = ok ? in + (((int64_t)iy * p.in_w + ix) * p.in_ld + cc * BKE) * (int64_t)sizeof(T) + a_piece[i] : zsrc;
-      lds_dma16(src, stage + (i * 4 + wave) * 1024);
+      const char* src;
+      if constexpr (ONE) {
+        src = a_src[i] + (int64_t)ks * a_step[i];
+      } else {
+        const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+        const bool ok = a_ok[i] && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        src = ok ? in + (((int64_t)iy * p.in_w + ix) * p.in_ld + cc * BKE) * (int64_t)sizeof(T) + a_piece[i] : zsrc;
+      }
+      lds_dma16_s(src, a_dst[i] + stage_off);
     }
 #pragma unroll
-    for (int i = 0; i < B_I; ++i) {
-      const char* src = b_src[i] ? b_src[i] + (int64_t)ks * KB : zsrc;
-      lds_dma16(src, stage + BM * KB + (i * 4 + wave) * 1024);
-    }
-    if (++cc == cchunks) {
-      cc = 0;
-      if (++kx == p.kw) { kx = 0; ++ky; }
+    for (int i = 0; i < B_I; ++i) lds_dma16_s(b_src[i] + (int64_t)ks * b_step[i], b_dst[i] + stage_off);
+    if constexpr (!ONE) {
+      if (++cc == cchunks) {
+        cc = 0;
+        if (++kx == p.kw) { kx = 0; ++ky; }
+      }
     }
   };
 
@@ -433,13 +472,13 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void con
 #pragma unroll
   for (int s = 0; s < SUBS; ++s) soff[s] = ((s * 4 + g) ^ sw) * 16;
 
-  issue(smem, 0);
+  issue(0u, 0);
   dma_wait_all();
   __syncthreads();
   const int nk_run = (p.dbg & 4) ? 0 : nk;
   for (int ks = 0; ks < nk_run; ++ks) {
     const char* cur = smem + (ks & 1) * STAGE;
-    if (ks + 1 < nk) issue(smem + ((ks + 1) & 1) * STAGE, ks + 1);
+    if (ks + 1 < nk) issue(((ks + 1) & 1) ? (unsigned)STAGE : 0u, ks + 1);
 #pragma unroll
     for (int s = 0; s < SUBS; ++s) {
       uint4 xf[FM], wf[FN];
@@ -574,12 +613,12 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void con
   }
 }
 
-template <typename T, int BN, int KB>
-inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
+template <typename T, int BN, int KB, bool ONE>
+inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
   constexpr int STAGES = 2 * (128 + BN) * KB;
   constexpr int CT = 128 * BN * (int)sizeof(T);
   constexpr int LDS = STAGES > CT ? STAGES : CT;
-  auto kern = conv_gemm_dma_kernel<T, BN, KB>;
+  auto kern = conv_gemm_dma_kernel<T, BN, KB, ONE>;
   static bool attr_done = false;
   if (!attr_done) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -617,6 +656,14 @@ inline void launch_conv_gemm_kb(const ConvGemmParams& p, hipStream_t stream) {
     launch_conv_gemm_cfg<T, 256, 32, 4, 1, KB>(p, stream);
   else
     launch_conv_gemm_cfg<T, 256, 16, 4, 1, KB>(p, stream);
+}
+
+template <typename T, int BN, int KB>
+inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
+  const bool one = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_y == 0 && p.pad_x == 0 && p.in_h == p.out_h &&
+                   p.in_w == p.out_w;
+  if (one) launch_conv_gemm_dma_v<T, BN, KB, true>(p, zero_page, stream);
+  else launch_conv_gemm_dma_v<T, BN, KB, false>(p, zero_page, stream);
 }
 
 // Does this launch take the fast (LDS-DMA) path?  (The engine needs to know: only that path emits LN partials.)
