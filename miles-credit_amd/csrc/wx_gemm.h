@@ -349,8 +349,11 @@ __device__ __forceinline__ int stage_swz(int row) {
 
 // ONE = 1x1 / stride 1 / no padding (every transformer GEMM): the per-lane source pointers are computed once and
 // a K step costs one 64-bit add per DMA instead of the full im2col address + bounds arithmetic.
-template <typename T, int BN, int KB, bool ONE>
-__global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void conv_gemm_dma_kernel(
+template <int N>
+__device__ __forceinline__ void dma_wait_allow() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BN, int KB, bool ONE, int NST>
+__global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 : 3) : 2) void conv_gemm_dma_kernel(
     const ConvGemmParams p, const char* __restrict__ zero_page) {
   constexpr int BM = 128;
   constexpr int BKE = KB / (int)sizeof(T);
@@ -472,13 +475,19 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void con
 #pragma unroll
   for (int s = 0; s < SUBS; ++s) soff[s] = ((s * 4 + g) ^ sw) * 16;
 
-  issue(0u, 0);
-  dma_wait_all();
+  // NST-stage ring: step ks+NST-1 is issued before the MFMAs of step ks; the wait before the barrier leaves the
+  // youngest NST-2 stages in flight (counted vmcnt -- the only VMEM ops in this loop are the DMA pieces).
+  constexpr int PER_STEP = A_I + B_I;
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j)
+    if (j < nk) issue((unsigned)(j * STAGE), j);
+  if (NST == 3 && nk > 1) dma_wait_allow<PER_STEP>(); else dma_wait_all();
   __syncthreads();
   const int nk_run = (p.dbg & 4) ? 0 : nk;
+  int cur_i = 0, nxt_i = NST - 1;  // ring indices of the stage being computed / being filled
   for (int ks = 0; ks < nk_run; ++ks) {
-    const char* cur = smem + (ks & 1) * STAGE;
-    if (ks + 1 < nk) issue(((ks + 1) & 1) ? (unsigned)STAGE : 0u, ks + 1);
+    const char* cur = smem + cur_i * STAGE;
+    if (ks + NST - 1 < nk) issue((unsigned)(nxt_i * STAGE), ks + NST - 1);
 #pragma unroll
     for (int s = 0; s < SUBS; ++s) {
       uint4 xf[FM], wf[FN];
@@ -491,9 +500,13 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void con
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<T>(wf[a], xf[b], acc[a][b]);
     }
-    dma_wait_all();   // step ks+1 has landed (issued before this step's MFMAs)
+    // step ks+1 must have landed; with 3 stages step ks+2 (just issued) may stay in flight
+    if (NST == 3 && ks + 2 < nk) dma_wait_allow<PER_STEP>(); else dma_wait_all();
     __syncthreads();  // ... for every wave, and everyone is done reading `cur`
+    cur_i = (cur_i + 1 == NST) ? 0 : cur_i + 1;
+    nxt_i = (nxt_i + 1 == NST) ? 0 : nxt_i + 1;
   }
+  if (NST == 3) { dma_wait_all(); __syncthreads(); }  // nothing of the ring is in flight when the tile is reused
 
   // ---- epilogue ---------------------------------------------------------------------------------
   // (1) residual tile -> LDS by DMA (same slot swizzle as the reads below): slot ^= row & (SPR-1)
@@ -613,12 +626,12 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? 4 : 2) void con
   }
 }
 
-template <typename T, int BN, int KB, bool ONE>
+template <typename T, int BN, int KB, bool ONE, int NST>
 inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
-  constexpr int STAGES = 2 * (128 + BN) * KB;
+  constexpr int STAGES = NST * (128 + BN) * KB;
   constexpr int CT = 128 * BN * (int)sizeof(T);
   constexpr int LDS = STAGES > CT ? STAGES : CT;
-  auto kern = conv_gemm_dma_kernel<T, BN, KB, ONE>;
+  auto kern = conv_gemm_dma_kernel<T, BN, KB, ONE, NST>;
   static bool attr_done = false;
   if (!attr_done) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -662,8 +675,13 @@ template <typename T, int BN, int KB>
 inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
   const bool one = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_y == 0 && p.pad_x == 0 && p.in_h == p.out_h &&
                    p.in_w == p.out_w;
-  if (one) launch_conv_gemm_dma_v<T, BN, KB, true>(p, zero_page, stream);
-  else launch_conv_gemm_dma_v<T, BN, KB, false>(p, zero_page, stream);
+  const bool three = KB == 64 && (p.dbg & 128);  // experiment switch: 3-stage ring, 3 workgroups/CU
+  if (one) {
+    if (three) launch_conv_gemm_dma_v<T, BN, KB, true, (KB == 64 ? 3 : 2)>(p, zero_page, stream);
+    else launch_conv_gemm_dma_v<T, BN, KB, true, 2>(p, zero_page, stream);
+  } else {
+    launch_conv_gemm_dma_v<T, BN, KB, false, 2>(p, zero_page, stream);
+  }
 }
 
 // Does this launch take the fast (LDS-DMA) path?  (The engine needs to know: only that path emits LN partials.)
