@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
     for (int j = 0; j < NKF; ++j) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        sv[j][r] = expf(sv[j][r] - mx);
+        // bf16 mode: probabilities are rounded to bf16 for the PV MFMA anyway -> one v_exp_f32 (2^x) instead of
+        // libm's ~12-instruction expf; fp32 mode keeps the exact path
+        if constexpr (sizeof(T) == 2) sv[j][r] = __builtin_amdgcn_exp2f((sv[j][r] - mx) * 1.44269504088896341f);
+        else sv[j][r] = expf(sv[j][r] - mx);
         sum += sv[j][r];
       }
     }
