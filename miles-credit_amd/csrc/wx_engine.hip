@@ -571,6 +571,7 @@ class Engine : public EngineBase {
   int gemm_cfg = 0;
   bool fuse_ln = true;
   float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
+  float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
   int stat_tiles_ready = 0;     // > 0: `statpart` holds partials of the current stream contents (that many per row)
   bool use_patch = true;
   double* gn_acc = nullptr;
@@ -603,6 +604,7 @@ class Engine : public EngineBase {
     WX_HIP(hipMemset(dec, 0, (int64_t)Hd * Wd * ld_dec * sizeof(T)));
     rowstat = (float2*)dalloc(max_hw * sizeof(float2));
     statpart = (float2*)dalloc(max_hw * 8 * sizeof(float2));
+    gnpart = (float2*)dalloc((int64_t)cdiv(max_hw, 128) * cfg.dim[3] * sizeof(float2));
     zero_page = (char*)dalloc(256);
     WX_HIP(hipMemset(zero_page, 0, 256));
     if (const char* e = getenv("WX_NO_DMA")) use_dma = !(e[0] == '1');
@@ -744,7 +746,8 @@ class Engine : public EngineBase {
   // returns true when the launch also produced LayerNorm partials for its output rows (want_stats)
   bool gemm(const char* cls, const ConvW& w, const T* in, int in_h, int in_w, int64_t in_ld, int stride, int pad_y,
             int pad_x, int out_h, int out_w, T* out, int64_t out_ld, const float2* rs, int act, const T* res,
-            int64_t res_ld, int out_mode = 0, int cout = 0, int py = 0, int px = 0, bool want_stats = false) {
+            int64_t res_ld, int out_mode = 0, int cout = 0, int py = 0, int px = 0, bool want_stats = false,
+            bool want_gn = false) {
     ConvGemmParams p;
     std::memset(&p, 0, sizeof(p));
     p.in = in; p.in_h = in_h; p.in_w = in_w; p.in_ld = in_ld; p.cin = w.cin;
@@ -763,6 +766,10 @@ class Engine : public EngineBase {
     bool made_stats = false;
     if (want_stats && fuse_ln && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr)) {
       p.stat_out = statpart;
+      made_stats = true;
+    }
+    if (want_gn && fuse_ln && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr)) {
+      p.gn_out = gnpart;
       made_stats = true;
     }
     timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream, gemm_cfg); });
@@ -819,16 +826,23 @@ class Engine : public EngineBase {
     capture(dbg_name, x, h, w, c, ld, w);
   }
   void group_norm_silu(const T* x, int c, int64_t m, int64_t g_off, int64_t b_off, const T* res, int64_t res_ld, T* out,
-                       int64_t out_ld) {
+                       int64_t out_ld, bool have_partials) {
     constexpr int VEC = 16 / (int)sizeof(T);
     if (c / VEC > 256) throw ConfigError("GroupNorm width unsupported");
-    WX_HIP(hipMemsetAsync(gn_acc, 0, 2 * c * sizeof(double), cur_stream));
-    const int rows_per_block = 256 / (c / VEC);
-    int blocks = (int)std::min<int64_t>(2048, (m + rows_per_block - 1) / rows_per_block);
-    timed("gn_stats", 0.0, (double)m * c * sizeof(T), [&] {
-      hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(blocks), dim3(256), 2 * c * sizeof(double), cur_stream, x, (int64_t)c, c, m, gn_acc);
-      WX_HIP(hipGetLastError());
-    });
+    if (have_partials) {  // the producing conv's epilogue left per-tile (sum, sum sq): just fold them
+      timed("gn_stats", 0.0, (double)cdiv(m, 128) * c * 8.0, [&] {
+        hipLaunchKernelGGL(gn_fold_partials_kernel, dim3(c), dim3(256), 0, cur_stream, gnpart, cdiv(m, 128), c, gn_acc);
+        WX_HIP(hipGetLastError());
+      });
+    } else {
+      WX_HIP(hipMemsetAsync(gn_acc, 0, 2 * c * sizeof(double), cur_stream));
+      const int rows_per_block = 256 / (c / VEC);
+      int blocks = (int)std::min<int64_t>(2048, (m + rows_per_block - 1) / rows_per_block);
+      timed("gn_stats", 0.0, (double)m * c * sizeof(T), [&] {
+        hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(blocks), dim3(256), 2 * c * sizeof(double), cur_stream, x, (int64_t)c, c, m, gn_acc);
+        WX_HIP(hipGetLastError());
+      });
+    }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(c, 128)), dim3(128), 0, cur_stream, gn_acc, f_dev + g_off, f_dev + b_off, c,
                        cfg.dim[0], (double)m, 1e-5f, gn_scale, gn_shift);
     WX_HIP(hipGetLastError());
@@ -918,10 +932,12 @@ class Engine : public EngineBase {
       const int64_t mo = (int64_t)sh[so] * sw[so];
       T *scut = dtmp[0], *ta = dtmp[1], *tb = dtmp[2];
       gemm("gemm_convT2", u.convt, in, sh[si], sw[si], in_ld, 1, 0, 0, sh[si], sw[si], scut, u.cout, nullptr, 0, nullptr, 0, 1, u.cout);
-      gemm("gemm_conv3", u.c1, scut, sh[so], sw[so], u.cout, 1, 1, 1, sh[so], sw[so], ta, u.cout, nullptr, 0, nullptr, 0);
-      group_norm_silu(ta, u.cout, mo, u.g1, u.b1, nullptr, 0, tb, u.cout);
-      gemm("gemm_conv3", u.c2, tb, sh[so], sw[so], u.cout, 1, 1, 1, sh[so], sw[so], ta, u.cout, nullptr, 0, nullptr, 0);
-      group_norm_silu(ta, u.cout, mo, u.g2, u.b2, scut, u.cout, cat[so], 2 * cfg.dim[so]);
+      bool gp = gemm("gemm_conv3", u.c1, scut, sh[so], sw[so], u.cout, 1, 1, 1, sh[so], sw[so], ta, u.cout, nullptr, 0, nullptr, 0,
+                     0, 0, 0, 0, false, true);
+      group_norm_silu(ta, u.cout, mo, u.g1, u.b1, nullptr, 0, tb, u.cout, gp);
+      gp = gemm("gemm_conv3", u.c2, tb, sh[so], sw[so], u.cout, 1, 1, 1, sh[so], sw[so], ta, u.cout, nullptr, 0, nullptr, 0,
+                0, 0, 0, 0, false, true);
+      group_norm_silu(ta, u.cout, mo, u.g2, u.b2, scut, u.cout, cat[so], 2 * cfg.dim[so], gp);
       capture("up_block" + std::to_string(i + 1), cat[so], sh[so], sw[so], u.cout, 2 * cfg.dim[so], sw[so]);
     }
     cur_stage = 7;

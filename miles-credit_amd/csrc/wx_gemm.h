@@ -37,6 +37,7 @@ struct ConvGemmParams {
   int stat_tiles;         // number of partials per row in `rowstat` (0 = final statistics)
   float stat_inv_c;       // 1 / channels, with stat_tiles > 0
   float2* stat_out;       // [M][n_tiles] partial (sum, sum sq) of THIS launch's output rows (fast path only), or nullptr
+  float2* gn_out;         // [m_tiles][n] per-channel (sum, sum sq) over each 128-row tile of the output (GroupNorm), or nullptr
   const float* colsum;    // [n] sum_c wt[n][c] (with rowstat)
   int act;             // 0 none, 1 exact GELU
   const void* res;     // residual added after activation (indexed like out), or nullptr
@@ -574,9 +575,13 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
   }
   __syncthreads();
   // (3) whole 16-byte pieces of full rows -> global; optionally the per-row (sum, sum sq) of this tile's
-  //     channels for the next LayerNorm (taken from the ROUNDED values the consumer will read)
+  //     channels for the next LayerNorm, or the per-channel (sum, sum sq) over the tile's rows for GroupNorm
+  //     (both taken from the ROUNDED values the consumer will read; fixed summation order: deterministic)
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
   constexpr int EPV = 16 / (int)sizeof(T);  // elements per piece
+  float gs[EPV], gq[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) gs[e] = gq[e] = 0.f;
 #pragma unroll 4
   for (int idx = tid; idx < BM * SPR; idx += 256) {
     const int ml = idx / SPR, sl = idx - ml * SPR;
@@ -593,6 +598,12 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
 #pragma unroll
       for (int o = 1; o < SPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
       if (sl == 0 && m < M) p.stat_out[(int64_t)m * n_tiles + tile_n] = make_float2(s1, s2);
+    }
+    if (p.gn_out && valid) {  // this thread sees the same channel slot `sl` in every pass (256 % SPR == 0)
+      float f[EPV];
+      unpack16<T>(piece, f);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { gs[e] += f[e]; gq[e] += f[e] * f[e]; }
     }
     if (!valid) continue;
     int64_t pix;
@@ -622,6 +633,30 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
           else out[pix * p.out_ld + ch + r] = __builtin_bit_cast(T, w[r]);
         }
       }
+    }
+  }
+  if (p.gn_out) {
+    // lanes sl, sl+SPR, ... of a wave hold the same channels -> fold them, then fold the 4 waves through LDS
+#pragma unroll
+    for (int o = SPR; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { gs[e] += __shfl_xor(gs[e], o); gq[e] += __shfl_xor(gq[e], o); }
+    }
+    __syncthreads();  // everyone is done reading the output tile
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][BN][2]
+    if (lane < SPR) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        red[((wave * BN) + lane * EPV + e) * 2 + 0] = gs[e];
+        red[((wave * BN) + lane * EPV + e) * 2 + 1] = gq[e];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n_blk + tid < p.n) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      p.gn_out[(int64_t)tile_m * p.n + n_blk + tid] = make_float2(a, b);
     }
   }
 }
@@ -698,7 +733,7 @@ template <typename T>
 inline void launch_conv_gemm(const ConvGemmParams& p, const void* zero_page, hipStream_t stream, int gemm_cfg = 0) {
   const int row_bytes = p.cin * (int)sizeof(T);
   const bool dma_ok = conv_gemm_is_dma<T>(p, zero_page);
-  if (p.stat_out && !dma_ok) throw std::runtime_error("conv_gemm: stat_out requested on the slow path");
+  if ((p.stat_out || p.gn_out) && !dma_ok) throw std::runtime_error("conv_gemm: statistics output requested on the slow path");
   if (dma_ok) {
     const int64_t ktot_bytes = (int64_t)p.kh * p.kw * row_bytes;
     // four resident workgroups per CU (KB 64) win whenever there are enough tiles to fill them; with fewer tiles
