@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 1
+#define WX_ABI_VERSION 2
 
 typedef struct wx_engine* wx_handle;
 
@@ -35,6 +35,12 @@ enum wx_status {
   WX_ERR_HIP = -3,         /* a HIP runtime call failed */
   WX_ERR_MISSING = -4,     /* a required state-dict tensor was never loaded */
   WX_ERR_SHAPE = -5        /* tensor shape does not match the configuration */
+};
+
+enum wx_arch {
+  WX_ARCH_CROSSFORMER = 0, /* credit/models/crossformer.py (model.type: crossformer): ConvTranspose decoder */
+  WX_ARCH_WXFORMER = 1     /* credit/models/wxformer/crossformer.py (model.type: wxformer / wxformer_base): sub-pixel conv
+                              + PixelShuffle decoder, ZeroPad2d-wrapped CrossEmbed branches (keys convs.<i>.1.*) */
 };
 
 enum wx_precision {
@@ -60,6 +66,7 @@ typedef struct wx_config {
   int32_t use_spectral_norm;
   int32_t precision;                /* enum wx_precision */
   int32_t max_batch;                /* largest B accepted by wx_forward (>= 1) */
+  int32_t arch;                     /* enum wx_arch: which reference class the state dict belongs to */
 } wx_config;
 
 /* ---- lifecycle -----------------------------------------------------------

@@ -48,7 +48,7 @@ struct FFL { ConvW w1, w2; };
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
 struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmbed branch (wx_embed.h)
 struct StageL { std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks; };
-struct UpL { ConvW convt, c1, c2; int64_t g1 = -1, b1 = -1, g2 = -1, b2 = -1; int cin = 0, cout = 0; };
+struct UpL { ConvW convt, convps, sharp, c1, c2; int64_t g1 = -1, b1 = -1, g2 = -1, b2 = -1; int cin = 0, cout = 0; };
 
 struct KernelStatAcc { int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
 
@@ -97,6 +97,7 @@ class Engine : public EngineBase {
     if (cfg.abi_version != WX_ABI_VERSION) throw ConfigError("wx_config.abi_version mismatch");
     if (cfg.frames < 1 || cfg.output_frames < 1) throw ConfigError("frames/output_frames must be >= 1");
     if (cfg.dim_head != 32) throw ConfigError("engine supports dim_head == 32 only (reference default)");
+    if (cfg.arch != WX_ARCH_CROSSFORMER && cfg.arch != WX_ARCH_WXFORMER) throw ConfigError("unknown wx_config.arch");
     C_in = (cfg.channels * cfg.levels + cfg.surface_channels + cfg.input_only_channels) * cfg.frames;
     C_out = (cfg.channels * cfg.levels + cfg.surface_channels + cfg.output_only_channels) * cfg.output_frames;
     Hp = cfg.image_height + (cfg.pad_activate ? cfg.pad_lat[0] + cfg.pad_lat[1] : 0);
@@ -114,10 +115,12 @@ class Engine : public EngineBase {
         const int k = cfg.embed_kernels[s][b];
         if (k < st) throw ConfigError("cross-embed kernel smaller than stride");
         const int pd = (k - st) / 2;
-        const int h2 = (h + 2 * pd - k) / st + 1, w2 = (w + 2 * pd - k) / st + 1;
+        // legacy: symmetric padding pd; wxformer: ZeroPad2d(lo = (k-s)/2, hi = (k-s) - lo) then an un-padded conv
+        const int pad_total = cfg.arch == WX_ARCH_WXFORMER ? (k - st) : 2 * pd;
+        const int h2 = (h + pad_total - k) / st + 1, w2 = (w + pad_total - k) / st + 1;
         if (oh >= 0 && (h2 != oh || w2 != ow)) throw ConfigError("cross-embed branches disagree on output size");
         oh = h2; ow = w2;
-        if (s == 0) halo = std::max(halo, pd);
+        if (s == 0) halo = std::max(halo, pad_total - pd);
       }
       sh[s] = h = oh; sw[s] = w = ow;
       if (cfg.dim[s] % 32) throw ConfigError("dim must be a multiple of 32");
@@ -182,7 +185,7 @@ class Engine : public EngineBase {
       for (size_t i = 1; i < ks.size(); ++i) { sc.push_back((int)(cout / (1 << i))); acc += sc.back(); }
       sc.push_back(cout - acc);
       for (size_t b = 0; b < ks.size(); ++b)
-        add_conv("layers." + std::to_string(s) + ".0.convs." + std::to_string(b), {sc[b], cin, ks[b], ks[b]}, true);
+        add_conv(embed_key(s, (int)b), {sc[b], cin, ks[b], ks[b]}, true);
       const int dq = cout / 4;
       for (int d = 0; d < cfg.depth[s]; ++d) {
         for (int j = 0; j < 4; ++j) {
@@ -215,18 +218,42 @@ class Engine : public EngineBase {
     const int ups[3][2] = {{last, last / 2}, {2 * (last / 2), last / 4}, {2 * (last / 4), last / 8}};
     for (int i = 0; i < 3; ++i) {
       const std::string p = "up_block" + std::to_string(i + 1);
-      add_conv(p + ".conv", {ups[i][0], ups[i][1], 2, 2}, true, true);
+      if (cfg.arch == WX_ARCH_WXFORMER) {  // UpBlockPS (wxformer/crossformer.py:137-162)
+        add_conv(p + ".conv", {4 * ups[i][1], ups[i][0], 3, 3}, true);
+        add_conv(p + ".sharp", {ups[i][1], ups[i][1], 3, 3}, true);
+      } else {
+        add_conv(p + ".conv", {ups[i][0], ups[i][1], 2, 2}, true, true);
+      }
       for (int j : {0, 3}) {
         add_conv(p + ".b." + std::to_string(j), {ups[i][1], ups[i][1], 3, 3}, true);
         add_key(p + ".b." + std::to_string(j + 1) + ".weight", {ups[i][1]});
         add_key(p + ".b." + std::to_string(j + 1) + ".bias", {ups[i][1]});
       }
     }
-    add_conv("up_block4", {2 * (last / 8), C_out, 4, 4}, true, true);
+    if (cfg.arch == WX_ARCH_WXFORMER) {  // Sequential(conv3x3 -> PixelShuffle -> conv3x3) (wxformer/crossformer.py:817-830)
+      add_conv("up_block4.0", {4 * C_out, 2 * (last / 8), 3, 3}, true);
+      add_conv("up_block4.2", {C_out, C_out, 3, 3}, true);
+    } else {
+      add_conv("up_block4", {2 * (last / 8), C_out, 4, 4}, true, true);
+    }
+  }
+  std::string embed_key(int s, int b) const {
+    return "layers." + std::to_string(s) + ".0.convs." + std::to_string(b) + (cfg.arch == WX_ARCH_WXFORMER ? ".1" : "");
   }
 
   void load_tensor(const char* key, const float* data, int ndim, const int64_t* shape) override {
     auto it = tensors.find(key);
+    if (it == tensors.end() && cfg.arch == WX_ARCH_WXFORMER) {
+      // pre-ZeroPad2d checkpoints keep CrossEmbed parameters at convs.<i>.<suffix>; the reference migrates them
+      // to convs.<i>.1.<suffix> on load (wxformer/crossformer.py:247-283) -- do the same
+      const std::string k(key);
+      const size_t pos = k.find(".0.convs.");
+      if (k.rfind("layers.", 0) == 0 && pos != std::string::npos) {
+        const size_t dot = k.find('.', pos + 9);
+        if (dot != std::string::npos && !(k.size() > dot + 2 && isdigit((unsigned char)k[dot + 1]) && k[dot + 2] == '.'))
+          it = tensors.find(k.substr(0, dot) + ".1" + k.substr(dot));
+      }
+    }
     if (it == tensors.end()) {
       // reference semantics: load_state_dict(strict=False) ignores unexpected keys (base_model.py:77-80)
       return;
@@ -263,6 +290,9 @@ class Engine : public EngineBase {
   StageL stages[4];
   UpL ups[3];
   ConvW up4[4];
+  ConvW ps4, fin4;   // wxformer head: sub-pixel conv (shuffled rows) and the final 3x3 conv
+  int cpad4 = 0;
+  T* ps4_buf = nullptr;
 
   // eval-mode spectral norm: W / (u . (W_mat v)); W_mat rows = dim 0 (dim 1 for ConvTranspose2d)
   std::vector<double> folded(const std::string& p, bool transposed) {
@@ -316,25 +346,28 @@ class Engine : public EngineBase {
     return off;
   }
   // Conv2d weight W[n][c][kh][kw] (rows [r0, r1)) -> [n][kh][kw][cpad]; optional LayerNorm fold (g, b per input channel)
+  // row_src (optional): output row o takes reference row row_src[o] (-1 = all-zero row) instead of r0 + o
   ConvW make_conv(const std::string& p, int r0, int r1, int cin, int cpad, int kh, int kw, bool has_bias,
-                  const float* ln_g, const float* ln_b) {
+                  const float* ln_g, const float* ln_b, const std::vector<int>* row_src = nullptr) {
     const std::vector<double> w = folded(p, false);
-    const int n = r1 - r0;
+    const int n = row_src ? (int)row_src->size() : r1 - r0;
     const int64_t k = (int64_t)kh * kw * cpad;
     std::vector<double> rows((size_t)n * k, 0.0);
     std::vector<float> bias(n, 0.f), colsum;
     const HostTensor* bt = has_bias ? &need(p + ".bias") : nullptr;
     for (int o = 0; o < n; ++o) {
       double tshift = 0.0;
+      const int ro = row_src ? (*row_src)[o] : r0 + o;
+      if (ro < 0) continue;  // zero row (channel padding)
       for (int c = 0; c < cin; ++c)
         for (int y = 0; y < kh; ++y)
           for (int x = 0; x < kw; ++x) {
-            double v = w[(((int64_t)(r0 + o) * cin + c) * kh + y) * kw + x];
+            double v = w[(((int64_t)ro * cin + c) * kh + y) * kw + x];
             if (ln_b) tshift += v * ln_b[c];
             if (ln_g) v *= ln_g[c];
             rows[(size_t)o * k + ((int64_t)y * kw + x) * cpad + c] = v;
           }
-      bias[o] = (float)(tshift + (bt ? (double)bt->data[r0 + o] : 0.0));
+      bias[o] = (float)(tshift + (bt ? (double)bt->data[ro] : 0.0));
     }
     ConvW cw;
     cw.n = n; cw.cin = cpad; cw.cin_true = cin; cw.kh = kh; cw.kw = kw;
@@ -503,7 +536,7 @@ class Engine : public EngineBase {
       for (size_t b = 0; b < ks.size(); ++b) {
         const int co = (b + 1 < ks.size()) ? (int)(cout / (1 << (b + 1))) : cout - acc;
         acc += co;
-        const std::string bp = "layers." + std::to_string(s) + ".0.convs." + std::to_string(b);
+        const std::string bp = embed_key(s, (int)b);
         const bool patch_ok = s == 0 && cfg.embed_strides[0] == 2 && co % 4 == 0 && ks.back() == 32 &&
                               ((ks[b] == 32 && co <= 16) || (ks[b] == 16 && co <= 16) || (ks[b] == 8 && co <= 32));
         st.patch.push_back(patch_ok ? make_patch(bp, co, cin, cpad, ks[b]) : PatchW());
@@ -528,14 +561,33 @@ class Engine : public EngineBase {
       UpL u;
       u.cin = upc[i][0]; u.cout = upc[i][1];
       if (u.cout % 32) throw ConfigError("decoder widths must be multiples of 32");
-      u.convt = make_convt2(p + ".conv", u.cin, u.cout);
+      if (cfg.arch == WX_ARCH_WXFORMER) {
+        // sub-pixel conv: reference channel c*4+q feeds sub-pixel q of channel c (PixelShuffle); rows reordered
+        // to q*cout + c so the ConvT-style scatter epilogue (out_mode 1) performs the shuffle
+        std::vector<int> src(4 * u.cout);
+        for (int q = 0; q < 4; ++q)
+          for (int c = 0; c < u.cout; ++c) src[q * u.cout + c] = c * 4 + q;
+        u.convps = make_conv(p + ".conv", 0, 0, u.cin, u.cin, 3, 3, true, nullptr, nullptr, &src);
+        u.sharp = make_conv(p + ".sharp", 0, u.cout, u.cout, u.cout, 3, 3, true, nullptr, nullptr);
+      } else {
+        u.convt = make_convt2(p + ".conv", u.cin, u.cout);
+      }
       u.c1 = make_conv(p + ".b.0", 0, u.cout, u.cout, u.cout, 3, 3, true, nullptr, nullptr);
       u.c2 = make_conv(p + ".b.3", 0, u.cout, u.cout, u.cout, 3, 3, true, nullptr, nullptr);
       u.g1 = push_f(need(p + ".b.1.weight").data); u.b1 = push_f(need(p + ".b.1.bias").data);
       u.g2 = push_f(need(p + ".b.4.weight").data); u.b2 = push_f(need(p + ".b.4.bias").data);
       ups[i] = u;
     }
-    make_convt4("up_block4", 2 * (last / 8), C_out);
+    if (cfg.arch == WX_ARCH_WXFORMER) {
+      cpad4 = ((C_out + 31) / 32) * 32;  // padded channel count of the shuffled map (zero rows / zero input weights)
+      std::vector<int> src(4 * cpad4, -1);
+      for (int q = 0; q < 4; ++q)
+        for (int c = 0; c < C_out; ++c) src[q * cpad4 + c] = c * 4 + q;
+      ps4 = make_conv("up_block4.0", 0, 0, 2 * (last / 8), 2 * (last / 8), 3, 3, true, nullptr, nullptr, &src);
+      fin4 = make_conv("up_block4.2", 0, C_out, C_out, cpad4, 3, 3, true, nullptr, nullptr);
+    } else {
+      make_convt4("up_block4", 2 * (last / 8), C_out);
+    }
 
     // upload
     if (wt_dev) { (void)hipFree(wt_dev); allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)wt_dev)); wt_dev = nullptr; }
@@ -562,7 +614,7 @@ class Engine : public EngineBase {
   T* x3 = nullptr;           // stage-3 stream
   T* scratch = nullptr;      // qkv / FF hidden
   T* attn_o = nullptr;       // attention output before to_out
-  T* dtmp[3] = {nullptr, nullptr, nullptr};  // decoder temporaries
+  T* dtmp[4] = {nullptr, nullptr, nullptr, nullptr};  // decoder temporaries
   T* dec = nullptr;          // up_block4 output [Hd][Wd][ld_dec]
   float2* rowstat = nullptr;
   char* zero_page = nullptr;
@@ -599,7 +651,8 @@ class Engine : public EngineBase {
     attn_o = (T*)dalloc(max_ao * sizeof(T));
     int64_t max_dt = 0;
     for (int i = 0; i < 3; ++i) max_dt = std::max(max_dt, (int64_t)sh[2 - i] * sw[2 - i] * ups[i].cout);
-    for (int i = 0; i < 3; ++i) dtmp[i] = (T*)dalloc(max_dt * sizeof(T));
+    for (int i = 0; i < 4; ++i) dtmp[i] = (T*)dalloc(max_dt * sizeof(T));
+    if (cfg.arch == WX_ARCH_WXFORMER) ps4_buf = (T*)dalloc((int64_t)Hd * Wd * cpad4 * sizeof(T));
     dec = (T*)dalloc((int64_t)Hd * Wd * ld_dec * sizeof(T));
     WX_HIP(hipMemset(dec, 0, (int64_t)Hd * Wd * ld_dec * sizeof(T)));
     rowstat = (float2*)dalloc(max_hw * sizeof(float2));
@@ -931,7 +984,15 @@ class Engine : public EngineBase {
       const int64_t in_ld = (i == 0) ? cfg.dim[3] : 2 * cfg.dim[si];
       const int64_t mo = (int64_t)sh[so] * sw[so];
       T *scut = dtmp[0], *ta = dtmp[1], *tb = dtmp[2];
-      gemm("gemm_convT2", u.convt, in, sh[si], sw[si], in_ld, 1, 0, 0, sh[si], sw[si], scut, u.cout, nullptr, 0, nullptr, 0, 1, u.cout);
+      if (cfg.arch == WX_ARCH_WXFORMER) {
+        // x = PixelShuffle(conv3x3(x)); x = x + sharp(x)   (wxformer/crossformer.py:157-158)
+        gemm("gemm_convPS", u.convps, in, sh[si], sw[si], in_ld, 1, 1, 1, sh[si], sw[si], dtmp[3], u.cout, nullptr, 0, nullptr, 0, 1,
+             u.cout);
+        gemm("gemm_conv3", u.sharp, dtmp[3], sh[so], sw[so], u.cout, 1, 1, 1, sh[so], sw[so], scut, u.cout, nullptr, 0, dtmp[3],
+             u.cout);
+      } else {
+        gemm("gemm_convT2", u.convt, in, sh[si], sw[si], in_ld, 1, 0, 0, sh[si], sw[si], scut, u.cout, nullptr, 0, nullptr, 0, 1, u.cout);
+      }
       bool gp = gemm("gemm_conv3", u.c1, scut, sh[so], sw[so], u.cout, 1, 1, 1, sh[so], sw[so], ta, u.cout, nullptr, 0, nullptr, 0,
                      0, 0, 0, 0, false, true);
       group_norm_silu(ta, u.cout, mo, u.g1, u.b1, nullptr, 0, tb, u.cout, gp);
@@ -941,10 +1002,16 @@ class Engine : public EngineBase {
       capture("up_block" + std::to_string(i + 1), cat[so], sh[so], sw[so], u.cout, 2 * cfg.dim[so], sw[so]);
     }
     cur_stage = 7;
-    for (int q = 0; q < 4; ++q) {
-      const int py = q >> 1, px = q & 1;
-      gemm("gemm_convT4", up4[q], cat[0], sh[0], sw[0], 2 * cfg.dim[0], 1, 1 - py, 1 - px, sh[0], sw[0], dec, ld_dec, nullptr, 0,
-           nullptr, 0, 2, 0, py, px);
+    if (cfg.arch == WX_ARCH_WXFORMER) {
+      gemm("gemm_convPS", ps4, cat[0], sh[0], sw[0], 2 * cfg.dim[0], 1, 1, 1, sh[0], sw[0], ps4_buf, cpad4, nullptr, 0, nullptr, 0, 1,
+           cpad4);
+      gemm("gemm_conv3", fin4, ps4_buf, Hd, Wd, cpad4, 1, 1, 1, Hd, Wd, dec, ld_dec, nullptr, 0, nullptr, 0);
+    } else {
+      for (int q = 0; q < 4; ++q) {
+        const int py = q >> 1, px = q & 1;
+        gemm("gemm_convT4", up4[q], cat[0], sh[0], sw[0], 2 * cfg.dim[0], 1, 1 - py, 1 - px, sh[0], sw[0], dec, ld_dec, nullptr, 0,
+             nullptr, 0, 2, 0, py, px);
+      }
     }
     capture("up_block4", dec, Hd, Wd, C_out, ld_dec, Wd);
   }

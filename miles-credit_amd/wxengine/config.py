@@ -49,9 +49,9 @@ class WXConfig:
     pad_lat: Tuple[int, int] = (0, 0)
     pad_lon: Tuple[int, int] = (0, 0)
     post_conf: Dict = field(default_factory=lambda: {"activate": False})
-    # which reference class the weights belong to: "crossformer" (legacy
-    # ConvTranspose decoder, credit/models/crossformer.py) — the class every
-    # BASELINE YAML selects.
+    # which reference class the weights belong to: "crossformer" (legacy ConvTranspose decoder,
+    # credit/models/crossformer.py — the class every BASELINE YAML selects) or "wxformer"
+    # (credit/models/wxformer/crossformer.py: same encoder, sub-pixel conv + PixelShuffle decoder).
     arch: str = "crossformer"
 
     # ------------------------------------------------------------------ #
@@ -86,11 +86,12 @@ class WXConfig:
 
     # ------------------------------------------------------------------ #
     def validate(self):
-        if self.arch != "crossformer":
-            raise ValueError(f"unsupported arch {self.arch!r} (only the legacy 'crossformer' decoder is built)")
+        if self.arch not in ("crossformer", "wxformer"):
+            raise ValueError(f"unsupported arch {self.arch!r} ('crossformer' = legacy ConvTranspose decoder, "
+                             "'wxformer' = PixelShuffle decoder)")
         if self.patch_height != 1 or self.patch_width != 1:
             raise ValueError("patch_height/patch_width > 1 (CubeEmbedding path) is not supported by the engine")
-        if self.upsample_v_conv:
+        if self.upsample_v_conv and self.arch == "crossformer":
             raise ValueError("upsample_v_conv=True decoder variant is not supported by the engine")
         if self.attention_type is not None:
             raise ValueError("decoder attention_type is not supported by the engine")
@@ -145,8 +146,12 @@ class WXConfig:
         h, w = self.padded_hw
         out = []
         for s, ks in zip(self.cross_embed_strides, self.cross_embed_kernel_sizes):
-            hs = {(h + 2 * ((k - s) // 2) - k) // s + 1 for k in ks}
-            ws = {(w + 2 * ((k - s) // 2) - k) // s + 1 for k in ks}
+            if self.arch == "wxformer":  # ZeroPad2d with total padding k-s (wxformer/crossformer.py:166-181)
+                hs = {(h + (k - s) - k) // s + 1 for k in ks}
+                ws = {(w + (k - s) - k) // s + 1 for k in ks}
+            else:
+                hs = {(h + 2 * ((k - s) // 2) - k) // s + 1 for k in ks}
+                ws = {(w + 2 * ((k - s) // 2) - k) // s + 1 for k in ks}
             if len(hs) != 1 or len(ws) != 1:
                 raise ValueError("cross-embed branches disagree on output size")
             h, w = hs.pop(), ws.pop()
@@ -212,7 +217,8 @@ class WXConfig:
         for s in range(4):
             cin, cout = dims[s], dims[s + 1]
             for b, (k, co) in enumerate(self.embed_dims(s)):
-                conv(f"layers.{s}.0.convs.{b}", (co, cin, k, k))
+                # wxformer wraps each branch in Sequential(ZeroPad2d, Conv2d): parameters live at convs.<b>.1
+                conv(f"layers.{s}.0.convs.{b}" + (".1" if self.arch == "wxformer" else ""), (co, cin, k, k))
             dq = cout // 4
             for d in range(self.depth[s]):
                 for j in (0, 1, 2, 3):
@@ -244,6 +250,17 @@ class WXConfig:
         spec["cube_embedding.norm.bias"] = (self.dim[0],)
         last = self.dim[-1]
         ups = [(last, last // 2), (2 * (last // 2), last // 4), (2 * (last // 4), last // 8)]
+        if self.arch == "wxformer":  # UpBlockPS / up_block4 Sequential (wxformer/crossformer.py:137-162, 817-830)
+            for i, (ci, co) in enumerate(ups, start=1):
+                conv(f"up_block{i}.conv", (4 * co, ci, 3, 3))
+                conv(f"up_block{i}.sharp", (co, co, 3, 3))
+                for j in (0, 3):
+                    conv(f"up_block{i}.b.{j}", (co, co, 3, 3))
+                    spec[f"up_block{i}.b.{j + 1}.weight"] = (co,)
+                    spec[f"up_block{i}.b.{j + 1}.bias"] = (co,)
+            conv("up_block4.0", (4 * self.output_channels, 2 * (last // 8), 3, 3))
+            conv("up_block4.2", (self.output_channels, self.output_channels, 3, 3))
+            return spec
         for i, (ci, co) in enumerate(ups, start=1):
             conv(f"up_block{i}.conv", (ci, co, 2, 2), transposed=True)
             for j in (0, 3):
@@ -293,6 +310,19 @@ def named_config(name: str) -> WXConfig:
                   dim=[32, 64, 128, 256], depth=[2, 2, 2, 2], global_window_size=[10, 5, 2, 1],
                   local_window_size=10,
                   padding_conf=dict(activate=True, mode="earth", pad_lat=[40, 40], pad_lon=[80, 80]))
+    elif name == "T0W":  # T0 geometry with the wxformer (PixelShuffle) decoder
+        return WXConfig.from_model_conf(_t0_conf(base), arch="wxformer")
+    elif name == "C1W":  # config/gen_2/examples/example-v2026.2.yml-style 1deg wxformer (C1 geometry, PS decoder)
+        mc = dict(base, image_height=181, image_width=360, levels=18,
+                  dim=[64, 128, 256, 512], depth=[2, 2, 4, 2], global_window_size=[8, 4, 2, 1], local_window_size=3,
+                  padding_conf=dict(activate=True, mode="earth", pad_lat=[30, 30], pad_lon=[12, 12]))
+        return WXConfig.from_model_conf(mc, arch="wxformer")
     else:
         raise KeyError(name)
     return WXConfig.from_model_conf(mc)
+
+
+def _t0_conf(base):
+    return dict(base, image_height=37, image_width=72, levels=3, output_only_channels=3,
+                dim=[32, 64, 128, 256], depth=[1, 1, 2, 1], global_window_size=[4, 2, 2, 1], local_window_size=3,
+                padding_conf=dict(activate=True, mode="earth", pad_lat=[6, 6], pad_lon=[12, 12]))

@@ -17,7 +17,8 @@ from .config import WXConfig
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwxengine.so")
 
-WX_ABI_VERSION = 1
+WX_ABI_VERSION = 2
+ARCH = {"crossformer": 0, "wxformer": 1}
 PREC = {"fp32": 0, "bf16": 1}
 
 
@@ -33,6 +34,7 @@ class wx_config(C.Structure):
         ("n_embed_kernels", C.c_int32 * 4), ("embed_kernels", (C.c_int32 * 4) * 4), ("embed_strides", C.c_int32 * 4),
         ("pad_activate", C.c_int32), ("pad_lat", C.c_int32 * 2), ("pad_lon", C.c_int32 * 2),
         ("interp", C.c_int32), ("use_spectral_norm", C.c_int32), ("precision", C.c_int32), ("max_batch", C.c_int32),
+        ("arch", C.c_int32),
     ]
 
 
@@ -121,6 +123,7 @@ def make_c_config(cfg: WXConfig, precision: str = "bf16", max_batch: int = 1) ->
     c.use_spectral_norm = int(cfg.use_spectral_norm)
     c.precision = PREC[precision]
     c.max_batch = max_batch
+    c.arch = ARCH[getattr(cfg, "arch", "crossformer")]
     return c
 
 

@@ -41,10 +41,10 @@ def _mangle(key: str) -> str:
 class WXFormerHIP(_Base):
     """CrossFormer forward on MI355X. Same kwargs as the reference class; extra kwarg `precision`."""
 
-    def __init__(self, precision: str = "bf16", **model_conf):
+    def __init__(self, precision: str = "bf16", arch: str = "crossformer", **model_conf):
         super().__init__()
         model_conf = copy.deepcopy(model_conf)
-        self.cfg = WXConfig.from_model_conf(model_conf)
+        self.cfg = WXConfig.from_model_conf(model_conf, arch=arch)
         self.precision = precision
         cfg = self.cfg
         # attributes the reference's callers read (SURVEY.md §8(b) "Constructor")
@@ -163,7 +163,16 @@ class WXFormerHIP(_Base):
         return eng.forward(x.contiguous().float())
 
 
-def register(model_type: str = "crossformer_hip"):
-    """Register with the reference's registry (credit.models.register_model) when it is importable."""
+class WXFormerPSHIP(WXFormerHIP):
+    """`model.type: wxformer` / `wxformer_base` (credit/models/wxformer/crossformer.py): PixelShuffle decoder."""
+
+    def __init__(self, precision: str = "bf16", **model_conf):
+        model_conf.pop("arch", None)
+        super().__init__(precision=precision, arch="wxformer", **model_conf)
+
+
+def register(model_type: str = "crossformer_hip", wxformer_type: str = "wxformer_hip"):
+    """Register both engine classes with the reference's registry (credit.models.register_model)."""
     from credit.models import register_model  # type: ignore
+    register_model(wxformer_type, "Loading the MI355X-native WXFormer (PixelShuffle decoder) engine ...")(WXFormerPSHIP)
     return register_model(model_type, "Loading the MI355X-native CrossFormer engine ...")(WXFormerHIP)

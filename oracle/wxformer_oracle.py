@@ -41,8 +41,12 @@ def _as_t(a, dtype) -> Tensor:
     return torch.as_tensor(a).to(dtype)
 
 
-def is_transposed_conv(prefix: str) -> bool:
-    # credit/models/crossformer.py:92 (UpBlock.conv) and :572 (up_block4) are ConvTranspose2d
+def is_transposed_conv(prefix: str, sd: Optional[Dict] = None) -> bool:
+    # credit/models/crossformer.py:92 (UpBlock.conv) and :572 (up_block4) are ConvTranspose2d; the wxformer
+    # decoder (credit/models/wxformer/crossformer.py:137-162, 817-830) has only Conv2d (its state dict carries
+    # "up_block1.sharp.*", which the legacy decoder never has)
+    if sd is not None and any(k.startswith("up_block1.sharp.") for k in sd):
+        return False
     return prefix == "up_block4" or (prefix.startswith("up_block") and prefix.endswith(".conv"))
 
 
@@ -59,7 +63,7 @@ def folded_weight(sd: Dict, prefix: str, dtype=torch.float32) -> Tensor:
     w = _as_t(sd[prefix + ".weight_orig"], dtype)
     u = _as_t(sd[prefix + ".weight_u"], dtype)
     v = _as_t(sd[prefix + ".weight_v"], dtype)
-    w_mat = w.transpose(0, 1).reshape(w.shape[1], -1) if is_transposed_conv(prefix) else w.reshape(w.shape[0], -1)
+    w_mat = w.transpose(0, 1).reshape(w.shape[1], -1) if is_transposed_conv(prefix, sd) else w.reshape(w.shape[0], -1)
     sigma = torch.dot(u, torch.mv(w_mat, v))
     return w / sigma
 
@@ -109,14 +113,23 @@ def earth_unpad(x: Tensor, pad_lat, pad_lon) -> Tensor:
 # --------------------------------------------------------------------------- #
 # a2: cross embed
 # --------------------------------------------------------------------------- #
-def cross_embed(x: Tensor, sd: Dict, prefix: str, kernels: List[int], stride: int) -> Tensor:
+def cross_embed(x: Tensor, sd: Dict, prefix: str, kernels: List[int], stride: int, arch: str = "crossformer") -> Tensor:
     """credit/models/crossformer.py:128-152: one strided conv per (ascending) kernel size,
-    padding (k-s)//2, outputs concatenated on channels."""
+    padding (k-s)//2, outputs concatenated on channels.  arch "wxformer"
+    (credit/models/wxformer/crossformer.py:199-236): explicit zero padding left/top (k-s)//2,
+    right/bottom (k-s)-(k-s)//2, then an un-padded conv whose parameters sit at convs.<b>.1."""
     outs = []
     for b, k in enumerate(sorted(kernels)):
-        p = f"{prefix}.convs.{b}"
-        outs.append(F.conv2d(x, folded_weight(sd, p, x.dtype), _bias(sd, p, x.dtype), stride=stride,
-                             padding=(k - stride) // 2))
+        if arch == "wxformer":
+            p = f"{prefix}.convs.{b}.1"
+            lo = (k - stride) // 2
+            hi = (k - stride) - lo
+            xp = F.pad(x, (lo, hi, lo, hi))
+            outs.append(F.conv2d(xp, folded_weight(sd, p, x.dtype), _bias(sd, p, x.dtype), stride=stride))
+        else:
+            p = f"{prefix}.convs.{b}"
+            outs.append(F.conv2d(x, folded_weight(sd, p, x.dtype), _bias(sd, p, x.dtype), stride=stride,
+                                 padding=(k - stride) // 2))
     return torch.cat(outs, dim=1)
 
 
@@ -266,6 +279,28 @@ def up_block(x: Tensor, sd: Dict, prefix: str, groups: int) -> Tensor:
     return x + shortcut
 
 
+def pixel_shuffle2(x: Tensor) -> Tensor:
+    """nn.PixelShuffle(2): channel c*4 + 2*dy + dx -> pixel (2y+dy, 2x+dx) of channel c."""
+    b, c4, h, w = x.shape
+    c = c4 // 4
+    return x.reshape(b, c, 2, 2, h, w).permute(0, 1, 4, 2, 5, 3).reshape(b, c, 2 * h, 2 * w)
+
+
+def up_block_ps(x: Tensor, sd: Dict, prefix: str, groups: int) -> Tensor:
+    """UpBlockPS.forward (credit/models/wxformer/crossformer.py:156-162): sub-pixel conv + PixelShuffle,
+    x += sharp(x), then the same residual stack as the legacy block."""
+    x = pixel_shuffle2(F.conv2d(x, folded_weight(sd, prefix + ".conv", x.dtype), _bias(sd, prefix + ".conv", x.dtype),
+                                padding=1))
+    x = x + F.conv2d(x, folded_weight(sd, prefix + ".sharp", x.dtype), _bias(sd, prefix + ".sharp", x.dtype), padding=1)
+    shortcut = x
+    for j in (0, 3):
+        p = f"{prefix}.b.{j}"
+        x = F.conv2d(x, folded_weight(sd, p, x.dtype), _bias(sd, p, x.dtype), padding=1)
+        q = f"{prefix}.b.{j + 1}"
+        x = group_norm_silu(x, _as_t(sd[q + ".weight"], x.dtype), _as_t(sd[q + ".bias"], x.dtype), groups)
+    return x + shortcut
+
+
 # --------------------------------------------------------------------------- #
 # a10: head
 # --------------------------------------------------------------------------- #
@@ -311,7 +346,8 @@ def forward(cfg, sd: Dict, x, dtype=torch.float32, capture: Optional[Dict] = Non
         z = x[bi:bi + 1]
         enc = []
         for s in range(4):
-            z = cross_embed(z, sd, f"layers.{s}.0", list(cfg.cross_embed_kernel_sizes[s]), cfg.cross_embed_strides[s])
+            z = cross_embed(z, sd, f"layers.{s}.0", list(cfg.cross_embed_kernel_sizes[s]), cfg.cross_embed_strides[s],
+                            getattr(cfg, "arch", "crossformer"))
             if capture is not None and bi == 0:
                 capture[f"layers.{s}.0"] = z
             z = transformer(z, sd, f"layers.{s}.1", cfg.depth[s], cfg.local_window_size[s],
@@ -320,17 +356,23 @@ def forward(cfg, sd: Dict, x, dtype=torch.float32, capture: Optional[Dict] = Non
                 capture[f"layers.{s}.1"] = z
             enc.append(z)
         g = cfg.dim[0]
-        z = up_block(z, sd, "up_block1", g)
+        ub = up_block_ps if getattr(cfg, "arch", "crossformer") == "wxformer" else up_block
+        z = ub(z, sd, "up_block1", g)
         if capture is not None and bi == 0:
             capture["up_block1"] = z
-        z = up_block(torch.cat([z, enc[2]], dim=1), sd, "up_block2", g)
+        z = ub(torch.cat([z, enc[2]], dim=1), sd, "up_block2", g)
         if capture is not None and bi == 0:
             capture["up_block2"] = z
-        z = up_block(torch.cat([z, enc[1]], dim=1), sd, "up_block3", g)
+        z = ub(torch.cat([z, enc[1]], dim=1), sd, "up_block3", g)
         if capture is not None and bi == 0:
             capture["up_block3"] = z
-        z = F.conv_transpose2d(torch.cat([z, enc[0]], dim=1), folded_weight(sd, "up_block4", dtype),
-                               _bias(sd, "up_block4", dtype), stride=2, padding=1)
+        z = torch.cat([z, enc[0]], dim=1)
+        if getattr(cfg, "arch", "crossformer") == "wxformer":  # wxformer/crossformer.py:817-830
+            z = pixel_shuffle2(F.conv2d(z, folded_weight(sd, "up_block4.0", dtype), _bias(sd, "up_block4.0", dtype), padding=1))
+            z = F.conv2d(z, folded_weight(sd, "up_block4.2", dtype), _bias(sd, "up_block4.2", dtype), padding=1)
+        else:
+            z = F.conv_transpose2d(z, folded_weight(sd, "up_block4", dtype), _bias(sd, "up_block4", dtype), stride=2,
+                                   padding=1)
         if capture is not None and bi == 0:
             capture["up_block4"] = z
         if cfg.pad_activate:

@@ -47,7 +47,7 @@ def check(y, ref, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", ["T0", "T1"])
+@pytest.mark.parametrize("name", ["T0", "T1", "T0W"])
 def test_forward_and_every_block_vs_oracle(name, prec):
     cfg = named_config(name)
     sd = synth_state_dict(cfg)
@@ -72,13 +72,15 @@ def test_forward_and_every_block_vs_oracle(name, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_c1_vs_oracle_and_reference_golden(prec):
-    cfg = named_config("C1")
+@pytest.mark.parametrize("name", ["C1", "C1W"])
+def test_c1_vs_oracle_and_reference_golden(name, prec):
+    """1-degree configs of both reference classes (legacy ConvTranspose decoder, wxformer PixelShuffle decoder)."""
+    cfg = named_config(name)
     x = synth_input(cfg)
-    y = get_engine("C1", prec).forward(torch.from_numpy(x).cuda()).cpu()
+    y = get_engine(name, prec).forward(torch.from_numpy(x).cuda()).cpu()
     y_ref = O.forward(cfg, synth_state_dict(cfg), x)
     check(y.numpy(), y_ref.numpy(), prec)
-    g = np.load(os.path.join(GOLD, "model_C1.npz"))
+    g = np.load(os.path.join(GOLD, f"model_{name}.npz"))
     s = int(g["stride"])
     check(y[0, :, 0, ::s, ::s].numpy(), g["y"], prec)
 

@@ -32,7 +32,10 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def reference_model(cfg, post_conf=None):
-    from credit.models.crossformer import CrossFormer
+    if getattr(cfg, "arch", "crossformer") == "wxformer":
+        from credit.models.wxformer.crossformer import CrossFormer
+    else:
+        from credit.models.crossformer import CrossFormer
     m = CrossFormer(
         image_height=cfg.image_height, image_width=cfg.image_width, frames=cfg.frames, channels=cfg.channels,
         surface_channels=cfg.surface_channels, input_only_channels=cfg.input_only_channels,
@@ -162,7 +165,7 @@ def glue_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,C1,C3S,C3")
+    ap.add_argument("--only", default="pad,T0,T1,glue,C1,C3S,C3,T0W,C1W")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -171,8 +174,10 @@ def main():
             pad_golden()
         elif item == "glue":
             glue_golden()
-        elif item in ("T0", "T1"):
-            model_golden(item, 1, capture_layers=(item == "T0"))
+        elif item in ("T0", "T1", "T0W"):
+            model_golden(item, 1, capture_layers=(item in ("T0", "T0W")))
+        elif item == "C1W":
+            model_golden(item, 8, False)
         elif item == "C1":
             model_golden(item, 8, False)
         elif item in ("C3S", "C3"):
