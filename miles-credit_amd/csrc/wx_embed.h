@@ -44,12 +44,17 @@ struct EmbedPatchParams {
   int dbg;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256, 1) void embed_patch_kernel(const EmbedPatchParams p, const char* __restrict__ zero_page) {
+// NW waves share one patch: NW = 8 (512 threads, 2 waves per SIMD, 4 fragments each) lets one wave's LDS/L1
+// latency hide under its partner's MFMAs; NW = 4 (8 fragments each) halves the weight-fragment L1 traffic.
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatchParams p, const char* __restrict__ zero_page) {
   constexpr int KS = 32, TH = 16, TW = 32;
   constexpr int PH = 2 * TH + KS - 2, PW = 2 * TW + KS - 2;
   constexpr int NPIX = PH * PW;
-  constexpr int NPIX_PAD = ((NPIX + 255) / 256) * 256;
+  constexpr int NT = NW * 64;
+  constexpr int NF = 32 / NW;                    // pixel fragments per wave (rows 16/NW, two 16-column halves)
+  constexpr int RPW = 16 / NW;                   // output rows per wave
+  constexpr int NPIX_PAD = ((NPIX + NT - 1) / NT) * NT;
   constexpr int CC = 16 / (int)sizeof(T);        // channels per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NPIX_PAD][16 B]
 
@@ -67,16 +72,16 @@ __global__ __launch_bounds__(256, 1) void embed_patch_kernel(const EmbedPatchPar
   const bool f16 = wt16 != nullptr, f8 = wt8 != nullptr;
   const int64_t pix_bytes = (int64_t)p.cpad * (int64_t)sizeof(T);
 
-  // fragment f of this wave: output row 4*wave + f/2, cols (f&1)*16 + li
-  int fbase[8];
+  // fragment f of this wave: output row RPW*wave + f/2, cols (f&1)*16 + li
+  int fbase[NF];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    const int r = 4 * wave + (f >> 1), c = (f & 1) * 16 + li;
+  for (int f = 0; f < NF; ++f) {
+    const int r = RPW * wave + (f >> 1), c = (f & 1) * 16 + li;
     fbase[f] = ((2 * r) * PW + 2 * c + g) * 16;
   }
-  f32x4_t a32[8], a16[8], a8[2][8];
+  f32x4_t a32[NF], a16[NF], a8[2][NF];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) {
+  for (int f = 0; f < NF; ++f) {
     a32[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     a16[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     a8[0][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -86,13 +91,13 @@ __global__ __launch_bounds__(256, 1) void embed_patch_kernel(const EmbedPatchPar
   for (int ch = 0; ch < chunks; ++ch) {
     // ---- stage the patch for this channel chunk (LDS-DMA, one pixel per lane) --------------------
     if (!(p.dbg & 16) || ch == 0)
-      for (int it = 0; it < NPIX_PAD / 256; ++it) {
-        const int idx = it * 256 + wave * 64 + lane;
+      for (int it = 0; it < NPIX_PAD / NT; ++it) {
+        const int idx = it * NT + wave * 64 + lane;
         const int py = idx / PW, px = idx - py * PW;
         const int by = by0 + py, bx = bx0 + px;
         const bool ok = idx < NPIX && by >= 0 && by < p.Hb && bx >= 0 && bx < p.Wb;
         const char* src = ok ? xin + ((int64_t)by * p.Wb + bx) * pix_bytes + ch * 16 : zero_page;
-        lds_dma16(src, smem + (it * 256 + wave * 64) * 16);
+        lds_dma16(src, smem + (it * NT + wave * 64) * 16);
       }
     dma_wait_all();
     __syncthreads();
@@ -132,21 +137,21 @@ __global__ __launch_bounds__(256, 1) void embed_patch_kernel(const EmbedPatchPar
       const char* prow = smem + ky * PW * 16;
 #pragma unroll
       for (int k4 = 0; k4 < 8; ++k4) {
-        uint4 xf[8];
+        uint4 xf[NF];
 #pragma unroll
-        for (int f = 0; f < 8; ++f) xf[f] = *reinterpret_cast<const uint4*>(prow + fbase[f] + k4 * 64);
+        for (int f = 0; f < NF; ++f) xf[f] = *reinterpret_cast<const uint4*>(prow + fbase[f] + k4 * 64);
 #pragma unroll
-        for (int f = 0; f < 8; ++f) a32[f] = mma_sub<T>(r32[k4], xf[f], a32[f]);
+        for (int f = 0; f < NF; ++f) a32[f] = mma_sub<T>(r32[k4], xf[f], a32[f]);
         if (k4 >= 2 && k4 < 6) {
           if (in16) {
 #pragma unroll
-            for (int f = 0; f < 8; ++f) a16[f] = mma_sub<T>(r16[k4 - 2 < 0 ? 0 : (k4 - 2 > 3 ? 3 : k4 - 2)], xf[f], a16[f]);
+            for (int f = 0; f < NF; ++f) a16[f] = mma_sub<T>(r16[k4 - 2 < 0 ? 0 : (k4 - 2 > 3 ? 3 : k4 - 2)], xf[f], a16[f]);
           }
         }
         if (k4 >= 3 && k4 < 5) {
           if (in8) {
 #pragma unroll
-            for (int f = 0; f < 8; ++f) {
+            for (int f = 0; f < NF; ++f) {
               a8[0][f] = mma_sub<T>(r8[k4 == 3 ? 0 : 1][0], xf[f], a8[0][f]);
               a8[1][f] = mma_sub<T>(r8[k4 == 3 ? 0 : 1][1], xf[f], a8[1][f]);
             }
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(256, 1) void embed_patch_kernel(const EmbedPatchPar
   T* __restrict__ o16 = reinterpret_cast<T*>(p.out16);
   T* __restrict__ o8 = reinterpret_cast<T*>(p.out8);
 #pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    const int oy = oy0 + 4 * wave + (f >> 1), ox = ox0 + (f & 1) * 16 + li;
+  for (int f = 0; f < NF; ++f) {
+    const int oy = oy0 + RPW * wave + (f >> 1), ox = ox0 + (f & 1) * 16 + li;
     if (oy >= p.out_h || ox >= p.out_w) continue;
     const int64_t pix = ((int64_t)oy * p.out_w + ox) * p.out_ld;
     if (g * 4 < p.n32) {
@@ -194,19 +199,25 @@ __global__ __launch_bounds__(256, 1) void embed_patch_kernel(const EmbedPatchPar
   }
 }
 
-template <typename T>
-inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream) {
+template <typename T, int NW>
+inline void launch_embed_patch_nw(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream) {
   constexpr int PH = 2 * 16 + 30, PW = 2 * 32 + 30;
-  constexpr int LDS = (((PH * PW) + 255) / 256) * 256 * 16;
-  auto kern = embed_patch_kernel<T>;
+  constexpr int NT = NW * 64;
+  constexpr int LDS = (((PH * PW) + NT - 1) / NT) * NT * 16;
+  auto kern = embed_patch_kernel<T, NW>;
   static bool attr_done = false;
   if (!attr_done) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
   const int blocks = cdiv(p.out_h, 16) * cdiv(p.out_w, 32);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
   WX_HIP(hipGetLastError());
+}
+template <typename T>
+inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream) {
+  if (p.dbg & 256) launch_embed_patch_nw<T, 4>(p, zero_page, stream);  // A/B switch
+  else launch_embed_patch_nw<T, 8>(p, zero_page, stream);
 }
 
 }  // namespace wx
