@@ -163,9 +163,70 @@ def glue_golden():
     np.savez_compressed(os.path.join(GOLD, "rollout_T0.npz"), **out)
 
 
+def fixer_inputs(seed=11):
+    """Physically plausible random fields on the reference's 10x18 / 7-level demo grid.
+    x: [T(7) | q(7) | U(7) | V(7)] x 2 frames; y: the same 28 + [TOA solar, TOA OLR, surf solar, surf LR, SH, LH, precip, evapor]."""
+    g = np.random.Generator(np.random.Philox(key=[seed, 3]))
+    H, W, L = 10, 18, 7
+
+    def state():
+        T = 250.0 + 30.0 * g.standard_normal((L, H, W))
+        q = np.abs(0.004 + 0.004 * g.standard_normal((L, H, W)))
+        U = 12.0 * g.standard_normal((L, H, W))
+        V = 8.0 * g.standard_normal((L, H, W))
+        return np.concatenate([T, q, U, V], 0)
+    x = np.stack([state(), state()], 1).astype(np.float32)            # [28, 2, H, W]
+    flux = 2.0e6 * g.standard_normal((6, H, W))
+    precip = np.abs(2e-3 * g.standard_normal((1, H, W)))
+    evapor = -np.abs(1e-3 * g.standard_normal((1, H, W)))
+    y = np.concatenate([state() * 1.0, flux, precip, evapor], 0).astype(np.float32)  # [36, H, W]
+    return x, y
+
+
+def fixers_golden():
+    """GlobalMassFixer / GlobalWaterFixer / GlobalEnergyFixer of the reference on its own simple_demo grid
+    (credit/postblock/gen1.py:188-223), trapz and midpoint, denorm False."""
+    from credit.postblock.gen1 import GlobalEnergyFixer, GlobalMassFixer, GlobalWaterFixer
+    x_np, y_np = fixer_inputs()
+    out = {"x": x_np, "y": y_np}
+    L = 7
+    for midpoint in (False, True):
+        nl = L - 1 if midpoint else L      # midpoint variants take one level fewer (mid-level values)
+        tag = "mid" if midpoint else "trapz"
+        # channel layout for this variant: first nl levels of each 7-level block
+        xs = np.concatenate([x_np[b * L:b * L + nl] for b in range(4)], 0)
+        ys = np.concatenate([y_np[b * L:b * L + nl] for b in range(4)] + [y_np[28:]], 0)
+        x = torch.from_numpy(xs)[None]
+        y = torch.from_numpy(ys)[None, :, None]
+        q0 = nl
+        base = {"simple_demo": True, "denorm": False, "grid_type": "pressure", "midpoint": midpoint,
+                "activate": True, "activate_outside_model": False}
+        conf_m = {"global_mass_fixer": dict(base, fix_level_num=3, q_inds=list(range(q0, q0 + nl))),
+                  "data": {"lead_time_periods": 6}}
+        conf_w = {"global_water_fixer": dict(base, q_inds=list(range(q0, q0 + nl)), precip_ind=4 * nl + 6,
+                                             evapor_ind=4 * nl + 7), "data": {"lead_time_periods": 6}}
+        conf_e = {"global_energy_fixer": dict(base, T_inds=list(range(0, nl)), q_inds=list(range(q0, q0 + nl)),
+                                              U_inds=list(range(2 * nl, 3 * nl)), V_inds=list(range(3 * nl, 4 * nl)),
+                                              TOA_rad_inds=[4 * nl, 4 * nl + 1], surf_rad_inds=[4 * nl + 2, 4 * nl + 3],
+                                              surf_flux_inds=[4 * nl + 4, 4 * nl + 5]), "data": {"lead_time_periods": 6}}
+        with torch.no_grad():
+            ym = GlobalMassFixer(conf_m)({"y_pred": y.clone(), "x": x.clone()})["y_pred"]
+            yw = GlobalWaterFixer(conf_w)({"y_pred": y.clone(), "x": x.clone()})["y_pred"]
+            ye = GlobalEnergyFixer(conf_e)({"y_pred": y.clone(), "x": x.clone()})["y_pred"]
+            # chained, in PostBlock order (mass -> water -> energy)
+            yc = GlobalEnergyFixer(conf_e)(GlobalWaterFixer(conf_w)(GlobalMassFixer(conf_m)(
+                {"y_pred": y.clone(), "x": x.clone()})))["y_pred"]
+        for name, t in (("mass", ym), ("water", yw), ("energy", ye), ("chain", yc)):
+            assert t.shape == y.shape, (name, t.shape)
+            out[f"{tag}_{name}"] = t[0, :, 0].double().numpy()
+        print(f"[golden] fixers {tag}: mass dq max {float((ym - y).abs().max()):.3e}  water dP max "
+              f"{float((yw - y).abs().max()):.3e}  energy dT max {float((ye - y).abs().max()):.3e}")
+    np.savez_compressed(os.path.join(GOLD, "fixers_demo.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,C1,C3S,C3,T0W,C1W")
+    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,C1,C3S,C3,T0W,C1W")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -174,6 +235,8 @@ def main():
             pad_golden()
         elif item == "glue":
             glue_golden()
+        elif item == "fixers":
+            fixers_golden()
         elif item in ("T0", "T1", "T0W"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W")))
         elif item == "C1W":
