@@ -115,6 +115,35 @@ int wx_forward(wx_handle h, const float* x_dev, float* y_dev, int batch, void* s
 int wx_step(wx_handle h, const float* x_dev, const float* frc_dev, float* y_dev, float* y_phys_dev,
             float* x_next_dev, void* stream);
 
+/* ---- conservation fixers (PostBlock) -------------------------------------------
+ * A wx_post is the device-side counterpart of credit/postblock/gen1.py::PostBlock for pressure-level grids: an ordered
+ * list of TracerFixer (:111-167), GlobalMassFixer (:170-391), GlobalWaterFixer (:394-569) and GlobalEnergyFixer
+ * (:572-822) operating in place on y [C_out][H][W] (float32, one batch item, time collapsed) given the step's input
+ * x [C_in][frames][H][W] (last frame used).  It is independent of the model geometry, so it serves both uses the
+ * reference has: inside the model (wx_attach_postblock: runs after every forward, before y_phys / x_next are formed)
+ * and outside it (rollout_to_netcdf.py:277-284: call wx_post_apply yourself).
+ *   wx_post_set_grid  <-> physics_pressure_level(lon2d, lat2d, p_level, midpoint)   (credit/physics_core.py:75-134)
+ *   wx_post_set_stats <-> load_transforms(..., scaler_only=True) for `denorm: True` fixers (per-channel mean/std)
+ *   n_seconds = 3600 * data.lead_time_periods; rad_inds = {TOA solar, TOA OLR, surf solar, surf LR, surf SH, surf LH}
+ * Hybrid-sigma grids are not built (WX_ERR_INVALID). */
+typedef struct wx_post* wx_post_handle;
+int wx_post_create(int H, int W, int c_in, int frames, int c_out, int device, wx_post_handle* out);
+int wx_post_destroy(wx_post_handle p);
+int wx_post_set_grid(wx_post_handle p, const float* lat2d, const float* lon2d, const float* p_levels, int n_levels,
+                     int midpoint);
+int wx_post_set_stats(wx_post_handle p, const float* mean_in, const float* std_in, const float* mean_out,
+                      const float* std_out);
+int wx_post_add_tracer_fixer(wx_post_handle p, const int32_t* inds, const float* thres, const float* thres_max, int n,
+                             int denorm);
+int wx_post_add_mass_fixer(wx_post_handle p, int q_start, int fix_level_num, int denorm);
+int wx_post_add_water_fixer(wx_post_handle p, int q_start, int precip_ind, int evapor_ind, float n_seconds, int denorm);
+int wx_post_add_energy_fixer(wx_post_handle p, int T_start, int q_start, int U_start, int V_start,
+                             const int32_t rad_inds[6], const float* gph_surf, float n_seconds, int denorm);
+int wx_post_apply(wx_post_handle p, const float* x_dev, float* y_dev, void* stream);
+/* Run `p` inside wx_forward / wx_step (after the tail, before y_phys and x_next); NULL detaches.  The engine does not
+ * take ownership. */
+int wx_attach_postblock(wx_handle h, wx_post_handle p);
+
 /* ---- lat-band sharding; optional -------------------------
  * wx_set_comm <-> DomainParallelManager (credit/domain_parallel/manager.py:22).  `nccl_comm` is an
  * ncclComm_t (RCCL) passed as void*.  Not required for single-GPU or replica runs. */

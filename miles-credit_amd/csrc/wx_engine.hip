@@ -19,6 +19,7 @@
 #include "wx_elem.h"
 #include "wx_embed.h"
 #include "wx_gemm.h"
+#include "wx_post.h"
 
 namespace wx {
 
@@ -69,6 +70,7 @@ class EngineBase {
   virtual void profile(int on) = 0;
   virtual void profile_reset() = 0;
   virtual int profile_read(wx_kernel_stat* out, int cap) = 0;
+  virtual void attach_post(PostBlock* p) = 0;
   int device = 0;
 };
 
@@ -766,6 +768,29 @@ class Engine : public EngineBase {
     pending.push_back({nm, flops, bytes, idx});
   }
 
+  PostBlock* post = nullptr;    // not owned
+  float* y_internal = nullptr;  // scratch for the normalised output when the caller does not ask for it
+  void attach_post(PostBlock* p) override {
+    if (p && (p->h != Ho || p->w != Wo || p->cout != C_out || p->cin * p->fr != C_in || p->fr != cfg.frames))
+      throw ConfigError("wx_attach_postblock: post block geometry does not match the model");
+    post = p;
+  }
+  // forward tail + optional post block + (y_phys, x_next) of one batch item
+  void finish_item(const float* x_item, float* y, float* y_phys, float* x_next) {
+    if (!post) { tail(y, y_phys, x_next); return; }
+    if (!y) {
+      if (!y_internal) y_internal = (float*)dalloc((size_t)C_out * Ho * Wo * sizeof(float));
+      y = y_internal;
+    }
+    tail(y, nullptr, nullptr);
+    timed("post_block", 0.0, 0.0, [&] { post->apply(x_item, y, cur_stream); });
+    if (y_phys || x_next) {
+      const int64_t plane = (int64_t)Ho * Wo;
+      hipLaunchKernelGGL(finish_kernel, dim3(2048), dim3(256), 0, cur_stream, y, plane, C_out, have_denorm ? d_mean : nullptr,
+                         have_denorm ? d_std : nullptr, y_phys, x_next, n_prog < 0 ? 0 : n_prog);
+      WX_HIP(hipGetLastError());
+    }
+  }
   bool dbg_on = false;
   struct DbgT { int64_t c, h, w; std::vector<float> data; };
   std::map<std::string, DbgT> dbg;
@@ -1049,7 +1074,7 @@ class Engine : public EngineBase {
     const int64_t out_item = (int64_t)C_out * Ho * Wo;
     for (int b = 0; b < batch; ++b) {
       core(x + b * in_item);
-      tail(y + b * out_item, nullptr, nullptr);
+      finish_item(x + b * in_item, y + b * out_item, nullptr, nullptr);
     }
     if (prof_on) drain();
   }
@@ -1065,7 +1090,7 @@ class Engine : public EngineBase {
     if (y_phys && !have_denorm) throw StateError("wx_step with y_phys needs wx_set_denorm first");
     cur_stream = s;
     core(x);
-    tail(y, y_phys, x_next);
+    finish_item(x, y, y_phys, x_next);
     if (x_next) {
       const int64_t plane = (int64_t)cfg.image_height * cfg.image_width;
       if (n_static > 0)
@@ -1156,6 +1181,49 @@ int wx_profile_reset(wx_handle h) { return guarded([&] { WX_NEED(h); h->impl->pr
 int wx_profile_read(wx_handle h, wx_kernel_stat* out, int capacity, int* count) {
   return guarded([&] { WX_NEED(h); if (!out || !count) throw wx::ConfigError("wx_profile_read: null argument"); *count = h->impl->profile_read(out, capacity); });
 }
+// ---- post block ------------------------------------------------------------------------------------------------
+struct wx_post {
+  std::unique_ptr<wx::PostBlock> impl;
+};
+#define WX_NEEDP(p) if (!(p) || !(p)->impl) throw wx::ConfigError("null post-block handle")
+int wx_post_create(int H, int W, int c_in, int frames, int c_out, int device, wx_post_handle* out) {
+  return guarded([&] {
+    if (!out) throw wx::ConfigError("wx_post_create: null argument");
+    int ndev = 0;
+    WX_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) throw wx::ConfigError("wx_post_create: no such GPU device");
+    std::unique_ptr<wx_post> p(new wx_post);
+    p->impl.reset(new wx::PostBlock(H, W, c_in, frames, c_out, device));
+    *out = p.release();
+  });
+}
+int wx_post_destroy(wx_post_handle p) { return guarded([&] { delete p; }); }
+int wx_post_set_grid(wx_post_handle p, const float* lat2d, const float* lon2d, const float* p_levels, int n_levels, int midpoint) {
+  return guarded([&] { WX_NEEDP(p); if (!lat2d || !lon2d || !p_levels) throw wx::ConfigError("wx_post_set_grid: null argument"); p->impl->set_grid(lat2d, lon2d, p_levels, n_levels, midpoint); });
+}
+int wx_post_set_stats(wx_post_handle p, const float* mi, const float* si, const float* mo, const float* so) {
+  return guarded([&] { WX_NEEDP(p); if (!mi || !si || !mo || !so) throw wx::ConfigError("wx_post_set_stats: null argument"); p->impl->set_stats(mi, si, mo, so); });
+}
+int wx_post_add_tracer_fixer(wx_post_handle p, const int32_t* inds, const float* thres, const float* thres_max, int n, int denorm) {
+  return guarded([&] { WX_NEEDP(p); if (n < 1 || !inds || !thres) throw wx::ConfigError("wx_post_add_tracer_fixer: bad argument"); p->impl->add_tracer(inds, thres, thres_max, n, denorm); });
+}
+int wx_post_add_mass_fixer(wx_post_handle p, int q_start, int fix_level_num, int denorm) {
+  return guarded([&] { WX_NEEDP(p); p->impl->add_mass(q_start, fix_level_num, denorm); });
+}
+int wx_post_add_water_fixer(wx_post_handle p, int q_start, int precip_ind, int evapor_ind, float n_seconds, int denorm) {
+  return guarded([&] { WX_NEEDP(p); p->impl->add_water(q_start, precip_ind, evapor_ind, n_seconds, denorm); });
+}
+int wx_post_add_energy_fixer(wx_post_handle p, int T_start, int q_start, int U_start, int V_start, const int32_t rad_inds[6],
+                             const float* gph_surf, float n_seconds, int denorm) {
+  return guarded([&] { WX_NEEDP(p); if (!rad_inds || !gph_surf) throw wx::ConfigError("wx_post_add_energy_fixer: null argument"); p->impl->add_energy(T_start, q_start, U_start, V_start, rad_inds, gph_surf, n_seconds, denorm); });
+}
+int wx_post_apply(wx_post_handle p, const float* x_dev, float* y_dev, void* stream) {
+  return guarded([&] { WX_NEEDP(p); if (!x_dev || !y_dev) throw wx::ConfigError("wx_post_apply: null pointer"); p->impl->apply(x_dev, y_dev, (hipStream_t)stream); });
+}
+int wx_attach_postblock(wx_handle h, wx_post_handle p) {
+  return guarded([&] { WX_NEED(h); h->impl->attach_post(p ? p->impl.get() : nullptr); });
+}
+
 const char* wx_last_error(void) { return wx::g_last_error.c_str(); }
 const char* wx_version(void) { return "wxengine 0.1 (gfx950)"; }
 

@@ -1,0 +1,343 @@
+// Conservation fixers of the reference PostBlock (credit/postblock/gen1.py) on the device, pressure-level grids:
+//   TracerFixer :136-167, GlobalMassFixer :280-391, GlobalWaterFixer :489-569, GlobalEnergyFixer :704-822,
+// over credit/physics_core.py::physics_pressure_level (:75-297).  SURVEY.md §8(a) a12.
+//
+// Every global fixer is "column integrals -> a few area-weighted global sums -> one scalar ratio -> elementwise
+// correction".  HBM-bound integer-free float work: one thread per grid cell walks its column (loads are coalesced
+// along longitude for every level), per-cell integrals in fp32 like the reference, the global sums in fp64 with a
+// fixed two-stage order (per-workgroup partials, then one workgroup) so results are bit-reproducible, then an
+// elementwise apply kernel.  Tensors are the caller's fp32 NCHW buffers (y [C_out][H][W], x [C_in][frames][H][W]).
+#pragma once
+#include <vector>
+
+#include "wx_common.h"
+
+namespace wx {
+
+constexpr float kGravity = 9.80665f, kRhoWater = 1000.0f, kLhWater = 2.501e6f, kCpDry = 1004.64f, kCpVapor = 1810.0f;
+constexpr double kRadEarth = 6371000.0;
+constexpr int kMaxLevels = 64;
+
+struct FixParams {
+  const float* x;        // input  [c_in][frames][HW]; the LAST frame is used
+  float* y;              // output [c_out][HW], fixed in place
+  int hw, c_in, frames, c_out;
+  const float* area;     // [HW]
+  const float* p;        // [n_p] pressure levels (Pa)
+  int n_p, midpoint;
+  const float *mean_in, *std_in, *mean_out, *std_out;  // nullptr unless denorm
+  // op
+  int kind;              // 1 mass, 2 water, 3 energy
+  int q0, nlev;          // q block start / levels carried per 3-D variable
+  int ind_fix, ind_fix_start;
+  int precip, evapor;
+  int T0, U0, V0, toa0, toa1, sr0, sr1, sf0, sf1;
+  const float* gph;      // [HW]
+  float n_seconds;
+  double* partial;       // [blocks][4]
+  double* sums;          // [4]
+  float* ratio;          // [1]
+  int n_blocks;
+};
+
+__device__ inline float fx_in(const FixParams& p, int ch, int cell) {
+  const float v = p.x[((int64_t)ch * p.frames + (p.frames - 1)) * p.hw + cell];
+  return p.mean_in ? v * p.std_in[ch] + p.mean_in[ch] : v;
+}
+__device__ inline float fx_out(const FixParams& p, int ch, int cell) {
+  const float v = p.y[(int64_t)ch * p.hw + cell];
+  return p.mean_out ? v * p.std_out[ch] + p.mean_out[ch] : v;
+}
+// pressure integral of f(l) over levels [a, b): trapz over p[a..b-1], or midpoint with thickness diff(p)
+template <typename F>
+__device__ inline float col_integral(const FixParams& p, int a, int b, F f) {
+  float acc = 0.f;
+  if (p.midpoint) {
+    for (int l = a; l < b; ++l) acc += f(l) * (p.p[l + 1] - p.p[l]);
+  } else {
+    float prev = f(a);
+    for (int l = a; l + 1 < b; ++l) {
+      const float cur = f(l + 1);
+      acc += 0.5f * (prev + cur) * (p.p[l + 1] - p.p[l]);
+      prev = cur;
+    }
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void fix_reduce_kernel(const FixParams p) {
+  __shared__ double sh[4][256];
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (cell < p.hw) {
+    const double a = (double)p.area[cell];
+    const int nl = p.nlev;
+    if (p.kind == 1) {
+      const float i0 = col_integral(p, 0, nl, [&](int l) { return 1.f - fx_in(p, p.q0 + l, cell); }) / kGravity;
+      const float ih = col_integral(p, 0, p.ind_fix, [&](int l) { return 1.f - fx_out(p, p.q0 + l, cell); }) / kGravity;
+      const float ifx = col_integral(p, p.ind_fix_start, nl, [&](int l) { return 1.f - fx_out(p, p.q0 + l, cell); }) / kGravity;
+      s[0] = i0 * a; s[1] = ih * a; s[2] = ifx * a;
+    } else if (p.kind == 2) {
+      const float t_in = col_integral(p, 0, nl, [&](int l) { return fx_in(p, p.q0 + l, cell); }) / kGravity;
+      const float t_pr = col_integral(p, 0, nl, [&](int l) { return fx_out(p, p.q0 + l, cell); }) / kGravity;
+      s[0] = (double)((t_pr - t_in) / p.n_seconds) * a;
+      s[1] = (double)(fx_out(p, p.evapor, cell) * kRhoWater / p.n_seconds) * a;
+      s[2] = (double)(fx_out(p, p.precip, cell) * kRhoWater / p.n_seconds) * a;
+    } else {
+      const float gph = p.gph[cell];
+      const float rt = (fx_out(p, p.toa0, cell) + fx_out(p, p.toa1, cell)) / p.n_seconds;
+      const float fs = (fx_out(p, p.sr0, cell) + fx_out(p, p.sr1, cell) + fx_out(p, p.sf0, cell) + fx_out(p, p.sf1, cell)) / p.n_seconds;
+      const float te0 = col_integral(p, 0, nl, [&](int l) {
+        const float q = fx_in(p, p.q0 + l, cell), u = fx_in(p, p.U0 + l, cell), v = fx_in(p, p.V0 + l, cell);
+        const float cp = (1.f - q) * kCpDry + q * kCpVapor;
+        return cp * fx_in(p, p.T0 + l, cell) + (kLhWater * q + gph + 0.5f * (u * u + v * v));
+      }) / kGravity;
+      const float te1 = col_integral(p, 0, nl, [&](int l) {
+        const float q = fx_out(p, p.q0 + l, cell), u = fx_out(p, p.U0 + l, cell), v = fx_out(p, p.V0 + l, cell);
+        const float cp = (1.f - q) * kCpDry + q * kCpVapor;
+        return cp * fx_out(p, p.T0 + l, cell) + (kLhWater * q + gph + 0.5f * (u * u + v * v));
+      }) / kGravity;
+      s[0] = (double)rt * a; s[1] = (double)fs * a; s[2] = (double)te0 * a; s[3] = (double)te1 * a;
+    }
+  }
+  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o)
+      for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) p.partial[(int64_t)blockIdx.x * 4 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void fix_finalize_kernel(const FixParams p) {
+  __shared__ double sh[4][256];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < p.n_blocks; b += 256)
+    for (int k = 0; k < 4; ++k) s[k] += p.partial[(int64_t)b * 4 + k];
+  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o)
+      for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double a = sh[0][0], b = sh[1][0], c = sh[2][0], d = sh[3][0];
+    for (int k = 0; k < 4; ++k) p.sums[k] = sh[k][0];
+    double r;
+    if (p.kind == 1) r = (a - b) / c;                                   // (M_dry(t0) - M_hold(t1)) / M_fix(t1)
+    else if (p.kind == 2) r = (c + (-a - b - c)) / c;                    // (P + residual) / P
+    else r = ((double)p.n_seconds * (a - b) + c) / d;                   // (dt (R_T - F_S) + TE(t0)) / TE(t1)
+    p.ratio[0] = (float)r;
+  }
+}
+
+__global__ __launch_bounds__(256) void fix_apply_kernel(const FixParams p) {
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= p.hw) return;
+  const float r = p.ratio[0];
+  auto put = [&](int ch, float v) {
+    if (p.mean_out) v = (v - p.mean_out[ch]) / p.std_out[ch];
+    p.y[(int64_t)ch * p.hw + cell] = v;
+  };
+  if (p.kind == 1) {
+    for (int l = p.ind_fix_start; l < p.nlev; ++l) put(p.q0 + l, 1.f - (1.f - fx_out(p, p.q0 + l, cell)) * r);
+  } else if (p.kind == 2) {
+    put(p.precip, fx_out(p, p.precip, cell) * r);
+  } else {
+    const float gph = p.gph[cell];
+    for (int l = 0; l < p.nlev; ++l) {
+      const float q = fx_out(p, p.q0 + l, cell), u = fx_out(p, p.U0 + l, cell), v = fx_out(p, p.V0 + l, cell);
+      const float cp = (1.f - q) * kCpDry + q * kCpVapor;
+      const float eq = kLhWater * q + gph + 0.5f * (u * u + v * v);
+      const float e1 = cp * fx_out(p, p.T0 + l, cell) + eq;
+      put(p.T0 + l, (e1 * r - eq) / cp);
+    }
+  }
+}
+
+// TracerFixer on the fp32 NCHW tensor (the engine's tail kernel has its own fused copy)
+__global__ __launch_bounds__(256) void fix_tracer_kernel(float* y, int hw, int n, const int* inds, const float* lo, const float* hi,
+                                                         const float* mean, const float* stdv) {
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= hw) return;
+  for (int k = 0; k < n; ++k) {
+    const int ch = inds[k];
+    float v = y[(int64_t)ch * hw + cell];
+    if (mean) v = v * stdv[ch] + mean[ch];
+    v = v < lo[k] ? lo[k] : v;
+    v = v >= hi[k] ? hi[k] : v;
+    if (mean) v = (v - mean[ch]) / stdv[ch];
+    y[(int64_t)ch * hw + cell] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+struct PostOp {
+  int kind = 0;  // 0 tracer, 1 mass, 2 water, 3 energy
+  int denorm = 0;
+  int q0 = 0, nlev = 0, fix_level_num = 0, precip = 0, evapor = 0, T0 = 0, U0 = 0, V0 = 0;
+  int toa0 = 0, toa1 = 0, sr0 = 0, sr1 = 0, sf0 = 0, sf1 = 0;
+  float n_seconds = 0.f;
+  float* gph = nullptr;
+  int n_tr = 0;
+  int* tr_inds = nullptr;
+  float *tr_lo = nullptr, *tr_hi = nullptr;
+};
+
+class PostBlock {
+ public:
+  PostBlock(int H, int W, int c_in, int frames, int c_out, int dev)
+      : h(H), w(W), cin(c_in), fr(frames), cout(c_out), device(dev) {
+    if (H < 3 || W < 3 || c_in < 1 || c_out < 1 || frames < 1) throw std::runtime_error("wx_post_create: bad geometry");
+    WX_HIP(hipSetDevice(device));
+    n_blocks = cdiv((int64_t)H * W, 256);
+    partial = (double*)alloc((size_t)n_blocks * 4 * sizeof(double));
+    sums = (double*)alloc(4 * sizeof(double));
+    ratio = (float*)alloc(sizeof(float));
+  }
+  ~PostBlock() {
+    (void)hipSetDevice(device);
+    for (void* p : allocs) (void)hipFree(p);
+  }
+  int h, w, cin, fr, cout, device, n_blocks = 0;
+  std::vector<void*> allocs;
+  float *area = nullptr, *plev = nullptr;
+  int n_p = 0, midpoint = 0;
+  float *mean_in = nullptr, *std_in = nullptr, *mean_out = nullptr, *std_out = nullptr;
+  double *partial = nullptr, *sums = nullptr;
+  float* ratio = nullptr;
+  std::vector<PostOp> ops;
+  std::vector<double> last_sums;
+
+  void* alloc(size_t bytes) {
+    void* p = nullptr;
+    WX_HIP(hipMalloc(&p, bytes));
+    allocs.push_back(p);
+    return p;
+  }
+  float* upload(const float* src, size_t n) {
+    float* d = (float*)alloc(n * sizeof(float));
+    WX_HIP(hipMemcpy(d, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+  }
+  // |R^2 d(sin lat) d(lon)|, second-order one-sided differences at the edges, lon difference wrapped into (-pi, pi]
+  // (credit/physics_core.py:113-125: torch.gradient(edge_order=2)); fp32 like the reference
+  void set_grid(const float* lat2d, const float* lon2d, const float* p_levels, int n_levels, int mid) {
+    if (n_levels < 2 || n_levels > kMaxLevels) throw std::runtime_error("wx_post_set_grid: 2..64 pressure levels");
+    WX_HIP(hipSetDevice(device));
+    std::vector<float> a((size_t)h * w);
+    const float d2r = 3.14159265358979323846f / 180.f;
+    auto sl = [&](int i, int j) { return std::sin(lat2d[(size_t)i * w + j] * d2r); };
+    auto lo = [&](int i, int j) { return lon2d[(size_t)i * w + j] * d2r; };
+    for (int i = 0; i < h; ++i)
+      for (int j = 0; j < w; ++j) {
+        float dphi, dlam;
+        if (i == 0) dphi = (-3.f * sl(0, j) + 4.f * sl(1, j) - sl(2, j)) / 2.f;
+        else if (i == h - 1) dphi = (3.f * sl(h - 1, j) - 4.f * sl(h - 2, j) + sl(h - 3, j)) / 2.f;
+        else dphi = (sl(i + 1, j) - sl(i - 1, j)) / 2.f;
+        if (j == 0) dlam = (-3.f * lo(i, 0) + 4.f * lo(i, 1) - lo(i, 2)) / 2.f;
+        else if (j == w - 1) dlam = (3.f * lo(i, w - 1) - 4.f * lo(i, w - 2) + lo(i, w - 3)) / 2.f;
+        else dlam = (lo(i, j + 1) - lo(i, j - 1)) / 2.f;
+        const float pi = 3.14159265358979323846f;
+        float t = std::fmod(dlam + pi, 2.f * pi);       // python %: result takes the sign of the divisor
+        if (t < 0.f) t += 2.f * pi;
+        dlam = t - pi;
+        a[(size_t)i * w + j] = std::fabs((float)(kRadEarth * kRadEarth) * dphi * dlam);
+      }
+    area = upload(a.data(), a.size());
+    plev = upload(p_levels, n_levels);
+    n_p = n_levels;
+    midpoint = mid;
+  }
+  void set_stats(const float* mi, const float* si, const float* mo, const float* so) {
+    WX_HIP(hipSetDevice(device));
+    mean_in = upload(mi, cin); std_in = upload(si, cin);
+    mean_out = upload(mo, cout); std_out = upload(so, cout);
+  }
+  void need_grid() const { if (!area) throw std::runtime_error("wx_post: call wx_post_set_grid first"); }
+  void need_stats(int denorm) const { if (denorm && !mean_out) throw std::runtime_error("wx_post: denorm needs wx_post_set_stats first"); }
+  void check_block(int start, int n, int limit, const char* what) const {
+    if (start < 0 || n < 1 || start + n > limit) throw std::runtime_error(std::string("wx_post: channel block out of range: ") + what);
+  }
+  int levels_carried() const { return midpoint ? n_p - 1 : n_p; }
+
+  void add_tracer(const int32_t* inds, const float* thres, const float* thres_max, int n, int denorm) {
+    need_stats(denorm);
+    WX_HIP(hipSetDevice(device));
+    PostOp op;
+    op.kind = 0; op.denorm = denorm; op.n_tr = n;
+    std::vector<float> hi(n, 3.4e38f);
+    for (int i = 0; i < n; ++i) {
+      if (inds[i] < 0 || inds[i] >= cout) throw std::runtime_error("wx_post: tracer index out of range");
+      if (thres_max) hi[i] = thres_max[i];
+    }
+    op.tr_inds = (int*)alloc(n * sizeof(int));
+    WX_HIP(hipMemcpy(op.tr_inds, inds, n * sizeof(int), hipMemcpyHostToDevice));
+    op.tr_lo = upload(thres, n);
+    op.tr_hi = upload(hi.data(), n);
+    ops.push_back(op);
+  }
+  void add_mass(int q0, int fix_level_num, int denorm) {
+    need_grid(); need_stats(denorm);
+    PostOp op;
+    op.kind = 1; op.denorm = denorm; op.q0 = q0; op.nlev = levels_carried(); op.fix_level_num = fix_level_num;
+    check_block(q0, op.nlev, cout, "q (output)"); check_block(q0, op.nlev, cin, "q (input)");
+    if (fix_level_num < 1 || fix_level_num > n_p) throw std::runtime_error("wx_post: fix_level_num out of range");
+    ops.push_back(op);
+  }
+  void add_water(int q0, int precip, int evapor, float n_seconds, int denorm) {
+    need_grid(); need_stats(denorm);
+    PostOp op;
+    op.kind = 2; op.denorm = denorm; op.q0 = q0; op.nlev = levels_carried(); op.precip = precip; op.evapor = evapor;
+    op.n_seconds = n_seconds;
+    check_block(q0, op.nlev, cout, "q (output)"); check_block(q0, op.nlev, cin, "q (input)");
+    check_block(precip, 1, cout, "precip"); check_block(evapor, 1, cout, "evapor");
+    ops.push_back(op);
+  }
+  void add_energy(int T0, int q0, int U0, int V0, const int32_t rad[6], const float* gph_surf, float n_seconds, int denorm) {
+    need_grid(); need_stats(denorm);
+    WX_HIP(hipSetDevice(device));
+    PostOp op;
+    op.kind = 3; op.denorm = denorm; op.T0 = T0; op.q0 = q0; op.U0 = U0; op.V0 = V0; op.nlev = levels_carried();
+    op.toa0 = rad[0]; op.toa1 = rad[1]; op.sr0 = rad[2]; op.sr1 = rad[3]; op.sf0 = rad[4]; op.sf1 = rad[5];
+    op.n_seconds = n_seconds;
+    for (int s : {T0, q0, U0, V0}) { check_block(s, op.nlev, cout, "3-D block (output)"); check_block(s, op.nlev, cin, "3-D block (input)"); }
+    for (int k = 0; k < 6; ++k) check_block(rad[k], 1, cout, "flux channel");
+    op.gph = upload(gph_surf, (size_t)h * w);
+    ops.push_back(op);
+  }
+
+  void apply(const float* x, float* y, hipStream_t stream) {
+    WX_HIP(hipSetDevice(device));
+    const int hw = h * w;
+    for (const PostOp& op : ops) {
+      if (op.kind == 0) {
+        hipLaunchKernelGGL(fix_tracer_kernel, dim3(n_blocks), dim3(256), 0, stream, y, hw, op.n_tr, op.tr_inds, op.tr_lo, op.tr_hi,
+                           op.denorm ? mean_out : nullptr, op.denorm ? std_out : nullptr);
+        WX_HIP(hipGetLastError());
+        continue;
+      }
+      FixParams p;
+      std::memset(&p, 0, sizeof(p));
+      p.x = x; p.y = y; p.hw = hw; p.c_in = cin; p.frames = fr; p.c_out = cout;
+      p.area = area; p.p = plev; p.n_p = n_p; p.midpoint = midpoint;
+      if (op.denorm) { p.mean_in = mean_in; p.std_in = std_in; p.mean_out = mean_out; p.std_out = std_out; }
+      p.kind = op.kind; p.q0 = op.q0; p.nlev = op.nlev;
+      p.ind_fix = n_p - op.fix_level_num + 1;                 // gen1.py:224 / :264
+      p.ind_fix_start = midpoint ? p.ind_fix : p.ind_fix - 1;  // gen1.py:267-270
+      p.precip = op.precip; p.evapor = op.evapor;
+      p.T0 = op.T0; p.U0 = op.U0; p.V0 = op.V0;
+      p.toa0 = op.toa0; p.toa1 = op.toa1; p.sr0 = op.sr0; p.sr1 = op.sr1; p.sf0 = op.sf0; p.sf1 = op.sf1;
+      p.gph = op.gph; p.n_seconds = op.n_seconds;
+      p.partial = partial; p.sums = sums; p.ratio = ratio; p.n_blocks = n_blocks;
+      hipLaunchKernelGGL(fix_reduce_kernel, dim3(n_blocks), dim3(256), 0, stream, p);
+      hipLaunchKernelGGL(fix_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
+      hipLaunchKernelGGL(fix_apply_kernel, dim3(n_blocks), dim3(256), 0, stream, p);
+      WX_HIP(hipGetLastError());
+    }
+  }
+};
+
+}  // namespace wx

@@ -67,6 +67,16 @@ _PROTOTYPES = {
     "wx_profile": ([C.c_void_p, C.c_int], C.c_int),
     "wx_profile_reset": ([C.c_void_p], C.c_int),
     "wx_profile_read": ([C.c_void_p, C.POINTER(wx_kernel_stat), C.c_int, C.POINTER(C.c_int)], C.c_int),
+    "wx_post_create": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    "wx_post_destroy": ([C.c_void_p], C.c_int),
+    "wx_post_set_grid": ([C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int], C.c_int),
+    "wx_post_set_stats": ([C.c_void_p] + [C.POINTER(C.c_float)] * 4, C.c_int),
+    "wx_post_add_tracer_fixer": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int], C.c_int),
+    "wx_post_add_mass_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_int),
+    "wx_post_add_water_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int], C.c_int),
+    "wx_post_add_energy_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_int], C.c_int),
+    "wx_post_apply": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "wx_attach_postblock": ([C.c_void_p, C.c_void_p], C.c_int),
     "wx_last_error": ([], C.c_char_p),
     "wx_version": ([], C.c_char_p),
 }
@@ -254,6 +264,11 @@ class WXEngine:
         """0 off, 1 per kernel class, 2 per kernel class and stage ("gemm_ff1.s2")."""
         _check(self.lib.wx_profile(self._h, int(on)))
 
+    def attach_postblock(self, post) -> None:
+        """Run `post` (a WXPostBlock, or None to detach) after every forward, before y_phys / x_next are formed."""
+        self._post = post  # keep it alive
+        _check(self.lib.wx_attach_postblock(self._h, post._p if post is not None else None))
+
     def profile_reset(self) -> None:
         _check(self.lib.wx_profile_reset(self._h))
 
@@ -263,3 +278,73 @@ class WXEngine:
         _check(self.lib.wx_profile_read(self._h, arr, 256, C.byref(n)))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops,
                      bytes=arr[i].bytes) for i in range(n.value)]
+
+
+def _fp(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class WXPostBlock:
+    """Device-side PostBlock (credit/postblock/gen1.py) for pressure-level grids: ordered fixers applied in place."""
+
+    def __init__(self, H: int, W: int, c_in: int, frames: int, c_out: int, device: int = 0):
+        import torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise WXEngineError("no GPU visible: the post block has no CPU fallback")
+        self.shape = (H, W, c_in, frames, c_out)
+        self._p = C.c_void_p()
+        _check(self.lib.wx_post_create(H, W, c_in, frames, c_out, device, C.byref(self._p)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_p", None) and self._p.value:
+                self.lib.wx_post_destroy(self._p)
+                self._p = C.c_void_p()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _ptr(a):
+        return a.ctypes.data_as(C.POINTER(C.c_float))
+
+    def set_grid(self, lat2d, lon2d, p_levels, midpoint: bool = False):
+        la, lo, pl = _fp(lat2d), _fp(lon2d), _fp(p_levels)
+        _check(self.lib.wx_post_set_grid(self._p, self._ptr(la), self._ptr(lo), self._ptr(pl), pl.size, int(midpoint)))
+
+    def set_stats(self, mean_in, std_in, mean_out, std_out):
+        a = [_fp(v).ravel() for v in (mean_in, std_in, mean_out, std_out)]
+        _check(self.lib.wx_post_set_stats(self._p, *[self._ptr(v) for v in a]))
+
+    def add_tracer_fixer(self, inds, thres, thres_max=None, denorm=False):
+        i = np.ascontiguousarray(inds, dtype=np.int32)
+        t = _fp(thres)
+        tm = None if thres_max is None else _fp(thres_max)
+        _check(self.lib.wx_post_add_tracer_fixer(self._p, i.ctypes.data_as(C.POINTER(C.c_int32)), self._ptr(t),
+                                                 None if tm is None else self._ptr(tm), i.size, int(denorm)))
+
+    def add_mass_fixer(self, q_start, fix_level_num, denorm=False):
+        _check(self.lib.wx_post_add_mass_fixer(self._p, q_start, fix_level_num, int(denorm)))
+
+    def add_water_fixer(self, q_start, precip_ind, evapor_ind, n_seconds, denorm=False):
+        _check(self.lib.wx_post_add_water_fixer(self._p, q_start, precip_ind, evapor_ind, float(n_seconds), int(denorm)))
+
+    def add_energy_fixer(self, T_start, q_start, U_start, V_start, rad_inds, gph_surf, n_seconds, denorm=False):
+        r = np.ascontiguousarray(rad_inds, dtype=np.int32)
+        assert r.size == 6
+        g = _fp(gph_surf)
+        _check(self.lib.wx_post_add_energy_fixer(self._p, T_start, q_start, U_start, V_start,
+                                                 r.ctypes.data_as(C.POINTER(C.c_int32)), self._ptr(g), float(n_seconds), int(denorm)))
+
+    def apply(self, x, y):
+        """x [C_in, frames, H, W], y [C_out, H, W] float32 CUDA tensors (leading batch dim of 1 allowed); y is fixed in place."""
+        import torch
+        for t, n in ((x, "x"), (y, "y")):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise WXEngineError(f"{n} must be a contiguous float32 tensor on the GPU")
+        H, W, c_in, fr, c_out = self.shape
+        if x.numel() != c_in * fr * H * W or y.numel() != c_out * H * W:
+            raise WXEngineError("post block: tensor sizes do not match the geometry")
+        _check(self.lib.wx_post_apply(self._p, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return y
