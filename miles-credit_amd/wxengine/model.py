@@ -63,16 +63,16 @@ class WXFormerHIP(_Base):
         self._denorm = None
         self._tracer = self._tracer_from_post_conf(cfg.post_conf)
 
-    # ---- post block (in-model tracer fixer only; other fixers are rejected loudly) ----------------
+    # ---- post block ---------------------------------------------------------------------------------------
     @staticmethod
     def _tracer_from_post_conf(post_conf: Dict):
+        """In-model TracerFixer (fused into the engine's tail kernel).  SKEBS and hybrid-sigma grids are rejected."""
         if not post_conf or not post_conf.get("activate", False):
             return None
-        for name in ("skebs", "global_mass_fixer", "global_water_fixer", "global_energy_fixer",
-                     "global_energy_fixer_updown"):
-            sub = post_conf.get(name) or {}
-            if sub.get("activate", False) and not sub.get("activate_outside_model", False):
-                raise ValueError(f"post_conf.{name} inside the model is not implemented by the HIP engine")
+        if (post_conf.get("skebs") or {}).get("activate", False):
+            raise ValueError("post_conf.skebs is not implemented by the HIP engine")
+        if (post_conf.get("global_energy_fixer_updown") or {}).get("activate", False):
+            raise ValueError("post_conf.global_energy_fixer_updown is not implemented by the HIP engine")
         tf = post_conf.get("tracer_fixer") or {}
         if not tf.get("activate", False):
             return None
@@ -80,6 +80,64 @@ class WXFormerHIP(_Base):
             raise ValueError("post_conf.tracer_fixer.tracer_inds missing (the reference's parser injects it)")
         return dict(inds=list(tf["tracer_inds"]), thres=list(tf["tracer_thres"]),
                     thres_max=tf.get("tracer_thres_max"), denorm=bool(tf.get("denorm", False)))
+
+    def _global_fixers(self):
+        """[(name, conf)] of in-model global fixers, in PostBlock order (credit/postblock/gen1.py:56-99)."""
+        pc = self.cfg.post_conf or {}
+        out = []
+        if not pc.get("activate", False):
+            return out
+        for name in ("global_mass_fixer", "global_water_fixer", "global_energy_fixer"):
+            sub = pc.get(name) or {}
+            if sub.get("activate", False) and not sub.get("activate_outside_model", False):
+                if sub.get("grid_type", "pressure") != "pressure":
+                    raise ValueError(f"post_conf.{name}: only pressure-level grids are implemented by the HIP engine")
+                out.append((name, sub))
+        return out
+
+    def set_physics(self, lat2d, lon2d, p_levels, gph_surf=None, mean_in=None, std_in=None):
+        """What the reference reads from `post_conf.data.save_loc_physics` (lat/lon/levels, surface geopotential)
+        and, for `denorm: True` fixers, the INPUT-channel statistics (the output ones come from set_denorm)."""
+        self._physics = dict(lat2d=np.asarray(lat2d, np.float32), lon2d=np.asarray(lon2d, np.float32),
+                             p=np.asarray(p_levels, np.float32),
+                             gph=None if gph_surf is None else np.asarray(gph_surf, np.float32),
+                             mean_in=mean_in, std_in=std_in)
+        self._dirty = True
+
+    def _build_post(self, device_index: int):
+        from .engine import WXPostBlock
+        fixers = self._global_fixers()
+        if not fixers:
+            return None
+        ph = getattr(self, "_physics", None)
+        if ph is None:
+            raise WXEngineError("global fixers are active: call set_physics(lat2d, lon2d, p_levels, gph_surf) first")
+        cfg = self.cfg
+        pb = WXPostBlock(cfg.out_hw[0], cfg.out_hw[1], cfg.base_input_channels, cfg.frames, cfg.base_output_channels,
+                         device_index)
+        midpoint = bool(fixers[0][1].get("midpoint", False))
+        pb.set_grid(ph["lat2d"], ph["lon2d"], ph["p"], midpoint)
+        if any(c.get("denorm", False) for _, c in fixers):
+            if self._denorm is None or ph["mean_in"] is None:
+                raise WXEngineError("denorm fixers need set_denorm(mean, std) and set_physics(..., mean_in=, std_in=)")
+            pb.set_stats(ph["mean_in"], ph["std_in"], self._denorm[0], self._denorm[1])
+        n_seconds = 3600.0 * float(((cfg.post_conf.get("data") or {}).get("lead_time_periods", 6)))
+        for name, c in fixers:
+            dn = bool(c.get("denorm", False))
+            if bool(c.get("midpoint", False)) != midpoint:
+                raise ValueError("all global fixers must agree on `midpoint`")
+            if name == "global_mass_fixer":
+                pb.add_mass_fixer(int(c["q_inds"][0]), int(c["fix_level_num"]), dn)
+            elif name == "global_water_fixer":
+                pb.add_water_fixer(int(c["q_inds"][0]), int(c["precip_ind"]), int(c["evapor_ind"]), n_seconds, dn)
+            else:
+                if ph["gph"] is None:
+                    raise WXEngineError("global_energy_fixer needs the surface geopotential: set_physics(..., gph_surf=)")
+                rad = [int(c["TOA_rad_inds"][0]), int(c["TOA_rad_inds"][1]), int(c["surf_rad_inds"][0]),
+                       int(c["surf_rad_inds"][1]), int(c["surf_flux_inds"][0]), int(c["surf_flux_inds"][1])]
+                pb.add_energy_fixer(int(c["T_inds"][0]), int(c["q_inds"][0]), int(c["U_inds"][0]), int(c["V_inds"][0]),
+                                    rad, ph["gph"], n_seconds, dn)
+        return pb
 
     def set_denorm(self, mean, std):
         """Per-output-channel statistics (what the reference reads from its scaler files)."""
@@ -147,6 +205,7 @@ class WXFormerHIP(_Base):
                     raise WXEngineError("tracer_fixer.denorm is True: call set_denorm(mean, std) first")
                 self._engine.set_tracer_fixer(self._tracer["inds"], self._tracer["thres"], self._tracer["thres_max"],
                                               self._tracer["denorm"])
+            self._engine.attach_postblock(self._build_post(device.index or 0))
             self._dirty = False
         return self._engine
 
