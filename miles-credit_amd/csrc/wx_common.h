@@ -11,6 +11,8 @@ namespace wx {
 typedef uint16_t bf16_t;  // raw bfloat16 storage
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;   // v_pk_{fma,mul,add}_f32 operand
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 struct HipError : std::runtime_error {
   using std::runtime_error::runtime_error;
@@ -25,10 +27,19 @@ struct HipError : std::runtime_error {
   } while (0)
 
 // ---- scalar conversions ---------------------------------------------------
+// two floats -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 __host__ __device__ inline bf16_t f2bf(float f) {  // round-to-nearest-even
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu);
+#else
   uint32_t u = __builtin_bit_cast(uint32_t, f);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
+#endif
 }
 __host__ __device__ inline float bf2f(bf16_t h) {
   uint32_t u = ((uint32_t)h) << 16;
@@ -80,11 +91,38 @@ template <>
 __device__ inline uint4 pack16<bf16_t>(const float* in) {
   uint32_t w[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(in[2 * i]) | ((uint32_t)f2bf(in[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(in[2 * i], in[2 * i + 1]);
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU for the bf16 engine: x * Phi(x) with Phi(x) - 1/2 = xc * P(xc^2) / Q(xc^2), xc = clamp(x, -5, 5), a (3,3)
+// rational minimax fit (weighted for the GELU error): |gelu_fast - gelu| <= 1.5e-5 for |x| <= 9 (fp32 evaluation),
+// i.e. < 1/100 of a bf16 ulp of the result wherever the result is not itself negligible.  ~10 VALU slots per element
+// (two elements per v_pk_fma) against ~45 for libm erff, which made the FF1 epilogue VALU-bound (tools/gemm_probe).
+// The fp32 engine keeps erff.
+__device__ inline f32x2_t gelu_fast2(f32x2_t x) {
+  const f32x2_t xc = {__builtin_amdgcn_fmed3f(x.x, -5.f, 5.f), __builtin_amdgcn_fmed3f(x.y, -5.f, 5.f)};
+  const f32x2_t u = xc * xc;
+  f32x2_t pn = u * 3.009831178e-05f + 3.759064428e-03f;
+  f32x2_t qn = u * 1.096669979e-03f + 2.464125424e-02f;
+  pn = pn * u + 2.940779157e-02f;
+  qn = qn * u + 2.400543728e-01f;
+  pn = pn * u + 3.988773138e-01f;
+  qn = qn * u + 1.0f;
+  const f32x2_t rq = {__builtin_amdgcn_rcpf(qn.x), __builtin_amdgcn_rcpf(qn.y)};
+  return x * (xc * (pn * rq) + 0.5f);
+}
+template <typename T>
+__device__ inline void gelu4(float* v) {  // exact (erff) for the fp32 engine, gelu_fast2 for bf16
+  if constexpr (sizeof(T) == 2) {
+    const f32x2_t a = gelu_fast2(f32x2_t{v[0], v[1]}), b = gelu_fast2(f32x2_t{v[2], v[3]});
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+  }
+}
 __device__ inline float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -50,7 +50,26 @@ struct ConvGemmParams {
   int cout;            // mode 1: channels per sub-pixel
   int py, px;          // mode 2
   int dbg;             // perf-experiment switches (0 in production): 1 skip global stores, 2 skip act, 4 skip K loop, 8 skip residual
+  unsigned long long* trace;  // tools/gemm_probe only: [blocks][8] phase timestamps (s_memtime) + HW_ID; nullptr in production
 };
+#ifdef WX_GEMM_TRACE
+__device__ __forceinline__ void trace_stamp(const ConvGemmParams& p, int slot) {
+  if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 16 + slot] = __builtin_readcyclecounter();
+}
+__device__ __forceinline__ unsigned long long trace_tick() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define WX_TICK(var) const unsigned long long var = trace_tick()
+#define WX_TACC(acc, a, b) acc += (b) - (a)
+#else
+__device__ __forceinline__ void trace_stamp(const ConvGemmParams&, int) {}
+#define WX_TICK(var)
+#define WX_TACC(acc, a, b)
+#endif
 
 __device__ inline float2 row_stats(const ConvGemmParams& p, int m) {
   if (p.stat_tiles == 0) return p.rowstat[m];
@@ -103,8 +122,8 @@ __device__ inline void store4<float>(float* p, const float* v) {
 template <>
 __device__ inline void store4<bf16_t>(bf16_t* p, const float* v) {
   uint2 t;
-  t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  t.x = pack_bf16x2(v[0], v[1]);
+  t.y = pack_bf16x2(v[2], v[3]);
   *reinterpret_cast<uint2*>(p) = t;
 }
 
@@ -262,10 +281,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_gemm_kernel(const 
         if (n < p.n) {
           if (p.rowstat) t = rstd * (t - mean * p.colsum[n]);
           if (p.bias) t += p.bias[n];
-          if (p.act == 1) t = gelu_erf(t);
         }
         v[r] = t;
       }
+      if (p.act == 1) gelu4<T>(v);
       int64_t pix;
       int ch;
       if (p.out_mode == 0) {
@@ -439,6 +458,11 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
     a_step[i] = ok ? KB : 0;
   }
 
+  trace_stamp(p, 0);
+#ifdef WX_GEMM_TRACE
+  if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+  unsigned long long tr_work = 0, tr_dma = 0, tr_bar = 0;
+#endif
   int ky = 0, kx = 0, cc = 0;
   auto issue = [&](unsigned stage_off, int ks) {
 #pragma unroll
@@ -479,15 +503,31 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
   // NST-stage ring: step ks+NST-1 is issued before the MFMAs of step ks; the wait before the barrier leaves the
   // youngest NST-2 stages in flight (counted vmcnt -- the only VMEM ops in this loop are the DMA pieces).
   constexpr int PER_STEP = A_I + B_I;
+  // epilogue parameters -> LDS now, so that the epilogue starts without a dependent L2 round trip:
+  //   s_par[0..127] bias, [128..255] colsum (one DMA instruction), [256..511] (mean, rstd) of the tile's 128 rows
+  constexpr int PARAM_OFF = (NST * STAGE > BM * RB) ? NST * STAGE : BM * RB;
+  float* s_par = reinterpret_cast<float*>(smem + PARAM_OFF);
+  if (wave == 0) {
+    const int idx = lane & 31;
+    const float* srcf = lane < 32 ? p.bias : (p.rowstat ? p.colsum : nullptr);
+    const char* src = (srcf && idx * 4 < BN) ? reinterpret_cast<const char*>(srcf + n_blk + idx * 4) : zero_page;
+    lds_dma16(src, reinterpret_cast<const char*>(s_par));
+  }
+  if (tid < BM) {
+    const int m = m_blk + tid;
+    *reinterpret_cast<float2*>(s_par + 256 + 2 * tid) = (p.rowstat && m < M) ? row_stats(p, m) : make_float2(0.f, 1.f);
+  }
 #pragma unroll
   for (int j = 0; j < NST - 1; ++j)
     if (j < nk) issue((unsigned)(j * STAGE), j);
   if (NST == 3 && nk > 1) dma_wait_allow<PER_STEP>(); else dma_wait_all();
   __syncthreads();
   const int nk_run = (p.dbg & 4) ? 0 : nk;
+  trace_stamp(p, 1);
   int cur_i = 0, nxt_i = NST - 1;  // ring indices of the stage being computed / being filled
   for (int ks = 0; ks < nk_run; ++ks) {
     const char* cur = smem + cur_i * STAGE;
+    WX_TICK(tk0);
     if (ks + NST - 1 < nk) issue((unsigned)(nxt_i * STAGE), ks + NST - 1);
 #pragma unroll
     for (int s = 0; s < SUBS; ++s) {
@@ -502,14 +542,32 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
         for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<T>(wf[a], xf[b], acc[a][b]);
     }
     // step ks+1 must have landed; with 3 stages step ks+2 (just issued) may stay in flight
+    WX_TICK(tk1);
     if (NST == 3 && ks + 2 < nk) dma_wait_allow<PER_STEP>(); else dma_wait_all();
+    WX_TICK(tk2);
     __syncthreads();  // ... for every wave, and everyone is done reading `cur`
+    WX_TICK(tk3);
+    WX_TACC(tr_work, tk0, tk1);
+    WX_TACC(tr_dma, tk1, tk2);
+    WX_TACC(tr_bar, tk2, tk3);
     cur_i = (cur_i + 1 == NST) ? 0 : cur_i + 1;
     nxt_i = (nxt_i + 1 == NST) ? 0 : nxt_i + 1;
   }
   if (NST == 3) { dma_wait_all(); __syncthreads(); }  // nothing of the ring is in flight when the tile is reused
 
+  trace_stamp(p, 2);
+#ifdef WX_GEMM_TRACE
+  if (p.trace && threadIdx.x == 0) {
+    p.trace[(size_t)blockIdx.x * 16 + 8] = tr_work;
+    p.trace[(size_t)blockIdx.x * 16 + 9] = tr_dma;
+    p.trace[(size_t)blockIdx.x * 16 + 10] = tr_bar;
+  }
+#endif
   // ---- epilogue ---------------------------------------------------------------------------------
+  // Straight-line and batched on purpose: the tile is short-K (8-16 steps for the transformer GEMMs), so the
+  // epilogue is a third of a workgroup's lifetime; every per-element branch / dependent load here was measured
+  // (tools/gemm_probe) as exposed latency.  bias, colsum and the LayerNorm row statistics were staged into LDS by
+  // the prologue.
   // (1) residual tile -> LDS by DMA (same slot swizzle as the reads below): slot ^= row & (SPR-1)
   const bool has_res = p.res != nullptr && !(p.dbg & 8);
   if (has_res) {
@@ -525,116 +583,172 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
       lds_dma16(src, smem + (i * 4 + wave) * 1024);
     }
   }
-  // bias / colsum are padded to a multiple of 128 floats by the host, so whole-vector loads are in bounds;
-  // loading them once per lane (not per element behind a branch) keeps the epilogue off the L2 latency path.
-  float4 bias4[FN], cs4[FN];
-#pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    const int n0 = n_blk + wn * WN + a * 16 + g * 4;
-    bias4[a] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    cs4[a] = p.rowstat ? *reinterpret_cast<const float4*>(p.colsum + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  float2 st[FM];
-#pragma unroll
-  for (int b = 0; b < FM; ++b) {
-    const int m = m_blk + wm * 64 + b * 16 + li;
-    st[b] = (p.rowstat && m < M) ? row_stats(p, m) : make_float2(0.f, 1.f);
-  }
-  if (has_res) {
-    dma_wait_all();
-    __syncthreads();
-  }
   const bool do_act = (p.act == 1) && !(p.dbg & 2);
-  // (2) accumulators (+LayerNorm fold, bias, GELU, residual) -> output type, in place in the LDS tile
-#pragma unroll
-  for (int b = 0; b < FM; ++b) {
-    const int ml = wm * 64 + b * 16 + li;
-    const float mean = st[b].x, rstd = st[b].y;
+  // (2) accumulators -> LayerNorm fold + bias (+ GELU), in place
+  {
+    float4 bias4[FN], cs4[FN];
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
       const int nl = wn * WN + a * 16 + g * 4;
-      float v[4];
-      v[0] = rstd * (acc[a][b][0] - mean * cs4[a].x) + bias4[a].x;
-      v[1] = rstd * (acc[a][b][1] - mean * cs4[a].y) + bias4[a].y;
-      v[2] = rstd * (acc[a][b][2] - mean * cs4[a].z) + bias4[a].z;
-      v[3] = rstd * (acc[a][b][3] - mean * cs4[a].w) + bias4[a].w;
-      if (do_act) {  // libm erff: an Abramowitz-Stegun rcp+exp variant measured 10-15 % SLOWER per FF1 launch (A/B, round 1)
+      bias4[a] = *reinterpret_cast<const float4*>(s_par + nl);
+      cs4[a] = *reinterpret_cast<const float4*>(s_par + 128 + nl);
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-      }
-      const int byte = nl * (int)sizeof(T);
-      T* cp = reinterpret_cast<T*>(smem + ml * RB + (((byte >> 4) ^ (ml & (SPR - 1))) << 4) + (byte & 15));
-      if (has_res) {
-        float rv[4];
-        load4<T>(cp, rv);
+    for (int b = 0; b < FM; ++b) {
+      const float2 st = *reinterpret_cast<const float2*>(s_par + 256 + 2 * (wm * 64 + b * 16 + li));
+      const float mean = st.x, rstd = st.y;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+      for (int a = 0; a < FN; ++a) {
+        float v[4];
+        v[0] = rstd * (acc[a][b][0] - mean * cs4[a].x) + bias4[a].x;
+        v[1] = rstd * (acc[a][b][1] - mean * cs4[a].y) + bias4[a].y;
+        v[2] = rstd * (acc[a][b][2] - mean * cs4[a].z) + bias4[a].z;
+        v[3] = rstd * (acc[a][b][3] - mean * cs4[a].w) + bias4[a].w;
+        acc[a][b] = f32x4_t{v[0], v[1], v[2], v[3]};
       }
-      store4<T>(cp, v);
     }
   }
+  if (do_act) {
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int a = 0; a < FN; ++a) {
+        float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+        gelu4<T>(v);
+        acc[a][b] = f32x4_t{v[0], v[1], v[2], v[3]};
+      }
+  }
+  // this lane's element (a, b) lives at row ml, 16-byte slot (byte>>4) ^ (ml & (SPR-1)) of the output-typed tile
+  const char* ctile[FM];
+#pragma unroll
+  for (int b = 0; b < FM; ++b) ctile[b] = smem + (wm * 64 + b * 16 + li) * RB;
+  auto coff = [&](int a, int b) {
+    const int ml = wm * 64 + b * 16 + li;
+    const int byte = (wn * WN + a * 16 + g * 4) * (int)sizeof(T);
+    return (((byte >> 4) ^ (ml & (SPR - 1))) << 4) + (byte & 15);
+  };
+  if (has_res) {  // (2b) + residual: all 16 reads in flight before the first add (single rounding at the store)
+    dma_wait_all();
+    __syncthreads();
+    float rv[FM][FN][4];
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int a = 0; a < FN; ++a) load4<T>(reinterpret_cast<const T*>(ctile[b] + coff(a, b)), rv[b][a]);
+#pragma unroll
+    for (int b = 0; b < FM; ++b)
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+        acc[a][b] = f32x4_t{acc[a][b][0] + rv[b][a][0], acc[a][b][1] + rv[b][a][1], acc[a][b][2] + rv[b][a][2],
+                            acc[a][b][3] + rv[b][a][3]};
+  }
+#pragma unroll
+  for (int b = 0; b < FM; ++b)
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      store4<T>(reinterpret_cast<T*>(const_cast<char*>(ctile[b]) + coff(a, b)), v);
+    }
   __syncthreads();
+  trace_stamp(p, 3);
   // (3) whole 16-byte pieces of full rows -> global; optionally the per-row (sum, sum sq) of this tile's
   //     channels for the next LayerNorm, or the per-channel (sum, sum sq) over the tile's rows for GroupNorm
   //     (both taken from the ROUNDED values the consumer will read; fixed summation order: deterministic)
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
   constexpr int EPV = 16 / (int)sizeof(T);  // elements per piece
+  constexpr int NPC = BM * SPR / 256;       // pieces per thread
+  constexpr int RPP = 256 / SPR;            // rows between a thread's consecutive pieces
   float gs[EPV], gq[EPV];
 #pragma unroll
   for (int e = 0; e < EPV; ++e) gs[e] = gq[e] = 0.f;
-#pragma unroll 4
-  for (int idx = tid; idx < BM * SPR; idx += 256) {
-    const int ml = idx / SPR, sl = idx - ml * SPR;
-    const int m = m_blk + ml, n0 = n_blk + sl * EPV;
-    const bool valid = m < M && n0 < p.n;
-    const uint4 piece = *reinterpret_cast<const uint4*>(smem + ml * RB + ((sl ^ (ml & (SPR - 1))) << 4));
-    if (p.stat_out) {
-      float f[EPV], s1 = 0.f, s2 = 0.f;
-      unpack16<T>(piece, f);
-      if (valid && n0 + EPV <= p.n) {
+  const int ml0 = tid / SPR, sl = tid % SPR;  // this thread: rows ml0 + i*RPP, channel slot sl (the same in every pass)
+  const int n0 = n_blk + sl * EPV;
+  uint4 pc[NPC];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) { s1 += f[e]; s2 += f[e] * f[e]; }
-      }
+  for (int i = 0; i < NPC; ++i) {
+    const int ml = ml0 + i * RPP;
+    pc[i] = *reinterpret_cast<const uint4*>(smem + ml * RB + ((sl ^ (ml & (SPR - 1))) << 4));
+  }
+  if (p.stat_out) {
+    float s1[NPC], s2[NPC];
 #pragma unroll
-      for (int o = 1; o < SPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-      if (sl == 0 && m < M) p.stat_out[(int64_t)m * n_tiles + tile_n] = make_float2(s1, s2);
-    }
-    if (p.gn_out && valid) {  // this thread sees the same channel slot `sl` in every pass (256 % SPR == 0)
+    for (int i = 0; i < NPC; ++i) {
       float f[EPV];
-      unpack16<T>(piece, f);
+      unpack16<T>(pc[i], f);
+      s1[i] = s2[i] = 0.f;
+      if (n0 + EPV <= p.n) {
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) { gs[e] += f[e]; gq[e] += f[e] * f[e]; }
-    }
-    if (!valid) continue;
-    int64_t pix;
-    int ch;
-    if (p.out_mode == 0) {
-      pix = m;
-      ch = n0;
-    } else {
-      const int oy = m / p.out_w, ox = m - oy * p.out_w;
-      if (p.out_mode == 1) {
-        const int q = n0 / p.cout;   // cout % 8 == 0 (host-checked): one piece never straddles two sub-pixels
-        ch = n0 - q * p.cout;
-        pix = (int64_t)(2 * oy + (q >> 1)) * (2 * p.out_w) + 2 * ox + (q & 1);
-      } else {
-        pix = (int64_t)(2 * oy + p.py) * (2 * p.out_w) + 2 * ox + p.px;
-        ch = n0;
+        for (int e = 0; e < EPV; ++e) { s1[i] += f[e]; s2[i] += f[e] * f[e]; }
       }
     }
-    if (n0 + EPV <= p.n) {
-      if (!(p.dbg & 1) || piece.x == 0x12345678u) *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch) = piece;
-    } else {
-      const uint32_t w[4] = {piece.x, piece.y, piece.z, piece.w};
 #pragma unroll
-      for (int r = 0; r < EPV; ++r) {  // constant indices only: keeps `piece` out of scratch
-        if (n0 + r < p.n) {
-          if constexpr (sizeof(T) == 2) out[pix * p.out_ld + ch + r] = (T)((w[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
-          else out[pix * p.out_ld + ch + r] = __builtin_bit_cast(T, w[r]);
+    for (int o = 1; o < SPR; o <<= 1) {
+#pragma unroll
+      for (int i = 0; i < NPC; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
+    }
+    if (sl == 0) {
+#pragma unroll
+      for (int i = 0; i < NPC; ++i) {
+        const int m = m_blk + ml0 + i * RPP;
+        if (m < M) p.stat_out[(int64_t)m * n_tiles + tile_n] = make_float2(s1[i], s2[i]);
+      }
+    }
+  }
+  if (p.gn_out) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      if (m_blk + ml0 + i * RPP < M && n0 < p.n) {
+        float f[EPV];
+        unpack16<T>(pc[i], f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { gs[e] += f[e]; gq[e] += f[e] * f[e]; }
+      }
+    }
+  }
+  if (p.out_mode == 0 && n0 + EPV <= p.n) {  // the common case: one pointer, NPC strided 16-byte stores
+    T* optr = out + (int64_t)(m_blk + ml0) * p.out_ld + n0;
+    const int64_t ostep = (int64_t)RPP * p.out_ld;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      if (m_blk + ml0 + i * RPP < M && (!(p.dbg & 1) || pc[i].x == 0x12345678u)) *reinterpret_cast<uint4*>(optr + i * ostep) = pc[i];
+    }
+  } else if (n0 < p.n) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int m = m_blk + ml0 + i * RPP;
+      if (m >= M) continue;
+      const uint4 piece = pc[i];
+      int64_t pix;
+      int ch;
+      if (p.out_mode == 0) {
+        pix = m;
+        ch = n0;
+      } else {
+        const int oy = m / p.out_w, ox = m - oy * p.out_w;
+        if (p.out_mode == 1) {
+          const int q = n0 / p.cout;   // cout % 8 == 0 (host-checked): one piece never straddles two sub-pixels
+          ch = n0 - q * p.cout;
+          pix = (int64_t)(2 * oy + (q >> 1)) * (2 * p.out_w) + 2 * ox + (q & 1);
+        } else {
+          pix = (int64_t)(2 * oy + p.py) * (2 * p.out_w) + 2 * ox + p.px;
+          ch = n0;
+        }
+      }
+      if (n0 + EPV <= p.n) {
+        *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch) = piece;
+      } else {
+        const uint32_t w[4] = {piece.x, piece.y, piece.z, piece.w};
+#pragma unroll
+        for (int r = 0; r < EPV; ++r) {  // constant indices only: keeps `piece` out of scratch
+          if (n0 + r < p.n) {
+            if constexpr (sizeof(T) == 2) out[pix * p.out_ld + ch + r] = (T)((w[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
+            else out[pix * p.out_ld + ch + r] = __builtin_bit_cast(T, w[r]);
+          }
         }
       }
     }
   }
+  trace_stamp(p, 4);
   if (p.gn_out) {
     // lanes sl, sl+SPR, ... of a wave hold the same channels -> fold them, then fold the 4 waves through LDS
 #pragma unroll
@@ -665,7 +779,7 @@ template <typename T, int BN, int KB, bool ONE, int NST>
 inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
   constexpr int STAGES = NST * (128 + BN) * KB;
   constexpr int CT = 128 * BN * (int)sizeof(T);
-  constexpr int LDS = STAGES > CT ? STAGES : CT;
+  constexpr int LDS = (STAGES > CT ? STAGES : CT) + 2048;  // + epilogue parameter block
   auto kern = conv_gemm_dma_kernel<T, BN, KB, ONE, NST>;
   static bool attr_done = false;
   if (!attr_done) {
