@@ -372,18 +372,26 @@ __device__ __forceinline__ int stage_swz(int row) {
 template <int N>
 __device__ __forceinline__ void dma_wait_allow() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BN, int KB, bool ONE, int NST>
-__global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 : 3) : 2) void conv_gemm_dma_kernel(
+// Every wave owns 64 pixels x BN/2 channels (<= 128 VGPRs).  The vector L1 feeds LDS at 64 B/clk/CU
+// (tools/l1_probe: 57-63 B/clk measured for global_load_lds_dwordx4 and for plain loads alike), which at
+// BM = BN = 128 is exactly the MFMA rate (64 FLOP per staged byte x 64 B/clk = 4096 FLOP/clk/CU): the 4-wave tile is
+// L1-bound by construction.  BM = 256 (8 waves, 4 x 2) stages 25 % fewer bytes per FLOP; two such workgroups and a
+// 3-stage ring fit a CU (2 x 74 KB LDS, 16 waves).
+template <typename T, int BM, int BN, int KB, bool ONE, int NST>
+__global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 : 3) : 2)) void conv_gemm_dma_kernel(
     const ConvGemmParams p, const char* __restrict__ zero_page) {
-  constexpr int BM = 128;
+  constexpr int WMR = 64;               // rows (pixels) per wave
+  constexpr int WAVES_M = BM / WMR;     // 2 or 4
+  constexpr int NW = WAVES_M * 2;       // waves per workgroup
+  constexpr int NT = NW * 64;
   constexpr int BKE = KB / (int)sizeof(T);
   constexpr int PPR = KB / 16;          // 16-byte slots per staged row
   constexpr int RPI = 64 / PPR;         // rows moved by one DMA wave-instruction
   constexpr int SUBS = KB / 64;
   constexpr int WN = BN / 2;            // 2x2 waves, wave tile 64 pixels x WN channels
-  constexpr int FM = 4, FN = WN / 16;
-  constexpr int A_I = BM / (4 * RPI);   // DMA instructions per wave per K step (activations / weights)
-  constexpr int B_I = BN / (4 * RPI);
+  constexpr int FM = WMR / 16, FN = WN / 16;
+  constexpr int A_I = BM / (NW * RPI);  // DMA instructions per wave per K step (activations / weights)
+  constexpr int B_I = BN / (NW * RPI);
   constexpr int STAGE = (BM + BN) * KB;
   constexpr int RB = BN * (int)sizeof(T);   // epilogue tile row bytes (un-padded, slot-swizzled)
   constexpr int SPR = RB / 16;              // 16-byte slots per epilogue row
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
   const int li = lane & 15, g = lane >> 4;
 
   const int M = p.out_h * p.out_w;
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
   int a_piece[A_I];
 #pragma unroll
   for (int i = 0; i < A_I; ++i) {
-    const int row = (i * 4 + wave) * RPI + lrow;
+    const int row = (i * NW + wave) * RPI + lrow;
     const int m = m_blk + row;
     a_ok[i] = m < M;
     const int oy = m / p.out_w, ox = m - oy * p.out_w;
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
   const char* b_src[B_I];
 #pragma unroll
   for (int i = 0; i < B_I; ++i) {
-    const int row = (i * 4 + wave) * RPI + lrow;
+    const int row = (i * NW + wave) * RPI + lrow;
     const int n = n_blk + row;
     const int piece = (lslot ^ stage_swz<KB>(row)) * 16;
     b_src[i] = (n < p.n_alloc) ? wt + ((int64_t)n * ktot) * (int64_t)sizeof(T) + piece : nullptr;
@@ -439,9 +447,9 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
   // LDS destinations of this wave's DMA instructions, as scalars (stage 0; stage 1 = + STAGE)
   unsigned a_dst[A_I], b_dst[B_I];
 #pragma unroll
-  for (int i = 0; i < A_I; ++i) a_dst[i] = lds_addr_sgpr(smem + (i * 4 + wave) * 1024);
+  for (int i = 0; i < A_I; ++i) a_dst[i] = lds_addr_sgpr(smem + (i * NW + wave) * 1024);
 #pragma unroll
-  for (int i = 0; i < B_I; ++i) b_dst[i] = lds_addr_sgpr(smem + BM * KB + (i * 4 + wave) * 1024);
+  for (int i = 0; i < B_I; ++i) b_dst[i] = lds_addr_sgpr(smem + BM * KB + (i * NW + wave) * 1024);
   // weights (and, for ONE, activations): base pointer + per-step stride; invalid rows read the zero page (stride 0)
   int64_t b_step[B_I];
 #pragma unroll
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
     for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int sw = stage_swz<KB>(li);  // fragment row bases are multiples of 16, so the swizzle depends on li only
-  const int x_base = (wm * 64 + li) * KB;
+  const int x_base = (wm * WMR + li) * KB;
   const int w_base = BM * KB + (wn * WN + li) * KB;
   int soff[SUBS];
 #pragma unroll
@@ -528,7 +536,12 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
   for (int ks = 0; ks < nk_run; ++ks) {
     const char* cur = smem + cur_i * STAGE;
     WX_TICK(tk0);
+#ifdef WX_GEMM_TRACE
+    if (ks + NST - 1 < nk && !(p.dbg & 1024)) issue((unsigned)(nxt_i * STAGE), ks + NST - 1);
+    if (p.dbg & 2048) cur = smem;  // ds_reads always from stage 0 (still executed)
+#else
     if (ks + NST - 1 < nk) issue((unsigned)(nxt_i * STAGE), ks + NST - 1);
+#endif
 #pragma unroll
     for (int s = 0; s < SUBS; ++s) {
       uint4 xf[FM], wf[FN];
@@ -536,6 +549,13 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
       for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const uint4*>(cur + x_base + b * 16 * KB + soff[s]);
 #pragma unroll
       for (int a = 0; a < FN; ++a) wf[a] = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * KB + soff[s]);
+#ifdef WX_GEMM_TRACE
+      if (p.dbg & 4096) {  // no MFMA: fold the fragments into the accumulators with a few VALU ops
+#pragma unroll
+        for (int a = 0; a < FN; ++a) acc[a][0][0] += __builtin_bit_cast(float, wf[a].x ^ xf[a % FM].y);
+        continue;
+      }
+#endif
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
@@ -574,13 +594,13 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
     const char* __restrict__ res = reinterpret_cast<const char*>(p.res);
     const int crow = lane / SPR, cslot = lane % SPR;
 #pragma unroll
-    for (int i = 0; i < BM / (4 * C_RPI); ++i) {
-      const int row = (i * 4 + wave) * C_RPI + crow;
+    for (int i = 0; i < BM / (NW * C_RPI); ++i) {
+      const int row = (i * NW + wave) * C_RPI + crow;
       const int m = m_blk + row;
       const int piece = cslot ^ (row & (SPR - 1));
       const bool ok = m < M && n_blk + piece * (16 / (int)sizeof(T)) < p.n;
       const char* src = ok ? res + ((int64_t)m * p.res_ld + n_blk) * (int64_t)sizeof(T) + piece * 16 : zero_page;
-      lds_dma16(src, smem + (i * 4 + wave) * 1024);
+      lds_dma16(src, smem + (i * NW + wave) * 1024);
     }
   }
   const bool do_act = (p.act == 1) && !(p.dbg & 2);
@@ -595,7 +615,7 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
     }
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
-      const float2 st = *reinterpret_cast<const float2*>(s_par + 256 + 2 * (wm * 64 + b * 16 + li));
+      const float2 st = *reinterpret_cast<const float2*>(s_par + 256 + 2 * (wm * WMR + b * 16 + li));
       const float mean = st.x, rstd = st.y;
 #pragma unroll
       for (int a = 0; a < FN; ++a) {
@@ -621,26 +641,30 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
   // this lane's element (a, b) lives at row ml, 16-byte slot (byte>>4) ^ (ml & (SPR-1)) of the output-typed tile
   const char* ctile[FM];
 #pragma unroll
-  for (int b = 0; b < FM; ++b) ctile[b] = smem + (wm * 64 + b * 16 + li) * RB;
+  for (int b = 0; b < FM; ++b) ctile[b] = smem + (wm * WMR + b * 16 + li) * RB;
   auto coff = [&](int a, int b) {
-    const int ml = wm * 64 + b * 16 + li;
+    const int ml = wm * WMR + b * 16 + li;
     const int byte = (wn * WN + a * 16 + g * 4) * (int)sizeof(T);
     return (((byte >> 4) ^ (ml & (SPR - 1))) << 4) + (byte & 15);
   };
   if (has_res) {  // (2b) + residual: all 16 reads in flight before the first add (single rounding at the store)
     dma_wait_all();
     __syncthreads();
-    float rv[FM][FN][4];
+    constexpr int RBT = 2;  // batches of RBT x FN reads in flight (register budget)
 #pragma unroll
-    for (int b = 0; b < FM; ++b)
+    for (int b0 = 0; b0 < FM; b0 += RBT) {
+      float rv[RBT][FN][4];
 #pragma unroll
-      for (int a = 0; a < FN; ++a) load4<T>(reinterpret_cast<const T*>(ctile[b] + coff(a, b)), rv[b][a]);
+      for (int b = 0; b < RBT; ++b)
 #pragma unroll
-    for (int b = 0; b < FM; ++b)
+        for (int a = 0; a < FN; ++a) load4<T>(reinterpret_cast<const T*>(ctile[b0 + b] + coff(a, b0 + b)), rv[b][a]);
 #pragma unroll
-      for (int a = 0; a < FN; ++a)
-        acc[a][b] = f32x4_t{acc[a][b][0] + rv[b][a][0], acc[a][b][1] + rv[b][a][1], acc[a][b][2] + rv[b][a][2],
-                            acc[a][b][3] + rv[b][a][3]};
+      for (int b = 0; b < RBT; ++b)
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+          acc[a][b0 + b] = f32x4_t{acc[a][b0 + b][0] + rv[b][a][0], acc[a][b0 + b][1] + rv[b][a][1],
+                                   acc[a][b0 + b][2] + rv[b][a][2], acc[a][b0 + b][3] + rv[b][a][3]};
+    }
   }
 #pragma unroll
   for (int b = 0; b < FM; ++b)
@@ -656,93 +680,98 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
   //     (both taken from the ROUNDED values the consumer will read; fixed summation order: deterministic)
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
   constexpr int EPV = 16 / (int)sizeof(T);  // elements per piece
-  constexpr int NPC = BM * SPR / 256;       // pieces per thread
-  constexpr int RPP = 256 / SPR;            // rows between a thread's consecutive pieces
+  constexpr int NPT = BM * SPR / NT;        // pieces per thread
+  constexpr int NPC = 4;                    // ... handled in batches of NPC (register budget)
+  constexpr int RPP = NT / SPR;             // rows between a thread's consecutive pieces
   float gs[EPV], gq[EPV];
 #pragma unroll
   for (int e = 0; e < EPV; ++e) gs[e] = gq[e] = 0.f;
-  const int ml0 = tid / SPR, sl = tid % SPR;  // this thread: rows ml0 + i*RPP, channel slot sl (the same in every pass)
+  const int sl = tid % SPR;                 // this thread's channel slot (the same in every pass)
   const int n0 = n_blk + sl * EPV;
-  uint4 pc[NPC];
 #pragma unroll
-  for (int i = 0; i < NPC; ++i) {
-    const int ml = ml0 + i * RPP;
-    pc[i] = *reinterpret_cast<const uint4*>(smem + ml * RB + ((sl ^ (ml & (SPR - 1))) << 4));
-  }
-  if (p.stat_out) {
-    float s1[NPC], s2[NPC];
+  for (int pb = 0; pb < NPT; pb += NPC) {
+    const int ml0 = tid / SPR + pb * RPP;   // this batch: rows ml0 + i*RPP
+    uint4 pc[NPC];
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
-      float f[EPV];
-      unpack16<T>(pc[i], f);
-      s1[i] = s2[i] = 0.f;
-      if (n0 + EPV <= p.n) {
+      const int ml = ml0 + i * RPP;
+      pc[i] = *reinterpret_cast<const uint4*>(smem + ml * RB + ((sl ^ (ml & (SPR - 1))) << 4));
+    }
+    if (p.stat_out) {
+      float s1[NPC], s2[NPC];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) { s1[i] += f[e]; s2[i] += f[e] * f[e]; }
+      for (int i = 0; i < NPC; ++i) {
+        float f[EPV];
+        unpack16<T>(pc[i], f);
+        s1[i] = s2[i] = 0.f;
+        if (n0 + EPV <= p.n) {
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) { s1[i] += f[e]; s2[i] += f[e] * f[e]; }
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < SPR; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
+      }
+      if (sl == 0) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+          const int m = m_blk + ml0 + i * RPP;
+          if (m < M) p.stat_out[(int64_t)m * n_tiles + tile_n] = make_float2(s1[i], s2[i]);
+        }
       }
     }
+    if (p.gn_out) {
 #pragma unroll
-    for (int o = 1; o < SPR; o <<= 1) {
+      for (int i = 0; i < NPC; ++i) {
+        if (m_blk + ml0 + i * RPP < M && n0 < p.n) {
+          float f[EPV];
+          unpack16<T>(pc[i], f);
 #pragma unroll
-      for (int i = 0; i < NPC; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
+          for (int e = 0; e < EPV; ++e) { gs[e] += f[e]; gq[e] += f[e] * f[e]; }
+        }
+      }
     }
-    if (sl == 0) {
+    if (p.out_mode == 0 && n0 + EPV <= p.n) {  // the common case: one pointer, NPC strided 16-byte stores
+      T* optr = out + (int64_t)(m_blk + ml0) * p.out_ld + n0;
+      const int64_t ostep = (int64_t)RPP * p.out_ld;
+#pragma unroll
+      for (int i = 0; i < NPC; ++i) {
+        if (m_blk + ml0 + i * RPP < M && (!(p.dbg & 1) || pc[i].x == 0x12345678u)) *reinterpret_cast<uint4*>(optr + i * ostep) = pc[i];
+      }
+    } else if (n0 < p.n) {
 #pragma unroll
       for (int i = 0; i < NPC; ++i) {
         const int m = m_blk + ml0 + i * RPP;
-        if (m < M) p.stat_out[(int64_t)m * n_tiles + tile_n] = make_float2(s1[i], s2[i]);
-      }
-    }
-  }
-  if (p.gn_out) {
-#pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      if (m_blk + ml0 + i * RPP < M && n0 < p.n) {
-        float f[EPV];
-        unpack16<T>(pc[i], f);
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) { gs[e] += f[e]; gq[e] += f[e] * f[e]; }
-      }
-    }
-  }
-  if (p.out_mode == 0 && n0 + EPV <= p.n) {  // the common case: one pointer, NPC strided 16-byte stores
-    T* optr = out + (int64_t)(m_blk + ml0) * p.out_ld + n0;
-    const int64_t ostep = (int64_t)RPP * p.out_ld;
-#pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      if (m_blk + ml0 + i * RPP < M && (!(p.dbg & 1) || pc[i].x == 0x12345678u)) *reinterpret_cast<uint4*>(optr + i * ostep) = pc[i];
-    }
-  } else if (n0 < p.n) {
-#pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      const int m = m_blk + ml0 + i * RPP;
-      if (m >= M) continue;
-      const uint4 piece = pc[i];
-      int64_t pix;
-      int ch;
-      if (p.out_mode == 0) {
-        pix = m;
-        ch = n0;
-      } else {
-        const int oy = m / p.out_w, ox = m - oy * p.out_w;
-        if (p.out_mode == 1) {
-          const int q = n0 / p.cout;   // cout % 8 == 0 (host-checked): one piece never straddles two sub-pixels
-          ch = n0 - q * p.cout;
-          pix = (int64_t)(2 * oy + (q >> 1)) * (2 * p.out_w) + 2 * ox + (q & 1);
-        } else {
-          pix = (int64_t)(2 * oy + p.py) * (2 * p.out_w) + 2 * ox + p.px;
+        if (m >= M) continue;
+        const uint4 piece = pc[i];
+        int64_t pix;
+        int ch;
+        if (p.out_mode == 0) {
+          pix = m;
           ch = n0;
+        } else {
+          const int oy = m / p.out_w, ox = m - oy * p.out_w;
+          if (p.out_mode == 1) {
+            const int q = n0 / p.cout;   // cout % 8 == 0 (host-checked): one piece never straddles two sub-pixels
+            ch = n0 - q * p.cout;
+            pix = (int64_t)(2 * oy + (q >> 1)) * (2 * p.out_w) + 2 * ox + (q & 1);
+          } else {
+            pix = (int64_t)(2 * oy + p.py) * (2 * p.out_w) + 2 * ox + p.px;
+            ch = n0;
+          }
         }
-      }
-      if (n0 + EPV <= p.n) {
-        *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch) = piece;
-      } else {
-        const uint32_t w[4] = {piece.x, piece.y, piece.z, piece.w};
+        if (n0 + EPV <= p.n) {
+          *reinterpret_cast<uint4*>(out + pix * p.out_ld + ch) = piece;
+        } else {
+          const uint32_t w[4] = {piece.x, piece.y, piece.z, piece.w};
 #pragma unroll
-        for (int r = 0; r < EPV; ++r) {  // constant indices only: keeps `piece` out of scratch
-          if (n0 + r < p.n) {
-            if constexpr (sizeof(T) == 2) out[pix * p.out_ld + ch + r] = (T)((w[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
-            else out[pix * p.out_ld + ch + r] = __builtin_bit_cast(T, w[r]);
+          for (int r = 0; r < EPV; ++r) {  // constant indices only: keeps `piece` out of scratch
+            if (n0 + r < p.n) {
+              if constexpr (sizeof(T) == 2) out[pix * p.out_ld + ch + r] = (T)((w[r >> 1] >> ((r & 1) * 16)) & 0xffffu);
+              else out[pix * p.out_ld + ch + r] = __builtin_bit_cast(T, w[r]);
+            }
           }
         }
       }
@@ -769,26 +798,26 @@ __global__ __launch_bounds__(256, (KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 :
     if (tid < BN && n_blk + tid < p.n) {
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      for (int w = 0; w < NW; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
       p.gn_out[(int64_t)tile_m * p.n + n_blk + tid] = make_float2(a, b);
     }
   }
 }
 
-template <typename T, int BN, int KB, bool ONE, int NST>
+template <typename T, int BM, int BN, int KB, bool ONE, int NST>
 inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
-  constexpr int STAGES = NST * (128 + BN) * KB;
-  constexpr int CT = 128 * BN * (int)sizeof(T);
-  constexpr int LDS = (STAGES > CT ? STAGES : CT) + 2048;  // + epilogue parameter block
-  auto kern = conv_gemm_dma_kernel<T, BN, KB, ONE, NST>;
+  constexpr int STAGES = NST * (BM + BN) * KB;
+  constexpr int CT = BM * BN * (int)sizeof(T);
+  constexpr int LDS = (STAGES > CT ? STAGES : CT) + 1024 + BM * 8;  // + epilogue parameter block
+  auto kern = conv_gemm_dma_kernel<T, BM, BN, KB, ONE, NST>;
   static bool attr_done = false;
   if (!attr_done) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
   const int M = p.out_h * p.out_w;
-  const int64_t blocks = (int64_t)cdiv(M, 128) * cdiv(p.n, BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
+  const int64_t blocks = (int64_t)cdiv(M, BM) * cdiv(p.n, BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BM * 2), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
   WX_HIP(hipGetLastError());
 }
 
@@ -826,10 +855,16 @@ inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page,
                    p.in_w == p.out_w;
   const bool three = KB == 64 && (p.dbg & 128);  // experiment switch: 3-stage ring, 3 workgroups/CU
   if (one) {
-    if (three) launch_conv_gemm_dma_v<T, BN, KB, true, (KB == 64 ? 3 : 2)>(p, zero_page, stream);
-    else launch_conv_gemm_dma_v<T, BN, KB, true, 2>(p, zero_page, stream);
+    if constexpr (KB == 64 && BN == 128 && sizeof(T) == 2) {
+      if ((p.dbg & 512) && !p.gn_out) {  // experiment switch: 256-row tiles
+        launch_conv_gemm_dma_v<T, 256, BN, KB, true, 3>(p, zero_page, stream);
+        return;
+      }
+    }
+    if (three) launch_conv_gemm_dma_v<T, 128, BN, KB, true, (KB == 64 ? 3 : 2)>(p, zero_page, stream);
+    else launch_conv_gemm_dma_v<T, 128, BN, KB, true, 2>(p, zero_page, stream);
   } else {
-    launch_conv_gemm_dma_v<T, BN, KB, false, 2>(p, zero_page, stream);
+    launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2>(p, zero_page, stream);
   }
 }
 

@@ -81,7 +81,8 @@ int main(int argc, char** argv) {
 
   // trace pass
   const int bn = N >= 96 ? 128 : 64;
-  const size_t blocks = (size_t)((M + 127) / 128) * ((N + bn - 1) / bn);
+  const int bm = (dbg & 512) ? 256 : 128;
+  const size_t blocks = (size_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   unsigned long long* tr = (unsigned long long*)dalloc(blocks * 128);
   WX_HIP(hipMemset(tr, 0, blocks * 128));
   p.trace = tr;
