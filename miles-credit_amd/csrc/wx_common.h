@@ -113,17 +113,58 @@ __device__ inline f32x2_t gelu_fast2(f32x2_t x) {
   const f32x2_t rq = {__builtin_amdgcn_rcpf(qn.x), __builtin_amdgcn_rcpf(qn.y)};
   return x * (xc * (pn * rq) + 0.5f);
 }
+// N pairs at a time, written step-by-step ACROSS the pairs: hipcc keeps the source order, and a chain-by-chain
+// formulation leaves every packed op waiting on its predecessor (s_nop between dependent v_pk_* ops) -- the
+// feed-forward kernels are VALU-bound on exactly this code.  One v_rcp_f32 (quarter rate) serves four denominators:
+//   r = 1/(Q0 Q1 Q2 Q3);  1/Q0 = r (Q2 Q3) Q1, ...   (Q in [1, 40]: the product stays far inside fp32 range)
+template <int NP>
+__device__ inline void gelu_fast_pairs(f32x2_t* v) {  // NP even
+  f32x2_t xc[NP], u[NP], pn[NP], qn[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) xc[i] = f32x2_t{__builtin_amdgcn_fmed3f(v[i].x, -5.f, 5.f), __builtin_amdgcn_fmed3f(v[i].y, -5.f, 5.f)};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) u[i] = xc[i] * xc[i];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) { pn[i] = u[i] * 3.009831178e-05f + 3.759064428e-03f; qn[i] = u[i] * 1.096669979e-03f + 2.464125424e-02f; }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) { pn[i] = pn[i] * u[i] + 2.940779157e-02f; qn[i] = qn[i] * u[i] + 2.400543728e-01f; }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) { pn[i] = pn[i] * u[i] + 3.988773138e-01f; qn[i] = qn[i] * u[i] + 1.0f; }
+  f32x2_t qq[NP / 2];
+  float r[NP / 2];
+#pragma unroll
+  for (int i = 0; i < NP / 2; ++i) qq[i] = qn[2 * i] * qn[2 * i + 1];  // (Qa.x Qb.x, Qa.y Qb.y)
+#pragma unroll
+  for (int i = 0; i < NP / 2; ++i) r[i] = __builtin_amdgcn_rcpf(qq[i].x * qq[i].y);
+#pragma unroll
+  for (int i = 0; i < NP / 2; ++i) {
+    const f32x2_t rr = f32x2_t{qq[i].y, qq[i].x} * r[i];  // (1/(Qa.x Qb.x), 1/(Qa.y Qb.y))
+    const f32x2_t ia = rr * qn[2 * i + 1], ib = rr * qn[2 * i];
+    pn[2 * i] = pn[2 * i] * ia;
+    pn[2 * i + 1] = pn[2 * i + 1] * ib;
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) xc[i] = xc[i] * pn[i] + 0.5f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) v[i] = v[i] * xc[i];
+}
+__device__ inline void gelu_fast4(f32x2_t& a, f32x2_t& b) {
+  f32x2_t v[2] = {a, b};
+  gelu_fast_pairs<2>(v);
+  a = v[0];
+  b = v[1];
+}
 template <typename T>
-__device__ inline void gelu4(float* v) {  // exact (erff) for the fp32 engine, gelu_fast2 for bf16
+__device__ inline void gelu4(float* v) {  // exact (erff) for the fp32 engine, the rational for bf16
   if constexpr (sizeof(T) == 2) {
-    const f32x2_t a = gelu_fast2(f32x2_t{v[0], v[1]}), b = gelu_fast2(f32x2_t{v[2], v[3]});
+    f32x2_t a = {v[0], v[1]}, b = {v[2], v[3]};
+    gelu_fast4(a, b);
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
   }
 }
-__device__ inline float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

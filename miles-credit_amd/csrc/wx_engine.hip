@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "wx_attn.h"
+#include "wx_ff.h"
 #include "wx_common.h"
 #include "wx_elem.h"
 #include "wx_embed.h"
@@ -45,7 +46,7 @@ struct ConvW {          // one repacked GEMM operand in the weight arena
   int cin_true = 0;     // unpadded channels (flop accounting)
 };
 struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1; int wsz = 0, kind = 0; };
-struct FFL { ConvW w1, w2; };
+struct FFL { ConvW w1, w2; int64_t pack = -1; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
 struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmbed branch (wx_embed.h)
 struct StageL { std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks; };
@@ -515,11 +516,36 @@ class Engine : public EngineBase {
     a.out = make_conv(p + ".to_out", 0, c, c, c, 1, 1, true, nullptr, nullptr);
     return a;
   }
+  // chunk blocks for ff_fused_kernel, built from the ROUNDED arena weights of w1 / w2 (same values as the unfused path)
+  int64_t pack_ff(const FFL& f, int c, int hidden) {
+    while (wt_host.size() % 8) wt_host.push_back(Elem<T>::from_f(0.f));
+    const int64_t off = (int64_t)wt_host.size();
+    const int nch = hidden / 32;
+    const int64_t cb = 64 * (int64_t)c;  // elements per chunk block (128*C bytes of bf16)
+    wt_host.resize(off + nch * cb);
+    for (int ch = 0; ch < nch; ++ch) {
+      const int64_t base = off + ch * cb;
+      for (int r = 0; r < 32; ++r)
+        for (int sl = 0; sl < c / 8; ++sl) {
+          const int ks = sl / 4, g = sl % 4, phys = sl ^ (r & 15);
+          for (int j = 0; j < 8; ++j)
+            wt_host[base + (int64_t)r * c + phys * 8 + j] = wt_host[f.w1.wt + (int64_t)(ch * 32 + r) * c + 32 * ks + ff_perm(g, j)];
+        }
+      for (int o = 0; o < c; ++o)
+        for (int g = 0; g < 4; ++g)
+          for (int j = 0; j < 8; ++j)
+            wt_host[base + 32 * (int64_t)c + (int64_t)o * 32 + ff_w2_slot(o, g) * 8 + j] = wt_host[f.w2.wt + (int64_t)o * hidden + ch * 32 + ff_perm(g, j)];
+    }
+    return off;
+  }
   FFL make_ff(const std::string& p, int c) {
     FFL f;
     const HostTensor &g = need(p + ".layers.0.g"), &b = need(p + ".layers.0.b");
     f.w1 = make_conv(p + ".layers.1", 0, 4 * c, c, c, 1, 1, true, g.data.data(), b.data.data());
     f.w2 = make_conv(p + ".layers.4", 0, c, 4 * c, 4 * c, 1, 1, true, nullptr, nullptr);
+    if constexpr (sizeof(T) == 2) {
+      if (ff_fused_supported(c, 4 * c)) f.pack = pack_ff(f, c, 4 * c);
+    }
     return f;
   }
 
@@ -624,6 +650,8 @@ class Engine : public EngineBase {
   int dbg_flags = 0;
   int gemm_cfg = 0;
   bool fuse_ln = true;
+  bool fuse_ff = true;          // stages with C in {128, 256}: FeedForward as one kernel (wx_ff.h), bf16 engine
+  int ff_variant = 0, ff_dbg = 0;
   float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
   int stat_tiles_ready = 0;     // > 0: `statpart` holds partials of the current stream contents (that many per row)
@@ -666,6 +694,9 @@ class Engine : public EngineBase {
     if (const char* e = getenv("WX_DBG")) dbg_flags = atoi(e);
     if (const char* e = getenv("WX_GEMM_CFG")) gemm_cfg = atoi(e);
     if (const char* e = getenv("WX_NO_LNFUSE")) fuse_ln = !(e[0] == '1');
+    if (const char* e = getenv("WX_NO_FFFUSE")) fuse_ff = !(e[0] == '1');
+    if (const char* e = getenv("WX_FF_VARIANT")) ff_variant = atoi(e);
+    if (const char* e = getenv("WX_FF_DBG")) ff_dbg = atoi(e);
     if (const char* e = getenv("WX_NO_PATCH")) use_patch = !(e[0] == '1');
     const int cmax = cfg.dim[3];
     gn_acc = (double*)dalloc(2 * cmax * sizeof(double));
@@ -897,6 +928,19 @@ class Engine : public EngineBase {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
     const int64_t ld = stream_ld(s);
+    if constexpr (sizeof(T) == 2) {
+      if (f.pack >= 0 && fuse_ff) {
+        FFParams fp;
+        fp.x = reinterpret_cast<const bf16_t*>(x); fp.ld = ld; fp.out = reinterpret_cast<bf16_t*>(x); fp.out_ld = ld;
+        fp.M = m; fp.hidden = 4 * c; fp.wpack = reinterpret_cast<const char*>(wt_dev + f.pack);
+        fp.cs1 = f_dev + f.w1.colsum; fp.b1 = f_dev + f.w1.bias; fp.b2 = f_dev + f.w2.bias;
+        fp.stat_out = fuse_ln ? statpart : nullptr; fp.dbg = ff_dbg;
+        timed("ff_fused", 16.0 * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] { launch_ff_fused(c, fp, zero_page, cur_stream, ff_variant); });
+        stat_tiles_ready = fuse_ln ? 1 : 0;
+        capture(dbg_name, x, h, w, c, ld, w);
+        return;
+      }
+    }
     const float2* rs = stream_stats(x, ld, c, m);
     gemm("gemm_ff1", f.w1, x, h, w, ld, 1, 0, 0, h, w, scratch, 4 * c, rs, 1, nullptr, 0);
     const bool st = gemm("gemm_ff2", f.w2, scratch, h, w, 4 * c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld, 0, 0, 0, 0, true);

@@ -1,0 +1,294 @@
+// Fused FeedForward block for the wide-and-shallow stages (C = 128 / 256), bf16 engine only:
+//
+//   x <- x + W2 . gelu( W1' . LN(x) + b1' ) + b2        credit/models/crossformer.py:195-207 (FeedForward) inside
+//                                                        the residual of Transformer.forward (:351-356)
+//
+// The unfused path writes the 4C-wide hidden to HBM and reads it back (stage 0: 2 x 328 MB per block, the GEMMs there
+// run at 250-350 TFLOP/s, memory- and epilogue-bound).  Here one wave keeps 16*PXF pixels in registers for the whole
+// block and walks the hidden dimension in chunks of 32:
+//
+//   GEMM1   h^T[32 hidden x px] = W1c . x^T      A = W1 chunk fragments from LDS, B = x fragments (registers, loaded once)
+//   LN fold + bias + GELU on the accumulators, rounded to bf16 -- the accumulator layout (4 consecutive hidden rows
+//           of one pixel per lane) IS an MFMA B-operand layout once W2's k-order is permuted to match, so the hidden
+//           never leaves the register file
+//   GEMM2   y^T[C x px] += W2c . h               A = W2 chunk fragments from LDS (host-permuted k order)
+//
+// and finally y + b2 + residual (the x registers again: their k-order is chosen so that the residual of accumulator
+// element (m, r) sits in the same lane) -> bf16 -> 8-byte stores, plus the per-pixel (sum, sum sq) the next LayerNorm
+// consumes.  LayerNorm statistics of x are computed in registers, two-pass (exactly the reference's formula).
+//
+// Weight traffic: one 128*C-byte chunk block per 32 hidden channels, staged by LDS-DMA into a 2-stage ring shared by
+// the workgroup's 4 waves; per chunk a wave issues 2*(C/32)*PXF + (C/16)*PXF MFMAs (64 for either configuration)
+// between two barriers -- 4x the work per barrier of the generic GEMM, and 3.3x (C=128) fewer staged bytes per FLOP.
+#pragma once
+#include "wx_common.h"
+#include "wx_gemm.h"
+
+namespace wx {
+
+struct FFParams {
+  const bf16_t* x;      // residual stream, token-major [M][ld]
+  int64_t ld;
+  bf16_t* out;          // may alias x (each workgroup reads its rows before it writes them)
+  int64_t out_ld;
+  int M;
+  int hidden;           // multiple of 32
+  const char* wpack;    // [hidden/32] chunk blocks of 128*C bytes: W1c (32 x C, slot-swizzled, k-permuted) | W2c (C x 32, k-permuted)
+  const float* cs1;     // [hidden] column sums of the rounded, gain-folded W1 rows
+  const float* b1;      // [hidden] folded bias
+  const float* b2;      // [C]
+  float2* stat_out;     // [M] (sum, sum sq) of the output rows, or nullptr
+  int dbg;              // unused
+};
+
+// k-slot permutation shared by x fragments, W1 and (through the accumulator layout) W2:
+// logical 16-byte slot (ks, g), element j  ->  channel 32*ks + (j < 4 ? 4*g + j : 16 + 4*g + j - 4)
+inline int ff_perm(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); }
+// physical 16-byte slot of logical slot g in row o of a W2 chunk (64-byte rows)
+inline int ff_w2_slot(int o, int g) { return (g + 2 * ((o & 15) >> 2)) & 3; }
+
+template <int C, int PXF, int OCC, int GP>
+__global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, const char* __restrict__ zero_page) {
+  constexpr int KS = C / 32;          // GEMM1 k steps
+  constexpr int MF = C / 16;          // GEMM2 output-channel fragments
+  constexpr int CB = 128 * C;         // chunk block bytes
+  constexpr int PXW = PXF * 16;       // pixels per wave
+  constexpr int DMA_I = CB / 4096;    // DMA instructions per wave per chunk
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int nch = p.hidden / 32;
+  float* s_par = reinterpret_cast<float*>(smem + 2 * CB);  // [hidden] cs1 | [hidden] b1
+
+  const int px0 = (blockIdx.x * 4 + wave) * PXW;
+
+  // ---- chunk 0 -> stage 0; parameters -> LDS ---------------------------------------------------
+  unsigned dst[DMA_I];
+#pragma unroll
+  for (int i = 0; i < DMA_I; ++i) dst[i] = lds_addr_sgpr(smem + (i * 4 + wave) * 1024);
+  const char* wsrc = p.wpack + wave * 1024 + lane * 16;
+  auto issue = [&](int ch, unsigned stage_off) {
+#pragma unroll
+    for (int i = 0; i < DMA_I; ++i) lds_dma16_s(wsrc + (int64_t)ch * CB + i * 4096, dst[i] + stage_off);
+  };
+  issue(0, 0u);
+  for (int i = tid; i < p.hidden; i += 256) {
+    s_par[i] = p.cs1[i];
+    s_par[p.hidden + i] = p.b1[i];
+  }
+
+  // ---- x fragments (B operand of GEMM1, residual of the epilogue) ---------------------------------
+  uint4 xb[KS][PXF];
+#pragma unroll
+  for (int f = 0; f < PXF; ++f) {
+    const int px = px0 + f * 16 + li;
+    const bool ok = px < p.M;
+    const bf16_t* row = p.x + (int64_t)(ok ? px : 0) * p.ld + 4 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+      if (ok) {
+        lo = *reinterpret_cast<const uint2*>(row + 32 * ks);
+        hi = *reinterpret_cast<const uint2*>(row + 32 * ks + 16);
+      }
+      xb[ks][f] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+  }
+  // ---- LayerNorm statistics, two-pass, in registers -----------------------------------------------
+  float mean[PXF], rstd[PXF];
+#pragma unroll
+  for (int f = 0; f < PXF; ++f) {
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float v[8];
+      unpack16<bf16_t>(xb[ks][f], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[e];
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float mu = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float v[8];
+      unpack16<bf16_t>(xb[ks][f], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q += (v[e] - mu) * (v[e] - mu);
+    }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    mean[f] = mu;
+    rstd[f] = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
+  }
+
+  f32x4_t y[MF][PXF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int f = 0; f < PXF; ++f) y[m][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  dma_wait_all();
+  __syncthreads();
+
+  const int w1_off = li * (2 * C);              // + mf*16*2C + ((ks*4+g) ^ li)*16
+  const int w2_off = 64 * C + li * 64 + ((g + 2 * (li >> 2)) & 3) * 16;  // + m*1024 (slot rotation: conflict-free b128 lane groups)
+  for (int ch = 0; ch < nch; ++ch) {
+    const char* cur = smem + (ch & 1) * CB;
+    if (ch + 1 < nch) issue(ch + 1, (unsigned)(((ch + 1) & 1) * CB));
+    // GEMM1, K steps in batches of 4: the 8 fragment reads of a batch are all in flight before its first MFMA.
+    // (`asm volatile("" ::: "memory")` pins only the LDS reads; MFMA / VALU remain free to interleave.  Left to
+    // itself hipcc reuses one register quad and serialises read -> wait -> 2 MFMAs.)
+    f32x4_t h[2][PXF];
+#pragma unroll
+    for (int f = 0; f < PXF; ++f) h[0][f] = h[1][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k0 = 0; k0 < KS; k0 += 4) {
+      uint4 a0[4], a1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int so = (((k0 + k) * 4 + g) ^ li) * 16;
+        a0[k] = *reinterpret_cast<const uint4*>(cur + w1_off + so);
+        a1[k] = *reinterpret_cast<const uint4*>(cur + w1_off + 16 * 2 * C + so);
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int f = 0; f < PXF; ++f) {
+          h[0][f] = mma_sub<bf16_t>(a0[k], xb[k0 + k][f], h[0][f]);
+          h[1][f] = mma_sub<bf16_t>(a1[k], xb[k0 + k][f], h[1][f]);
+        }
+    }
+    // first batch of W2 fragments + this chunk's parameters: their latency hides under the GELU arithmetic
+    uint4 a2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a2[m] = *reinterpret_cast<const uint4*>(cur + w2_off + m * 1024);
+    const float4 c0 = *reinterpret_cast<const float4*>(s_par + ch * 32 + 4 * g);
+    const float4 c1 = *reinterpret_cast<const float4*>(s_par + ch * 32 + 16 + 4 * g);
+    const float4 d0 = *reinterpret_cast<const float4*>(s_par + p.hidden + ch * 32 + 4 * g);
+    const float4 d1 = *reinterpret_cast<const float4*>(s_par + p.hidden + ch * 32 + 16 + 4 * g);
+    asm volatile("" ::: "memory");
+    // LayerNorm fold + bias + GELU -> bf16 B operand of GEMM2
+    uint4 hb[PXF];
+    {
+      f32x2_t v[PXF * 4];
+#pragma unroll
+      for (int f = 0; f < PXF; ++f) {
+        const float mu = mean[f], rs = rstd[f];
+        v[f * 4 + 0] = f32x2_t{rs * (h[0][f][0] - mu * c0.x) + d0.x, rs * (h[0][f][1] - mu * c0.y) + d0.y};
+        v[f * 4 + 1] = f32x2_t{rs * (h[0][f][2] - mu * c0.z) + d0.z, rs * (h[0][f][3] - mu * c0.w) + d0.w};
+        v[f * 4 + 2] = f32x2_t{rs * (h[1][f][0] - mu * c1.x) + d1.x, rs * (h[1][f][1] - mu * c1.y) + d1.y};
+        v[f * 4 + 3] = f32x2_t{rs * (h[1][f][2] - mu * c1.z) + d1.z, rs * (h[1][f][3] - mu * c1.w) + d1.w};
+      }
+#pragma unroll
+      for (int i = 0; i < PXF * 4; i += GP) gelu_fast_pairs<GP>(v + i);  // GP pairs in lock-step (ILP vs registers)
+#pragma unroll
+      for (int f = 0; f < PXF; ++f)
+        hb[f] = make_uint4(pack_bf16x2(v[f * 4].x, v[f * 4].y), pack_bf16x2(v[f * 4 + 1].x, v[f * 4 + 1].y),
+                           pack_bf16x2(v[f * 4 + 2].x, v[f * 4 + 2].y), pack_bf16x2(v[f * 4 + 3].x, v[f * 4 + 3].y));
+    }
+    // GEMM2, output fragments in batches of 4; the next batch is read while the current one multiplies
+#pragma unroll
+    for (int m0 = 0; m0 < MF; m0 += 4) {
+      uint4 an[4];
+      if (m0 + 4 < MF) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) an[m] = *reinterpret_cast<const uint4*>(cur + w2_off + (m0 + 4 + m) * 1024);
+        asm volatile("" ::: "memory");
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int f = 0; f < PXF; ++f) y[m0 + m][f] = mma_sub<bf16_t>(a2[m], hb[f], y[m0 + m][f]);
+      if (m0 + 4 < MF) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a2[m] = an[m];
+      }
+    }
+    dma_wait_all();
+    __syncthreads();
+  }
+
+  // ---- epilogue: + b2 + residual -> bf16, statistics, stores ----------------------------------------
+  // Pixel / pointer arithmetic is redone from an opaque copy of the thread id: otherwise hipcc keeps the prologue's
+  // values alive across the chunk loop, spills them, and every in-loop scratch reload waits on vmcnt -- i.e. on the
+  // weight DMA in flight.
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  const int li2 = tid2 & 15, g2 = (tid2 >> 4) & 3;
+  const int px0b = (blockIdx.x * 4 + (tid2 >> 6)) * PXW;
+#pragma unroll
+  for (int f = 0; f < PXF; ++f) {
+    const int px = px0b + f * 16 + li2;
+    const bool ok = px < p.M;
+    bf16_t* orow = p.out + (int64_t)(ok ? px : 0) * p.out_ld + 4 * g2;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const float4 bb = *reinterpret_cast<const float4*>(p.b2 + m * 16 + 4 * g2);
+      const uint4 xr = xb[m / 2][f];
+      const uint32_t r01 = (m & 1) ? xr.z : xr.x, r23 = (m & 1) ? xr.w : xr.y;
+      const float v0 = y[m][f][0] + bb.x + __builtin_bit_cast(float, r01 << 16);
+      const float v1 = y[m][f][1] + bb.y + __builtin_bit_cast(float, r01 & 0xffff0000u);
+      const float v2 = y[m][f][2] + bb.z + __builtin_bit_cast(float, r23 << 16);
+      const float v3 = y[m][f][3] + bb.w + __builtin_bit_cast(float, r23 & 0xffff0000u);
+      uint2 o;
+      o.x = pack_bf16x2(v0, v1);
+      o.y = pack_bf16x2(v2, v3);
+      if (p.stat_out) {  // from the ROUNDED values, like the GEMM epilogue
+        const float q0 = __builtin_bit_cast(float, o.x << 16), q1 = __builtin_bit_cast(float, o.x & 0xffff0000u);
+        const float q2 = __builtin_bit_cast(float, o.y << 16), q3 = __builtin_bit_cast(float, o.y & 0xffff0000u);
+        s1 += (q0 + q1) + (q2 + q3);
+        s2 += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+      }
+      if (ok) *reinterpret_cast<uint2*>(orow + m * 16) = o;
+    }
+    if (p.stat_out) {
+      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      if (ok && g2 == 0) p.stat_out[px] = make_float2(s1, s2);
+    }
+  }
+}
+
+template <int C, int PXF, int OCC, int GP>
+inline void launch_ff_fused_v(const FFParams& p, const void* zero_page, hipStream_t stream) {
+  const int LDS = 2 * 128 * C + 8 * p.hidden;
+  auto kern = ff_fused_kernel<C, PXF, OCC, GP>;
+  static int attr_lds = 0;
+  if (LDS > attr_lds) {
+    WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_lds = LDS;
+  }
+  const int tile = 4 * PXF * 16;
+  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(p.M, tile)), dim3(256), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
+  WX_HIP(hipGetLastError());
+}
+
+inline bool ff_fused_supported(int c, int hidden) { return (c == 128 || c == 256) && hidden % 32 == 0 && hidden <= 2048; }
+
+// Register allocation decides these kernels: any scratch reload inside the chunk loop waits on vmcnt, i.e. on the weight
+// DMA in flight.  Measured on C3 (4 launches / stage, MI355X): C=128: <2 px-frags, 2 waves/SIMD, 4 GELU pairs> 0.549 ms
+// (0 B scratch) vs <2, 3 waves/SIMD> 0.618-0.636 ms (232-248 B) vs unfused FF1+FF2 1.08 ms; C=256: <1, 2/SIMD, 4> 0.514 ms
+// (0 B) vs <2, 2/SIMD> 0.71 ms (512 B) vs unfused 0.63 ms.
+inline void launch_ff_fused(int c, const FFParams& p, const void* zero_page, hipStream_t stream, int variant = 0) {
+  if (c == 128) {
+    switch (variant) {
+      case 1: launch_ff_fused_v<128, 2, 2, 8>(p, zero_page, stream); break;
+      case 2: launch_ff_fused_v<128, 2, 3, 2>(p, zero_page, stream); break;
+      default: launch_ff_fused_v<128, 2, 2, 4>(p, zero_page, stream); break;
+    }
+  } else if (c == 256) {
+    switch (variant) {
+      case 1: launch_ff_fused_v<256, 1, 3, 2>(p, zero_page, stream); break;
+      case 2: launch_ff_fused_v<256, 2, 2, 2>(p, zero_page, stream); break;
+      default: launch_ff_fused_v<256, 1, 2, 4>(p, zero_page, stream); break;
+    }
+  } else {
+    throw std::runtime_error("ff_fused: unsupported width");
+  }
+}
+
+}  // namespace wx
