@@ -25,10 +25,17 @@ struct AttnParams {
   int64_t ld_out;
   const float* bias;  // [NP][NP] fp32, NP = 16*NKF; padded keys hold -1e30
   int H, W, C, heads, wsz, kind;  // kind 0 short, 1 long
-  float scale;
+  float scale;                    // bf16 engine: scale * log2(e), and the bias table is pre-multiplied by log2(e)
+  int pack;                       // windows per 16-token tile (1, or 16 / wsz^2 for the 2x2 windows of the long
+                                  // attention at stage 2: four windows share one MFMA tile, the bias table is
+                                  // block-diagonal with -1e30 between windows)
 };
 
-template <typename T, int NKF>
+// SPLIT = false: one wave per (window tile, head), four independent tasks per workgroup.
+// SPLIT = true : the workgroup's four waves share one task -- V^T is staged once by all 256 threads and the query
+//                blocks are dealt round-robin to the waves.  Same work, a quarter of the per-task latency: the
+//                stage-2/3 launches have only 3-6 tasks per SIMD and were bound by the length of one task.
+template <typename T, int NKF, bool SPLIT>
 __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
   constexpr int D = 32;
   constexpr int NP = NKF * 16;
@@ -41,17 +48,27 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int N = p.wsz * p.wsz;
+  const int NW1 = p.wsz * p.wsz;        // tokens per window
+  const int N = NW1 * p.pack;           // tokens per tile
   const int wins_x = p.W / p.wsz, wins_y = p.H / p.wsz;
-  const int64_t task = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t n_tasks = (int64_t)wins_x * wins_y * p.heads;
+  const int n_win = wins_x * wins_y;
+  const int64_t task = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;
+  const int64_t n_tasks = (int64_t)((n_win + p.pack - 1) / p.pack) * p.heads;
   const bool active = task < n_tasks;
   const int head = active ? (int)(task % p.heads) : 0;
-  const int win = active ? (int)(task / p.heads) : 0;
-  const int wy = win / wins_x, wx_ = win - wy * wins_x;
+  const int win0 = active ? (int)(task / p.heads) * p.pack : 0;
 
+  // token t of the tile -> pixel index, or -1 when its window lies beyond the last one (packed tiles only)
   auto token_pixel = [&](int t) -> int64_t {
-    const int ty = t / p.wsz, tx = t - ty * p.wsz;
+    int w = win0, tl = t;
+    if (p.pack > 1) {
+      const int sub = t / NW1;
+      w += sub;
+      tl = t - sub * NW1;
+      if (w >= n_win) return -1;
+    }
+    const int wy = w / wins_x, wx_ = w - wy * wins_x;
+    const int ty = tl / p.wsz, tx = tl - ty * p.wsz;
     int py, px;
     if (p.kind == 0) {
       py = wy * p.wsz + ty;
@@ -64,16 +81,17 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
   };
 
   const T* __restrict__ qkv = reinterpret_cast<const T*>(p.qkv);
-  T* vt = reinterpret_cast<T*>(smem + wave * VT_BYTES);
+  T* vt = reinterpret_cast<T*>(smem + (SPLIT ? 0 : wave) * VT_BYTES);
 
   // ---- V^T into this wave's LDS slice (zero-filled beyond N) -------------------------------
   {
     constexpr int PIECES = D / VEC;  // 16-byte pieces per token row
     constexpr int COLS_FILL = (sizeof(T) == 2) ? NKB * 32 : NP;
-    for (int idx = lane; idx < COLS_FILL * PIECES; idx += 64) {
+    for (int idx = SPLIT ? (int)threadIdx.x : lane; idx < COLS_FILL * PIECES; idx += SPLIT ? 256 : 64) {
       const int t = idx % COLS_FILL, piece = idx / COLS_FILL;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (active && t < N) v = *reinterpret_cast<const uint4*>(qkv + token_pixel(t) * p.ld_qkv + 2 * p.C + head * D + piece * VEC);
+      const int64_t tp = (active && t < N) ? token_pixel(t) : -1;
+      if (tp >= 0) v = *reinterpret_cast<const uint4*>(qkv + tp * p.ld_qkv + 2 * p.C + head * D + piece * VEC);
       const T* e = reinterpret_cast<const T*>(&v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) vt[(piece * VEC + i) * VT_COLS + t] = e[i];
@@ -82,16 +100,22 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
   __syncthreads();
   if (!active) return;
 
+  // pixel of token j*16 + li (key rows of fragment j == query rows of query block j): computed once, the window
+  // decomposition costs two integer divisions per token
+  int tokpix[NKF];
+#pragma unroll
+  for (int j = 0; j < NKF; ++j) tokpix[j] = (j * 16 + li < N) ? (int)token_pixel(j * 16 + li) : -1;
+
   // ---- K fragments (A operand of S^T) and V^T fragments (A operand of O^T) ------------------
   uint4 kf[NKF][QK_SUBS];
 #pragma unroll
   for (int j = 0; j < NKF; ++j) {
-    const int key = j * 16 + li;
 #pragma unroll
     for (int s = 0; s < QK_SUBS; ++s) {
       kf[j][s] = make_uint4(0u, 0u, 0u, 0u);
-      if (key < N)
-        kf[j][s] = *reinterpret_cast<const uint4*>(qkv + token_pixel(key) * p.ld_qkv + p.C + head * D + (s * 64 + g * 16) / (int)sizeof(T));
+      const int64_t kp = tokpix[j];
+      if (kp >= 0)
+        kf[j][s] = *reinterpret_cast<const uint4*>(qkv + kp * p.ld_qkv + p.C + head * D + (s * 64 + g * 16) / (int)sizeof(T));
     }
   }
   constexpr int NVF = (sizeof(T) == 2) ? NKB : NKF;
@@ -113,10 +137,14 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
 
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
   const int nqb = (N + 15) / 16;
-  for (int qb = 0; qb < nqb; ++qb) {
+  for (int qb = SPLIT ? wave : 0; qb < nqb; qb += SPLIT ? 4 : 1) {
     const int query = qb * 16 + li;
-    const bool qok = query < N;
-    const int64_t qpix = qok ? token_pixel(query) : 0;
+    int qp = -1;
+#pragma unroll
+    for (int j = 0; j < NKF; ++j) qp = (j == qb) ? tokpix[j] : qp;  // constant indices only (no scratch)
+    const int64_t qpix_ = qp;
+    const bool qok = qpix_ >= 0;
+    const int64_t qpix = qok ? qpix_ : 0;
     uint4 qf[QK_SUBS];
 #pragma unroll
     for (int s = 0; s < QK_SUBS; ++s) {
@@ -149,7 +177,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
       for (int r = 0; r < 4; ++r) {
         // bf16 mode: probabilities are rounded to bf16 for the PV MFMA anyway -> one v_exp_f32 (2^x) instead of
         // libm's ~12-instruction expf; fp32 mode keeps the exact path
-        if constexpr (sizeof(T) == 2) sv[j][r] = __builtin_amdgcn_exp2f((sv[j][r] - mx) * 1.44269504088896341f);
+        if constexpr (sizeof(T) == 2) sv[j][r] = __builtin_amdgcn_exp2f(sv[j][r] - mx);  // log2(e) folded into scale / bias
         else sv[j][r] = expf(sv[j][r] - mx);
         sum += sv[j][r];
       }
@@ -169,10 +197,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
           hi[r] = (2 * b + 1 < NKF) ? sv[(2 * b + 1 < NKF) ? 2 * b + 1 : 0][r] : 0.f;
         }
         uint4 pf;
-        pf.x = (uint32_t)f2bf(lo[0]) | ((uint32_t)f2bf(lo[1]) << 16);
-        pf.y = (uint32_t)f2bf(lo[2]) | ((uint32_t)f2bf(lo[3]) << 16);
-        pf.z = (uint32_t)f2bf(hi[0]) | ((uint32_t)f2bf(hi[1]) << 16);
-        pf.w = (uint32_t)f2bf(hi[2]) | ((uint32_t)f2bf(hi[3]) << 16);
+        pf.x = pack_bf16x2(lo[0], lo[1]);
+        pf.y = pack_bf16x2(lo[2], lo[3]);
+        pf.z = pack_bf16x2(hi[0], hi[1]);
+        pf.w = pack_bf16x2(hi[2], hi[3]);
 #pragma unroll
         for (int df = 0; df < 2; ++df) oacc[df] = mma_sub<T>(vf[df][b], pf, oacc[df]);
       }
@@ -201,24 +229,25 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
   }
 }
 
-template <typename T, int NKF>
+template <typename T, int NKF, bool SPLIT>
 inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
   constexpr int NKB = (NKF + 1) / 2;
   constexpr int VT_COLS = (sizeof(T) == 2) ? (NKB * 32 + 8) : (NKF * 16 + 4);
-  constexpr int LDS = 4 * 32 * VT_COLS * (int)sizeof(T);
-  auto kern = window_attn_kernel<T, NKF>;
+  constexpr int LDS = (SPLIT ? 1 : 4) * 32 * VT_COLS * (int)sizeof(T);
+  auto kern = window_attn_kernel<T, NKF, SPLIT>;
   static bool attr_done = false;
   if (!attr_done) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
-  const int64_t tasks = (int64_t)(p.H / p.wsz) * (p.W / p.wsz) * p.heads;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((tasks + 3) / 4)), dim3(256), LDS, stream, p);
+  const int n_win = (p.H / p.wsz) * (p.W / p.wsz);
+  const int64_t tasks = (int64_t)((n_win + p.pack - 1) / p.pack) * p.heads;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(SPLIT ? tasks : (tasks + 3) / 4)), dim3(256), LDS, stream, p);
   WX_HIP(hipGetLastError());
 }
 
-inline int attn_nkf(int wsz) {
-  const int n = wsz * wsz;
+// tokens per window tile -> key fragments
+inline int attn_nkf_tokens(int n) {
   if (n <= 16) return 1;
   if (n <= 32) return 2;
   if (n <= 64) return 4;
@@ -226,15 +255,23 @@ inline int attn_nkf(int wsz) {
   if (n <= 128) return 8;
   return -1;
 }
+inline int attn_pack(int wsz) { const int n = wsz * wsz; return n <= 8 ? 16 / n : 1; }
+inline int attn_nkf(int wsz) { return attn_nkf_tokens(wsz * wsz * attn_pack(wsz)); }
 
 template <typename T>
-inline void launch_window_attn(const AttnParams& p, hipStream_t stream) {
-  switch (attn_nkf(p.wsz)) {
-    case 1: launch_window_attn_n<T, 1>(p, stream); break;
-    case 2: launch_window_attn_n<T, 2>(p, stream); break;
-    case 4: launch_window_attn_n<T, 4>(p, stream); break;
-    case 7: launch_window_attn_n<T, 7>(p, stream); break;
-    case 8: launch_window_attn_n<T, 8>(p, stream); break;
+inline void launch_window_attn(const AttnParams& p, hipStream_t stream, int split_mode = 0) {
+  // split_mode: 0 = automatic (split when the launch has fewer than ~8 tasks per SIMD), 1 = never, 2 = always (>= 4 key fragments)
+  const int n_win = (p.H / p.wsz) * (p.W / p.wsz);
+  const int64_t tasks = (int64_t)((n_win + p.pack - 1) / p.pack) * p.heads;
+  const int nkf = attn_nkf_tokens(p.wsz * p.wsz * p.pack);
+  const bool split = nkf >= 4 && split_mode == 2;  // measured slower on every C3 launch (0.535 vs 0.471 ms at stage 2): experiment only
+  (void)tasks;
+  switch (nkf) {
+    case 1: launch_window_attn_n<T, 1, false>(p, stream); break;
+    case 2: launch_window_attn_n<T, 2, false>(p, stream); break;
+    case 4: if (split) launch_window_attn_n<T, 4, true>(p, stream); else launch_window_attn_n<T, 4, false>(p, stream); break;
+    case 7: if (split) launch_window_attn_n<T, 7, true>(p, stream); else launch_window_attn_n<T, 7, false>(p, stream); break;
+    case 8: if (split) launch_window_attn_n<T, 8, true>(p, stream); else launch_window_attn_n<T, 8, false>(p, stream); break;
     default: throw std::runtime_error("window attention supports at most 128 tokens per window (wsz <= 11)");
   }
 }

@@ -487,16 +487,21 @@ class Engine : public EngineBase {
         for (int j = 0; j < dq; ++j) s += w9[j] * h[j];
         table[a * side + b] = s;
       }
-    const int N = wsz * wsz, NP = attn_nkf(wsz) * 16;
+    // [NP][NP] table the kernel adds to the scores: padded keys (and, for packed tiles, keys of another window) get
+    // -1e30; the bf16 engine exponentiates with v_exp_f32 (2^x), so its table carries the log2(e) factor
+    const int N1 = wsz * wsz, G = attn_pack(wsz), N = N1 * G, NP = attn_nkf(wsz) * 16;
+    const double pre = sizeof(T) == 2 ? 1.4426950408889634 : 1.0;
     std::vector<float> padded((size_t)NP * NP, 0.f);
     for (int i = 0; i < NP; ++i)
       for (int j = 0; j < NP; ++j) {
         float v;
         if (j >= N) v = -1.0e30f;
         else if (i >= N) v = 0.f;
+        else if (i / N1 != j / N1) v = -1.0e30f;
         else {
-          const int dr = i / wsz - j / wsz + wsz - 1, dc = i % wsz - j % wsz + wsz - 1;
-          v = (float)table[dr * (2 * wsz - 1) + dc];
+          const int il = i % N1, jl = j % N1;
+          const int dr = il / wsz - jl / wsz + wsz - 1, dc = il % wsz - jl % wsz + wsz - 1;
+          v = (float)(pre * table[dr * (2 * wsz - 1) + dc]);
         }
         padded[(size_t)i * NP + j] = v;
       }
@@ -651,7 +656,7 @@ class Engine : public EngineBase {
   int gemm_cfg = 0;
   bool fuse_ln = true;
   bool fuse_ff = true;          // stages with C in {128, 256}: FeedForward as one kernel (wx_ff.h), bf16 engine
-  int ff_variant = 0, ff_dbg = 0;
+  int ff_variant = 0, ff_dbg = 0, attn_split = 0;
   float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
   int stat_tiles_ready = 0;     // > 0: `statpart` holds partials of the current stream contents (that many per row)
@@ -697,6 +702,7 @@ class Engine : public EngineBase {
     if (const char* e = getenv("WX_NO_FFFUSE")) fuse_ff = !(e[0] == '1');
     if (const char* e = getenv("WX_FF_VARIANT")) ff_variant = atoi(e);
     if (const char* e = getenv("WX_FF_DBG")) ff_dbg = atoi(e);
+    if (const char* e = getenv("WX_ATTN_SPLIT")) attn_split = atoi(e);
     if (const char* e = getenv("WX_NO_PATCH")) use_patch = !(e[0] == '1');
     const int cmax = cfg.dim[3];
     gn_acc = (double*)dalloc(2 * cmax * sizeof(double));
@@ -914,9 +920,10 @@ class Engine : public EngineBase {
       AttnParams p;
       p.qkv = scratch; p.ld_qkv = 3 * c; p.out = attn_o; p.ld_out = c; p.bias = f_dev + a.bias_tab;
       p.H = h; p.W = w; p.C = c; p.heads = c / 32; p.wsz = a.wsz; p.kind = a.kind;
-      p.scale = 1.0f / std::sqrt(32.0f);
+      p.scale = (float)((sizeof(T) == 2 ? 1.4426950408889634 : 1.0) / std::sqrt(32.0));
+      p.pack = attn_pack(a.wsz);
       const double n = (double)a.wsz * a.wsz;
-      timed("window_attn", 4.0 * m * n * c, 4.0 * m * c * sizeof(T), [&] { launch_window_attn<T>(p, cur_stream); });
+      timed("window_attn", 4.0 * m * n * c, 4.0 * m * c * sizeof(T), [&] { launch_window_attn<T>(p, cur_stream, attn_split); });
       capture(dbg_name + ".qkv", scratch, h, w, 3 * c, 3 * c, w);
     }
     capture(dbg_name + ".attn", attn_o, h, w, c, c, w);
