@@ -46,7 +46,7 @@ struct ConvW {          // one repacked GEMM operand in the weight arena
   int cin_true = 0;     // unpadded channels (flop accounting)
 };
 struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1; int wsz = 0, kind = 0; };
-struct FFL { ConvW w1, w2; int64_t pack = -1; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset
+struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset; pack_pre: the same preceded by the attention's Wout blocks
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
 struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmbed branch (wx_embed.h)
 struct StageL { std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks; };
@@ -522,14 +522,19 @@ class Engine : public EngineBase {
     return a;
   }
   // chunk blocks for ff_fused_kernel, built from the ROUNDED arena weights of w1 / w2 (same values as the unfused path)
-  int64_t pack_ff(const FFL& f, int c, int hidden) {
+  int64_t pack_ff(const FFL& f, int c, int hidden, const ConvW* wout = nullptr) {
     while (wt_host.size() % 8) wt_host.push_back(Elem<T>::from_f(0.f));
     const int64_t off = (int64_t)wt_host.size();
-    const int nch = hidden / 32;
+    const int nch = hidden / 32, npre = wout ? c / 64 : 0;
     const int64_t cb = 64 * (int64_t)c;  // elements per chunk block (128*C bytes of bf16)
-    wt_host.resize(off + nch * cb);
+    wt_host.resize(off + (npre + nch) * cb);
+    for (int i = 0; i < npre; ++i)       // Wout rows [64 i, 64 i + 64), natural k order, 16-byte slots XOR-swizzled by row
+      for (int r = 0; r < 64; ++r)
+        for (int sl = 0; sl < c / 8; ++sl)
+          for (int j = 0; j < 8; ++j)
+            wt_host[off + i * cb + (int64_t)r * c + (sl ^ (r & 15)) * 8 + j] = wt_host[wout->wt + (int64_t)(i * 64 + r) * c + sl * 8 + j];
     for (int ch = 0; ch < nch; ++ch) {
-      const int64_t base = off + ch * cb;
+      const int64_t base = off + (npre + ch) * cb;
       for (int r = 0; r < 32; ++r)
         for (int sl = 0; sl < c / 8; ++sl) {
           const int ks = sl / 4, g = sl % 4, phys = sl ^ (r & 15);
@@ -543,13 +548,16 @@ class Engine : public EngineBase {
     }
     return off;
   }
-  FFL make_ff(const std::string& p, int c) {
+  FFL make_ff(const std::string& p, int c, const AttnL* prev = nullptr) {
     FFL f;
     const HostTensor &g = need(p + ".layers.0.g"), &b = need(p + ".layers.0.b");
     f.w1 = make_conv(p + ".layers.1", 0, 4 * c, c, c, 1, 1, true, g.data.data(), b.data.data());
     f.w2 = make_conv(p + ".layers.4", 0, c, 4 * c, 4 * c, 1, 1, true, nullptr, nullptr);
     if constexpr (sizeof(T) == 2) {
-      if (ff_fused_supported(c, 4 * c)) f.pack = pack_ff(f, c, 4 * c);
+      if (ff_fused_supported(c, 4 * c)) {
+        f.pack = pack_ff(f, c, 4 * c);
+        if (prev) f.pack_pre = pack_ff(f, c, 4 * c, &prev->out);
+      }
     }
     return f;
   }
@@ -580,9 +588,9 @@ class Engine : public EngineBase {
         const std::string p = "layers." + std::to_string(s) + ".1.layers." + std::to_string(d);
         BlockL bl;
         bl.sa = make_attn(p + ".0", cout, cfg.local_window_size[s], 0);
-        bl.sf = make_ff(p + ".1", cout);
+        bl.sf = make_ff(p + ".1", cout, &bl.sa);
         bl.la = make_attn(p + ".2", cout, cfg.global_window_size[s], 1);
-        bl.lf = make_ff(p + ".3", cout);
+        bl.lf = make_ff(p + ".3", cout, &bl.la);
         st.blocks.push_back(bl);
       }
       stages[s] = std::move(st);
@@ -655,7 +663,7 @@ class Engine : public EngineBase {
   int dbg_flags = 0;
   int gemm_cfg = 0;
   bool fuse_ln = true;
-  bool fuse_ff = true;          // stages with C in {128, 256}: FeedForward as one kernel (wx_ff.h), bf16 engine
+  bool fuse_ff = true, fuse_out = true;          // stages with C in {128, 256}: FeedForward as one kernel (wx_ff.h), bf16 engine
   int ff_variant = 0, ff_dbg = 0, attn_split = 0;
   float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
@@ -700,6 +708,7 @@ class Engine : public EngineBase {
     if (const char* e = getenv("WX_GEMM_CFG")) gemm_cfg = atoi(e);
     if (const char* e = getenv("WX_NO_LNFUSE")) fuse_ln = !(e[0] == '1');
     if (const char* e = getenv("WX_NO_FFFUSE")) fuse_ff = !(e[0] == '1');
+    if (const char* e = getenv("WX_NO_OUTFUSE")) fuse_out = !(e[0] == '1');
     if (const char* e = getenv("WX_FF_VARIANT")) ff_variant = atoi(e);
     if (const char* e = getenv("WX_FF_DBG")) ff_dbg = atoi(e);
     if (const char* e = getenv("WX_ATTN_SPLIT")) attn_split = atoi(e);
@@ -908,7 +917,8 @@ class Engine : public EngineBase {
     ln_stats(x, ld, c, m);
     return rowstat;
   }
-  void attention(const AttnL& a, int s, const std::string& dbg_name) {
+  // defer_out: leave the attention output in attn_o; the fused feed-forward kernel applies to_out + residual itself
+  void attention(const AttnL& a, int s, const std::string& dbg_name, bool defer_out = false) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
     const int64_t ld = stream_ld(s);
@@ -927,11 +937,13 @@ class Engine : public EngineBase {
       capture(dbg_name + ".qkv", scratch, h, w, 3 * c, 3 * c, w);
     }
     capture(dbg_name + ".attn", attn_o, h, w, c, c, w);
+    if (defer_out) return;
     const bool st = gemm("gemm_out", a.out, attn_o, h, w, c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld, 0, 0, 0, 0, true);
     stat_tiles_ready = st ? conv_gemm_n_tiles(c) : 0;
     capture(dbg_name, x, h, w, c, ld, w);
   }
-  void feedforward(const FFL& f, int s, const std::string& dbg_name) {
+  bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on; }
+  void feedforward(const FFL& f, int s, const std::string& dbg_name, const AttnL* pre = nullptr) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
     const int64_t ld = stream_ld(s);
@@ -939,10 +951,11 @@ class Engine : public EngineBase {
       if (f.pack >= 0 && fuse_ff) {
         FFParams fp;
         fp.x = reinterpret_cast<const bf16_t*>(x); fp.ld = ld; fp.out = reinterpret_cast<bf16_t*>(x); fp.out_ld = ld;
-        fp.M = m; fp.hidden = 4 * c; fp.wpack = reinterpret_cast<const char*>(wt_dev + f.pack);
+        fp.M = m; fp.hidden = 4 * c; fp.wpack = reinterpret_cast<const char*>(wt_dev + (pre ? f.pack_pre : f.pack));
+        fp.o = pre ? reinterpret_cast<const bf16_t*>(attn_o) : nullptr; fp.ld_o = c; fp.bo = pre ? f_dev + pre->out.bias : nullptr;
         fp.cs1 = f_dev + f.w1.colsum; fp.b1 = f_dev + f.w1.bias; fp.b2 = f_dev + f.w2.bias;
         fp.stat_out = fuse_ln ? statpart : nullptr; fp.dbg = ff_dbg;
-        timed("ff_fused", 16.0 * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] { launch_ff_fused(c, fp, zero_page, cur_stream, ff_variant); });
+        timed(pre ? "out_ff_fused" : "ff_fused", (pre ? 18.0 : 16.0) * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] { launch_ff_fused(c, fp, zero_page, cur_stream, ff_variant); });
         stat_tiles_ready = fuse_ln ? 1 : 0;
         capture(dbg_name, x, h, w, c, ld, w);
         return;
@@ -1042,10 +1055,12 @@ class Engine : public EngineBase {
       capture(sp + ".0", x, sh[s], sw[s], cfg.dim[s], ld, sw[s]);
       for (size_t d = 0; d < st.blocks.size(); ++d) {
         const std::string bp = sp + ".1.layers." + std::to_string(d);
-        attention(st.blocks[d].sa, s, bp + ".0");
-        feedforward(st.blocks[d].sf, s, bp + ".1");
-        attention(st.blocks[d].la, s, bp + ".2");
-        feedforward(st.blocks[d].lf, s, bp + ".3");
+        const BlockL& bl = st.blocks[d];
+        const bool ds = ff_takes_out(bl.sf), dl = ff_takes_out(bl.lf);
+        attention(bl.sa, s, bp + ".0", ds);
+        feedforward(bl.sf, s, bp + ".1", ds ? &bl.sa : nullptr);
+        attention(bl.la, s, bp + ".2", dl);
+        feedforward(bl.lf, s, bp + ".3", dl ? &bl.la : nullptr);
       }
       capture(sp + ".1", x, sh[s], sw[s], cfg.dim[s], ld, sw[s]);
     }

@@ -39,6 +39,11 @@ struct FFParams {
   const float* b2;      // [C]
   float2* stat_out;     // [M] (sum, sum sq) of the output rows, or nullptr
   int dbg;              // unused
+  // PRE variant (attention out-projection fused in front): x1 = x + Wout . o + bo replaces x before the block above.
+  // wpack then starts with C/64 blocks of 128*C bytes holding Wout rows [64 i, 64 i + 64) (natural k order, slot-swizzled).
+  const bf16_t* o;      // attention output [M][ld_o]
+  int64_t ld_o;
+  const float* bo;      // [C]
 };
 
 // k-slot permutation shared by x fragments, W1 and (through the accumulator layout) W2:
@@ -47,7 +52,7 @@ inline int ff_perm(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 
 // physical 16-byte slot of logical slot g in row o of a W2 chunk (64-byte rows)
 inline int ff_w2_slot(int o, int g) { return (g + 2 * ((o & 15) >> 2)) & 3; }
 
-template <int C, int PXF, int OCC, int GP>
+template <int C, int PXF, int OCC, int GP, bool PRE>
 __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, const char* __restrict__ zero_page) {
   constexpr int KS = C / 32;          // GEMM1 k steps
   constexpr int MF = C / 16;          // GEMM2 output-channel fragments
@@ -94,6 +99,66 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
       xb[ks][f] = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
   }
+  f32x4_t y[MF][PXF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int f = 0; f < PXF; ++f) y[m][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int w1_off = li * (2 * C);              // + mf*16*2C + ((ks*4+g) ^ li)*16
+  const int w2_off = 64 * C + li * 64 + ((g + 2 * (li >> 2)) & 3) * 16;  // + m*1024 (slot rotation: conflict-free b128 lane groups)
+
+  constexpr int NPRE = PRE ? C / 64 : 0;  // out-projection blocks ahead of the feed-forward chunks in the ring
+  // ---- x1 = x + Wout . o + bo (crossformer.py:314-316 to_out + the attention residual :352), kept in registers ----
+  uint4 ob[PRE ? KS : 1][PXF];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int f = 0; f < PXF; ++f) {
+      const int px = px0 + f * 16 + li;
+      const bool ok = px < p.M;
+      const bf16_t* row = p.o + (int64_t)(ok ? px : 0) * p.ld_o + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) ob[ks][f] = ok ? *reinterpret_cast<const uint4*>(row + 32 * ks) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  dma_wait_all();
+  __syncthreads();
+  if constexpr (PRE) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const char* cur = smem + (i & 1) * CB;
+      issue(i + 1, (unsigned)(((i + 1) & 1) * CB));  // the first feed-forward chunk follows the last block
+#pragma unroll
+      for (int ml = 0; ml < 4; ++ml) {
+        uint4 a[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const uint4*>(cur + w1_off + ml * 16 * 2 * C + (((ks * 4 + g) ^ li) * 16));
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int f = 0; f < PXF; ++f) y[i * 4 + ml][f] = mma_sub<bf16_t>(a[ks], ob[ks][f], y[i * 4 + ml][f]);
+      }
+      dma_wait_all();
+      __syncthreads();
+    }
+    // x1 -> bf16, into the x registers (accumulator layout == the permuted-k B layout); y back to zero
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const float4 bb = *reinterpret_cast<const float4*>(p.bo + m * 16 + 4 * g);
+#pragma unroll
+      for (int f = 0; f < PXF; ++f) {
+        uint4& xr = xb[m / 2][f];
+        const uint32_t r01 = (m & 1) ? xr.z : xr.x, r23 = (m & 1) ? xr.w : xr.y;
+        const uint32_t n01 = pack_bf16x2(y[m][f][0] + bb.x + __builtin_bit_cast(float, r01 << 16),
+                                         y[m][f][1] + bb.y + __builtin_bit_cast(float, r01 & 0xffff0000u));
+        const uint32_t n23 = pack_bf16x2(y[m][f][2] + bb.z + __builtin_bit_cast(float, r23 << 16),
+                                         y[m][f][3] + bb.w + __builtin_bit_cast(float, r23 & 0xffff0000u));
+        if (m & 1) { xr.z = n01; xr.w = n23; } else { xr.x = n01; xr.y = n23; }
+        y[m][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
   // ---- LayerNorm statistics, two-pass, in registers -----------------------------------------------
   float mean[PXF], rstd[PXF];
 #pragma unroll
@@ -123,20 +188,9 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
     rstd[f] = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
   }
 
-  f32x4_t y[MF][PXF];
-#pragma unroll
-  for (int m = 0; m < MF; ++m)
-#pragma unroll
-    for (int f = 0; f < PXF; ++f) y[m][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  dma_wait_all();
-  __syncthreads();
-
-  const int w1_off = li * (2 * C);              // + mf*16*2C + ((ks*4+g) ^ li)*16
-  const int w2_off = 64 * C + li * 64 + ((g + 2 * (li >> 2)) & 3) * 16;  // + m*1024 (slot rotation: conflict-free b128 lane groups)
-  for (int ch = 0; ch < nch; ++ch) {
+  for (int ch = 0; ch < nch; ++ch) {  // NPRE is even: the ring parity of chunk ch is ch & 1 either way
     const char* cur = smem + (ch & 1) * CB;
-    if (ch + 1 < nch) issue(ch + 1, (unsigned)(((ch + 1) & 1) * CB));
+    if (ch + 1 < nch) issue(NPRE + ch + 1, (unsigned)(((ch + 1) & 1) * CB));
     // GEMM1, K steps in batches of 4: the 8 fragment reads of a batch are all in flight before its first MFMA.
     // (`asm volatile("" ::: "memory")` pins only the LDS reads; MFMA / VALU remain free to interleave.  Left to
     // itself hipcc reuses one register quad and serialises read -> wait -> 2 MFMAs.)
@@ -253,10 +307,10 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   }
 }
 
-template <int C, int PXF, int OCC, int GP>
+template <int C, int PXF, int OCC, int GP, bool PRE>
 inline void launch_ff_fused_v(const FFParams& p, const void* zero_page, hipStream_t stream) {
   const int LDS = 2 * 128 * C + 8 * p.hidden;
-  auto kern = ff_fused_kernel<C, PXF, OCC, GP>;
+  auto kern = ff_fused_kernel<C, PXF, OCC, GP, PRE>;
   static int attr_lds = 0;
   if (LDS > attr_lds) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -274,17 +328,20 @@ inline bool ff_fused_supported(int c, int hidden) { return (c == 128 || c == 256
 // (0 B scratch) vs <2, 3 waves/SIMD> 0.618-0.636 ms (232-248 B) vs unfused FF1+FF2 1.08 ms; C=256: <1, 2/SIMD, 4> 0.514 ms
 // (0 B) vs <2, 2/SIMD> 0.71 ms (512 B) vs unfused 0.63 ms.
 inline void launch_ff_fused(int c, const FFParams& p, const void* zero_page, hipStream_t stream, int variant = 0) {
+  const bool pre = p.o != nullptr;
   if (c == 128) {
+    if (pre) { launch_ff_fused_v<128, 2, 2, 4, true>(p, zero_page, stream); return; }
     switch (variant) {
-      case 1: launch_ff_fused_v<128, 2, 2, 8>(p, zero_page, stream); break;
-      case 2: launch_ff_fused_v<128, 2, 3, 2>(p, zero_page, stream); break;
-      default: launch_ff_fused_v<128, 2, 2, 4>(p, zero_page, stream); break;
+      case 1: launch_ff_fused_v<128, 2, 2, 8, false>(p, zero_page, stream); break;
+      case 2: launch_ff_fused_v<128, 2, 3, 2, false>(p, zero_page, stream); break;
+      default: launch_ff_fused_v<128, 2, 2, 4, false>(p, zero_page, stream); break;
     }
   } else if (c == 256) {
+    if (pre) { launch_ff_fused_v<256, 1, 2, 4, true>(p, zero_page, stream); return; }
     switch (variant) {
-      case 1: launch_ff_fused_v<256, 1, 3, 2>(p, zero_page, stream); break;
-      case 2: launch_ff_fused_v<256, 2, 2, 2>(p, zero_page, stream); break;
-      default: launch_ff_fused_v<256, 1, 2, 4>(p, zero_page, stream); break;
+      case 1: launch_ff_fused_v<256, 1, 3, 2, false>(p, zero_page, stream); break;
+      case 2: launch_ff_fused_v<256, 2, 2, 2, false>(p, zero_page, stream); break;
+      default: launch_ff_fused_v<256, 1, 2, 4, false>(p, zero_page, stream); break;
     }
   } else {
     throw std::runtime_error("ff_fused: unsupported width");
