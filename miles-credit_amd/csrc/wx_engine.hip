@@ -46,7 +46,7 @@ struct ConvW {          // one repacked GEMM operand in the weight arena
   int cin_true = 0;     // unpadded channels (flop accounting)
 };
 struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1; int wsz = 0, kind = 0; };
-struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset; pack_pre: the same preceded by the attention's Wout blocks
+struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1, pack_pp = -1; const AttnL* next = nullptr; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset; pack_pre: the same preceded by the attention's Wout blocks
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
 struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmbed branch (wx_embed.h)
 struct StageL { std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks; };
@@ -522,12 +522,18 @@ class Engine : public EngineBase {
     return a;
   }
   // chunk blocks for ff_fused_kernel, built from the ROUNDED arena weights of w1 / w2 (same values as the unfused path)
-  int64_t pack_ff(const FFL& f, int c, int hidden, const ConvW* wout = nullptr) {
+  int64_t pack_ff(const FFL& f, int c, int hidden, const ConvW* wout = nullptr, const ConvW* wqkv = nullptr) {
     while (wt_host.size() % 8) wt_host.push_back(Elem<T>::from_f(0.f));
     const int64_t off = (int64_t)wt_host.size();
-    const int nch = hidden / 32, npre = wout ? c / 64 : 0;
+    const int nch = hidden / 32, npre = wout ? c / 64 : 0, npost = wqkv ? 3 * c / 64 : 0;
     const int64_t cb = 64 * (int64_t)c;  // elements per chunk block (128*C bytes of bf16)
-    wt_host.resize(off + (npre + nch) * cb);
+    wt_host.resize(off + (npre + nch + npost) * cb);
+    for (int i = 0; i < npost; ++i)      // Wqkv' rows [64 i, 64 i + 64), k order permuted like W1 (the input sits in accumulator layout)
+      for (int r = 0; r < 64; ++r)
+        for (int sl = 0; sl < c / 8; ++sl)
+          for (int j = 0; j < 8; ++j)
+            wt_host[off + (npre + nch + i) * cb + (int64_t)r * c + (sl ^ (r & 15)) * 8 + j] =
+                wt_host[wqkv->wt + (int64_t)(i * 64 + r) * c + 32 * (sl / 4) + ff_perm(sl % 4, j)];
     for (int i = 0; i < npre; ++i)       // Wout rows [64 i, 64 i + 64), natural k order, 16-byte slots XOR-swizzled by row
       for (int r = 0; r < 64; ++r)
         for (int sl = 0; sl < c / 8; ++sl)
@@ -594,6 +600,21 @@ class Engine : public EngineBase {
         st.blocks.push_back(bl);
       }
       stages[s] = std::move(st);
+      // second pass (block addresses are final now): feed-forward kernels that also run the NEXT attention's to_qkv
+      if constexpr (sizeof(T) == 2) {
+        std::vector<BlockL>& bs = stages[s].blocks;
+        const int c = cfg.dim[s];
+        for (size_t d = 0; d < bs.size(); ++d) {
+          FFL* ffs[2] = {&bs[d].sf, &bs[d].lf};
+          const AttnL* prev[2] = {&bs[d].sa, &bs[d].la};
+          const AttnL* next[2] = {&bs[d].la, d + 1 < bs.size() ? &bs[d + 1].sa : nullptr};
+          for (int k = 0; k < 2; ++k)
+            if (ffs[k]->pack_pre >= 0 && next[k] && next[k]->wsz > 1) {
+              ffs[k]->next = next[k];
+              ffs[k]->pack_pp = pack_ff(*ffs[k], c, 4 * c, &prev[k]->out, &next[k]->qkv);
+            }
+        }
+      }
     }
     const int last = cfg.dim[3];
     const int upc[3][2] = {{last, last / 2}, {2 * (last / 2), last / 4}, {2 * (last / 4), last / 8}};
@@ -663,7 +684,7 @@ class Engine : public EngineBase {
   int dbg_flags = 0;
   int gemm_cfg = 0;
   bool fuse_ln = true;
-  bool fuse_ff = true, fuse_out = true;          // stages with C in {128, 256}: FeedForward as one kernel (wx_ff.h), bf16 engine
+  bool fuse_ff = true, fuse_out = true, fuse_qkv = true;          // stages with C in {128, 256}: FeedForward as one kernel (wx_ff.h), bf16 engine
   int ff_variant = 0, ff_dbg = 0, attn_split = 0;
   float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
@@ -709,6 +730,7 @@ class Engine : public EngineBase {
     if (const char* e = getenv("WX_NO_LNFUSE")) fuse_ln = !(e[0] == '1');
     if (const char* e = getenv("WX_NO_FFFUSE")) fuse_ff = !(e[0] == '1');
     if (const char* e = getenv("WX_NO_OUTFUSE")) fuse_out = !(e[0] == '1');
+    if (const char* e = getenv("WX_NO_QKVFUSE")) fuse_qkv = !(e[0] == '1');
     if (const char* e = getenv("WX_FF_VARIANT")) ff_variant = atoi(e);
     if (const char* e = getenv("WX_FF_DBG")) ff_dbg = atoi(e);
     if (const char* e = getenv("WX_ATTN_SPLIT")) attn_split = atoi(e);
@@ -918,15 +940,16 @@ class Engine : public EngineBase {
     return rowstat;
   }
   // defer_out: leave the attention output in attn_o; the fused feed-forward kernel applies to_out + residual itself
-  void attention(const AttnL& a, int s, const std::string& dbg_name, bool defer_out = false) {
+  // qkv_ready: the previous fused feed-forward kernel already wrote this attention's q|k|v into `scratch`
+  void attention(const AttnL& a, int s, const std::string& dbg_name, bool defer_out = false, bool qkv_ready = false) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
     const int64_t ld = stream_ld(s);
-    const float2* rs = stream_stats(x, ld, c, m);
+    const float2* rs = qkv_ready ? nullptr : stream_stats(x, ld, c, m);
     if (a.wsz == 1) {
       gemm("gemm_qkv", a.vonly, x, h, w, ld, 1, 0, 0, h, w, attn_o, c, rs, 0, nullptr, 0);
     } else {
-      gemm("gemm_qkv", a.qkv, x, h, w, ld, 1, 0, 0, h, w, scratch, 3 * c, rs, 0, nullptr, 0);
+      if (!qkv_ready) gemm("gemm_qkv", a.qkv, x, h, w, ld, 1, 0, 0, h, w, scratch, 3 * c, rs, 0, nullptr, 0);
       AttnParams p;
       p.qkv = scratch; p.ld_qkv = 3 * c; p.out = attn_o; p.ld_out = c; p.bias = f_dev + a.bias_tab;
       p.H = h; p.W = w; p.C = c; p.heads = c / 32; p.wsz = a.wsz; p.kind = a.kind;
@@ -943,6 +966,7 @@ class Engine : public EngineBase {
     capture(dbg_name, x, h, w, c, ld, w);
   }
   bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on; }
+  bool ff_makes_qkv(const FFL& f) const { return ff_takes_out(f) && fuse_qkv && f.pack_pp >= 0; }
   void feedforward(const FFL& f, int s, const std::string& dbg_name, const AttnL* pre = nullptr) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
@@ -951,11 +975,14 @@ class Engine : public EngineBase {
       if (f.pack >= 0 && fuse_ff) {
         FFParams fp;
         fp.x = reinterpret_cast<const bf16_t*>(x); fp.ld = ld; fp.out = reinterpret_cast<bf16_t*>(x); fp.out_ld = ld;
-        fp.M = m; fp.hidden = 4 * c; fp.wpack = reinterpret_cast<const char*>(wt_dev + (pre ? f.pack_pre : f.pack));
+        const bool post = pre && ff_makes_qkv(f);
+        fp.M = m; fp.hidden = 4 * c; fp.wpack = reinterpret_cast<const char*>(wt_dev + (post ? f.pack_pp : pre ? f.pack_pre : f.pack));
+        fp.qkv = post ? reinterpret_cast<bf16_t*>(scratch) : nullptr; fp.ld_qkv = 3 * c;
+        fp.csq = post ? f_dev + f.next->qkv.colsum : nullptr; fp.bq = post ? f_dev + f.next->qkv.bias : nullptr;
         fp.o = pre ? reinterpret_cast<const bf16_t*>(attn_o) : nullptr; fp.ld_o = c; fp.bo = pre ? f_dev + pre->out.bias : nullptr;
         fp.cs1 = f_dev + f.w1.colsum; fp.b1 = f_dev + f.w1.bias; fp.b2 = f_dev + f.w2.bias;
         fp.stat_out = fuse_ln ? statpart : nullptr; fp.dbg = ff_dbg;
-        timed(pre ? "out_ff_fused" : "ff_fused", (pre ? 18.0 : 16.0) * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] { launch_ff_fused(c, fp, zero_page, cur_stream, ff_variant); });
+        timed(post ? "out_ff_qkv_fused" : pre ? "out_ff_fused" : "ff_fused", (post ? 24.0 : pre ? 18.0 : 16.0) * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] { launch_ff_fused(c, fp, zero_page, cur_stream, ff_variant); });
         stat_tiles_ready = fuse_ln ? 1 : 0;
         capture(dbg_name, x, h, w, c, ld, w);
         return;
@@ -1053,14 +1080,16 @@ class Engine : public EngineBase {
       }
       const std::string sp = "layers." + std::to_string(s);
       capture(sp + ".0", x, sh[s], sw[s], cfg.dim[s], ld, sw[s]);
+      bool qkv_made = false;  // the previous fused kernel already produced this attention's q|k|v
       for (size_t d = 0; d < st.blocks.size(); ++d) {
         const std::string bp = sp + ".1.layers." + std::to_string(d);
         const BlockL& bl = st.blocks[d];
         const bool ds = ff_takes_out(bl.sf), dl = ff_takes_out(bl.lf);
-        attention(bl.sa, s, bp + ".0", ds);
+        attention(bl.sa, s, bp + ".0", ds, qkv_made);
         feedforward(bl.sf, s, bp + ".1", ds ? &bl.sa : nullptr);
-        attention(bl.la, s, bp + ".2", dl);
+        attention(bl.la, s, bp + ".2", dl, ds && ff_makes_qkv(bl.sf));
         feedforward(bl.lf, s, bp + ".3", dl ? &bl.la : nullptr);
+        qkv_made = dl && ff_makes_qkv(bl.lf);
       }
       capture(sp + ".1", x, sh[s], sw[s], cfg.dim[s], ld, sw[s]);
     }

@@ -44,6 +44,12 @@ struct FFParams {
   const bf16_t* o;      // attention output [M][ld_o]
   int64_t ld_o;
   const float* bo;      // [C]
+  // POST variant (the NEXT attention's LayerNorm + to_qkv fused behind): qkv = Wqkv' . LN(x_out), written to `qkv`.
+  // wpack then ends with 3C/64 blocks of 128*C bytes holding Wqkv' rows [64 i, 64 i + 64) (permuted k order, slot-swizzled).
+  bf16_t* qkv;          // [M][ld_qkv] or nullptr
+  int64_t ld_qkv;
+  const float* csq;     // [3C] column sums of the rounded gain-folded Wqkv rows
+  const float* bq;      // [3C] folded bias (LayerNorm shift through Wqkv)
 };
 
 // k-slot permutation shared by x fragments, W1 and (through the accumulator layout) W2:
@@ -52,7 +58,7 @@ inline int ff_perm(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 
 // physical 16-byte slot of logical slot g in row o of a W2 chunk (64-byte rows)
 inline int ff_w2_slot(int o, int g) { return (g + 2 * ((o & 15) >> 2)) & 3; }
 
-template <int C, int PXF, int OCC, int GP, bool PRE>
+template <int C, int PXF, int OCC, int GP, bool PRE, bool POST>
 __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, const char* __restrict__ zero_page) {
   constexpr int KS = C / 32;          // GEMM1 k steps
   constexpr int MF = C / 16;          // GEMM2 output-channel fragments
@@ -80,6 +86,12 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   for (int i = tid; i < p.hidden; i += 256) {
     s_par[i] = p.cs1[i];
     s_par[p.hidden + i] = p.b1[i];
+  }
+  if constexpr (POST) {  // [3C] csq | [3C] bq behind them: a global load inside the block loop would wait on vmcnt = on the DMA
+    for (int i = tid; i < 3 * C; i += 256) {
+      s_par[2 * p.hidden + i] = p.csq[i];
+      s_par[2 * p.hidden + 3 * C + i] = p.bq[i];
+    }
   }
 
   // ---- x fragments (B operand of GEMM1, residual of the epilogue) ---------------------------------
@@ -109,6 +121,7 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   const int w2_off = 64 * C + li * 64 + ((g + 2 * (li >> 2)) & 3) * 16;  // + m*1024 (slot rotation: conflict-free b128 lane groups)
 
   constexpr int NPRE = PRE ? C / 64 : 0;  // out-projection blocks ahead of the feed-forward chunks in the ring
+  constexpr int NPOST = POST ? 3 * C / 64 : 0;  // to_qkv blocks behind them
   // ---- x1 = x + Wout . o + bo (crossformer.py:314-316 to_out + the attention residual :352), kept in registers ----
   uint4 ob[PRE ? KS : 1][PXF];
   if constexpr (PRE) {
@@ -161,36 +174,39 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   }
   // ---- LayerNorm statistics, two-pass, in registers -----------------------------------------------
   float mean[PXF], rstd[PXF];
+  auto row_statistics = [&]() {
 #pragma unroll
-  for (int f = 0; f < PXF; ++f) {
-    float s = 0.f;
+    for (int f = 0; f < PXF; ++f) {
+      float s = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      float v[8];
-      unpack16<bf16_t>(xb[ks][f], v);
+      for (int ks = 0; ks < KS; ++ks) {
+        float v[8];
+        unpack16<bf16_t>(xb[ks][f], v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[e];
+        for (int e = 0; e < 8; ++e) s += v[e];
+      }
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mu = s * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float v[8];
+        unpack16<bf16_t>(xb[ks][f], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q += (v[e] - mu) * (v[e] - mu);
+      }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      mean[f] = mu;
+      rstd[f] = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
     }
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    const float mu = s * (1.0f / C);
-    float q = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      float v[8];
-      unpack16<bf16_t>(xb[ks][f], v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) q += (v[e] - mu) * (v[e] - mu);
-    }
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    mean[f] = mu;
-    rstd[f] = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
-  }
+  };
+  row_statistics();
 
   for (int ch = 0; ch < nch; ++ch) {  // NPRE is even: the ring parity of chunk ch is ch & 1 either way
     const char* cur = smem + (ch & 1) * CB;
-    if (ch + 1 < nch) issue(NPRE + ch + 1, (unsigned)(((ch + 1) & 1) * CB));
+    if (ch + 1 < nch + NPOST) issue(NPRE + ch + 1, (unsigned)(((ch + 1) & 1) * CB));
     // GEMM1, K steps in batches of 4: the 8 fragment reads of a batch are all in flight before its first MFMA.
     // (`asm volatile("" ::: "memory")` pins only the LDS reads; MFMA / VALU remain free to interleave.  Left to
     // itself hipcc reuses one register quad and serialises read -> wait -> 2 MFMAs.)
@@ -298,6 +314,9 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
         s2 += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
       }
       if (ok) *reinterpret_cast<uint2*>(orow + m * 16) = o;
+      if constexpr (POST) {  // the rounded output row becomes the next block's input, same register layout
+        if (m & 1) { xb[m / 2][f].z = o.x; xb[m / 2][f].w = o.y; } else { xb[m / 2][f].x = o.x; xb[m / 2][f].y = o.y; }
+      }
     }
     if (p.stat_out) {
       s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
@@ -305,12 +324,54 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
       if (ok && g2 == 0) p.stat_out[px] = make_float2(s1, s2);
     }
   }
+  if constexpr (POST) {
+    // ---- next attention: LayerNorm(x_out) folded into to_qkv (crossformer.py:268-270), 64 output rows per ring block ----
+    row_statistics();
+#pragma unroll 1
+    for (int i = 0; i < NPOST; ++i) {  // nch is even: ring parity of block i is i & 1
+      const char* cur = smem + (i & 1) * CB;
+      if (i + 1 < NPOST) issue(NPRE + nch + i + 1, (unsigned)(((i + 1) & 1) * CB));
+      f32x4_t qa[4][PXF];
+#pragma unroll
+      for (int ml = 0; ml < 4; ++ml)
+#pragma unroll
+        for (int f = 0; f < PXF; ++f) qa[ml][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ml = 0; ml < 4; ++ml) {
+        uint4 a[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const uint4*>(cur + w1_off + ml * 16 * 2 * C + (((ks * 4 + g) ^ li) * 16));
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int f = 0; f < PXF; ++f) qa[ml][f] = mma_sub<bf16_t>(a[ks], xb[ks][f], qa[ml][f]);
+      }
+#pragma unroll
+      for (int ml = 0; ml < 4; ++ml) {
+        const int n0 = i * 64 + ml * 16 + 4 * g2;
+        const float4 cs = *reinterpret_cast<const float4*>(s_par + 2 * p.hidden + n0);
+        const float4 bb = *reinterpret_cast<const float4*>(s_par + 2 * p.hidden + 3 * C + n0);
+#pragma unroll
+        for (int f = 0; f < PXF; ++f) {
+          const int px = px0b + f * 16 + li2;
+          const float mu = mean[f], rs = rstd[f];
+          uint2 o;
+          o.x = pack_bf16x2(rs * (qa[ml][f][0] - mu * cs.x) + bb.x, rs * (qa[ml][f][1] - mu * cs.y) + bb.y);
+          o.y = pack_bf16x2(rs * (qa[ml][f][2] - mu * cs.z) + bb.z, rs * (qa[ml][f][3] - mu * cs.w) + bb.w);
+          if (px < p.M) *reinterpret_cast<uint2*>(p.qkv + (int64_t)px * p.ld_qkv + n0) = o;
+        }
+      }
+      dma_wait_all();
+      __syncthreads();
+    }
+  }
 }
 
-template <int C, int PXF, int OCC, int GP, bool PRE>
+template <int C, int PXF, int OCC, int GP, bool PRE, bool POST>
 inline void launch_ff_fused_v(const FFParams& p, const void* zero_page, hipStream_t stream) {
-  const int LDS = 2 * 128 * C + 8 * p.hidden;
-  auto kern = ff_fused_kernel<C, PXF, OCC, GP, PRE>;
+  const int LDS = 2 * 128 * C + 8 * p.hidden + (POST ? 24 * C : 0);
+  auto kern = ff_fused_kernel<C, PXF, OCC, GP, PRE, POST>;
   static int attr_lds = 0;
   if (LDS > attr_lds) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -328,20 +389,23 @@ inline bool ff_fused_supported(int c, int hidden) { return (c == 128 || c == 256
 // (0 B scratch) vs <2, 3 waves/SIMD> 0.618-0.636 ms (232-248 B) vs unfused FF1+FF2 1.08 ms; C=256: <1, 2/SIMD, 4> 0.514 ms
 // (0 B) vs <2, 2/SIMD> 0.71 ms (512 B) vs unfused 0.63 ms.
 inline void launch_ff_fused(int c, const FFParams& p, const void* zero_page, hipStream_t stream, int variant = 0) {
-  const bool pre = p.o != nullptr;
+  const bool pre = p.o != nullptr, post = p.qkv != nullptr;
+  if (post && !pre) throw std::runtime_error("ff_fused: the to_qkv tail is only built together with the to_out head");
   if (c == 128) {
-    if (pre) { launch_ff_fused_v<128, 2, 2, 4, true>(p, zero_page, stream); return; }
+    if (pre && post) { launch_ff_fused_v<128, 2, 2, 4, true, true>(p, zero_page, stream); return; }
+    if (pre) { launch_ff_fused_v<128, 2, 2, 4, true, false>(p, zero_page, stream); return; }
     switch (variant) {
-      case 1: launch_ff_fused_v<128, 2, 2, 8, false>(p, zero_page, stream); break;
-      case 2: launch_ff_fused_v<128, 2, 3, 2, false>(p, zero_page, stream); break;
-      default: launch_ff_fused_v<128, 2, 2, 4, false>(p, zero_page, stream); break;
+      case 1: launch_ff_fused_v<128, 2, 2, 8, false, false>(p, zero_page, stream); break;
+      case 2: launch_ff_fused_v<128, 2, 3, 2, false, false>(p, zero_page, stream); break;
+      default: launch_ff_fused_v<128, 2, 2, 4, false, false>(p, zero_page, stream); break;
     }
   } else if (c == 256) {
-    if (pre) { launch_ff_fused_v<256, 1, 2, 4, true>(p, zero_page, stream); return; }
+    if (pre && post) { launch_ff_fused_v<256, 1, 2, 4, true, true>(p, zero_page, stream); return; }
+    if (pre) { launch_ff_fused_v<256, 1, 2, 4, true, false>(p, zero_page, stream); return; }
     switch (variant) {
-      case 1: launch_ff_fused_v<256, 1, 3, 2, false>(p, zero_page, stream); break;
-      case 2: launch_ff_fused_v<256, 2, 2, 2, false>(p, zero_page, stream); break;
-      default: launch_ff_fused_v<256, 1, 2, 4, false>(p, zero_page, stream); break;
+      case 1: launch_ff_fused_v<256, 1, 3, 2, false, false>(p, zero_page, stream); break;
+      case 2: launch_ff_fused_v<256, 2, 2, 2, false, false>(p, zero_page, stream); break;
+      default: launch_ff_fused_v<256, 1, 2, 4, false, false>(p, zero_page, stream); break;
     }
   } else {
     throw std::runtime_error("ff_fused: unsupported width");
