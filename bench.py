@@ -129,10 +129,19 @@ def main():
         tot_ms = sum(r["ms"] for r in rows)
         achieved = g_fl / (g_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
+        # HBM traffic of the same kernel from the PMC passes of tools/collect_profiles.sh (rocprofv3 cannot run inside
+        # this process; the summary is committed next to the kernel-stats it was collected with)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")
+        if args.config == "C3" and args.precision == "bf16" and os.path.isfile(tpath):
+            k = json.load(open(tpath))["kernels"].get("wx::conv_gemm_dma_kernel")
+            if k:
+                traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
         roofline = {
-            "bound": "mfma", "kernel": "wx::conv_gemm_kernel (implicit-GEMM MFMA conv; all gemm_* launches)",
+            "bound": "mfma", "kernel": "wx::conv_gemm_dma_kernel (implicit-GEMM MFMA conv; all gemm_* launches)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": None,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE; profiles/pmc_traffic_r01.json)",
+            "algorithmic_bytes_per_launch": round(sum(r["bytes"] for r in gemm) / max(g_n, 1)),
             "launches_per_step": g_n // nprof, "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2),
             "flops_per_step": g_fl / nprof, "kernel_ms_per_step": round(g_ms / nprof, 3),
             "all_kernels_ms_per_step": round(tot_ms / nprof, 3),

@@ -27,6 +27,10 @@ namespace wx {
 
 struct EmbedPatchParams {
   const void* xin;     // packed input [(Hb)][(Wb)][cpad] (halo included), element type T
+  const void* xin_planar;  // the same pixels as [cpad*sizeof(T)/16][Hb][Wb] x 16 B planes, or nullptr.  The patch of ONE
+                           // channel chunk is then a dense 16-byte-per-pixel rectangle; from the pixel-major buffer every
+                           // 16-byte piece drags its whole 128-byte line through L2 once per chunk pass (PMC: 3.6 GB
+                           // FETCH_SIZE per launch for 0.17 GB of input -- the staging, not the MFMAs, bounded the kernel)
   int Hb, Wb, cpad;    // buffer dims in pixels / channels
   int org;             // halo - 15 : buffer offset of the 32x32 window origin
   const void* wt32;    // [chunks][32][8][64 lanes] x 16 B
@@ -66,6 +70,7 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
   const int by0 = 2 * oy0 + p.org, bx0 = 2 * ox0 + p.org;  // patch origin in buffer coordinates
   const int chunks = p.cpad / CC;
   const char* __restrict__ xin = reinterpret_cast<const char*>(p.xin);
+  const char* __restrict__ planar = reinterpret_cast<const char*>(p.xin_planar);
   const uint4* __restrict__ wt32 = reinterpret_cast<const uint4*>(p.wt32);
   const uint4* __restrict__ wt16 = reinterpret_cast<const uint4*>(p.wt16);
   const uint4* __restrict__ wt8 = reinterpret_cast<const uint4*>(p.wt8);
@@ -96,7 +101,9 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
         const int py = idx / PW, px = idx - py * PW;
         const int by = by0 + py, bx = bx0 + px;
         const bool ok = idx < NPIX && by >= 0 && by < p.Hb && bx >= 0 && bx < p.Wb;
-        const char* src = ok ? xin + ((int64_t)by * p.Wb + bx) * pix_bytes + ch * 16 : zero_page;
+        const char* src = !ok ? zero_page
+                          : planar ? planar + (((int64_t)ch * p.Hb + by) * p.Wb + bx) * 16
+                                   : xin + ((int64_t)by * p.Wb + bx) * pix_bytes + ch * 16;
         lds_dma16(src, smem + (it * NT + wave * 64) * 16);
       }
     dma_wait_all();

@@ -672,6 +672,7 @@ class Engine : public EngineBase {
     return p;
   }
   T* xin = nullptr;          // packed, halo'd input
+  T* xin_planar = nullptr;   // chunk-planar copy for the LDS-patch CrossEmbed kernel (wx_embed.h)
   T* cat[3] = {nullptr, nullptr, nullptr};   // [HW_s][2*C_s]: [up-block output | encoder stream]
   T* x3 = nullptr;           // stage-3 stream
   T* scratch = nullptr;      // qkv / FF hidden
@@ -689,7 +690,7 @@ class Engine : public EngineBase {
   float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
   int stat_tiles_ready = 0;     // > 0: `statpart` holds partials of the current stream contents (that many per row)
-  bool use_patch = true;
+  bool use_patch = true, planar_xin = true;
   double* gn_acc = nullptr;
   float *gn_scale = nullptr, *gn_shift = nullptr;
   float *d_mean = nullptr, *d_std = nullptr, *d_lo = nullptr, *d_hi = nullptr;
@@ -702,6 +703,10 @@ class Engine : public EngineBase {
     const int64_t xin_elems = (int64_t)(Hp + 2 * halo + 2) * (Wp + 2 * halo + 2) * cpad0;
     xin = (T*)dalloc(xin_elems * sizeof(T));
     WX_HIP(hipMemset(xin, 0, xin_elems * sizeof(T)));
+    if (use_patch && planar_xin) {
+      xin_planar = (T*)dalloc(xin_elems * sizeof(T));
+      WX_HIP(hipMemset(xin_planar, 0, xin_elems * sizeof(T)));
+    }
     int64_t max_sc = 0, max_ao = 0, max_hw = 0;
     for (int s = 0; s < 4; ++s) {
       const int64_t hw = (int64_t)sh[s] * sw[s];
@@ -735,6 +740,7 @@ class Engine : public EngineBase {
     if (const char* e = getenv("WX_FF_DBG")) ff_dbg = atoi(e);
     if (const char* e = getenv("WX_ATTN_SPLIT")) attn_split = atoi(e);
     if (const char* e = getenv("WX_NO_PATCH")) use_patch = !(e[0] == '1');
+    if (const char* e = getenv("WX_NO_PLANAR")) planar_xin = !(e[0] == '1');
     const int cmax = cfg.dim[3];
     gn_acc = (double*)dalloc(2 * cmax * sizeof(double));
     gn_scale = (float*)dalloc(cmax * sizeof(float));
@@ -1031,7 +1037,7 @@ class Engine : public EngineBase {
       p.x = x_item; p.dst = xin; p.C = C_in; p.H = cfg.image_height; p.W = cfg.image_width;
       p.p0 = cfg.pad_activate ? cfg.pad_lat[0] : 0; p.p1 = cfg.pad_activate ? cfg.pad_lat[1] : 0;
       p.pl = cfg.pad_activate ? cfg.pad_lon[0] : 0; p.pr = cfg.pad_activate ? cfg.pad_lon[1] : 0;
-      p.halo = halo; p.cpad = cpad0;
+      p.halo = halo; p.cpad = cpad0; p.dst_planar = xin_planar; p.Hb = Hp + 2 * halo;
       timed("pack_input", 0.0, (double)C_in * cfg.image_height * cfg.image_width * 4.0 + (double)Hp * Wp * cpad0 * sizeof(T), [&] {
         hipLaunchKernelGGL(pack_input_kernel<T>, dim3(cdiv(Wp, 64), Hp), dim3(256), 0, cur_stream, p);
         WX_HIP(hipGetLastError());
@@ -1052,7 +1058,7 @@ class Engine : public EngineBase {
           if (k != 32) { choff += st.embed[b].n; continue; }  // rides along in the fused launch issued with k = 32
           EmbedPatchParams ep;
           std::memset(&ep, 0, sizeof(ep));
-          ep.xin = xin; ep.Hb = Hp + 2 * halo; ep.Wb = Wp + 2 * halo; ep.cpad = cpad0; ep.org = halo - 15;
+          ep.xin = xin; ep.xin_planar = xin_planar; ep.Hb = Hp + 2 * halo; ep.Wb = Wp + 2 * halo; ep.cpad = cpad0; ep.org = halo - 15;
           ep.out_ld = ld; ep.out_h = sh[0]; ep.out_w = sw[0]; ep.dbg = dbg_flags;
           double fl = 0.0;
           int off = 0;
