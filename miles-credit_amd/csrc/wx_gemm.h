@@ -377,7 +377,7 @@ __device__ __forceinline__ void dma_wait_allow() { asm volatile("s_waitcnt vmcnt
 // BM = BN = 128 is exactly the MFMA rate (64 FLOP per staged byte x 64 B/clk = 4096 FLOP/clk/CU): the 4-wave tile is
 // L1-bound by construction.  BM = 256 (8 waves, 4 x 2) stages 25 % fewer bytes per FLOP; two such workgroups and a
 // 3-stage ring fit a CU (2 x 74 KB LDS, 16 waves).
-template <typename T, int BM, int BN, int KB, bool ONE, int NST>
+template <typename T, int BM, int BN, int KB, bool ONE, int NST, bool TAPIN>
 __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 : 3) : 2)) void conv_gemm_dma_kernel(
     const ConvGemmParams p, const char* __restrict__ zero_page) {
   constexpr int WMR = 64;               // rows (pixels) per wave
@@ -472,6 +472,9 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   unsigned long long tr_work = 0, tr_dma = 0, tr_bar = 0;
 #endif
   int ky = 0, kx = 0, cc = 0;
+  // TAPIN (compile time: a run-time switch here cost 12 B of scratch inside the K loop and 30-80 % per launch)
+  // measured: ConvT-k4 (8 chunks) 0.41 -> 0.31 ms with taps inner; CrossEmbed k=4 on 2 chunks 0.11 -> 0.15 ms, so narrow
+  // inputs keep the chunk-inner order
   auto issue = [&](unsigned stage_off, int ks) {
 #pragma unroll
     for (int i = 0; i < A_I; ++i) {
@@ -485,12 +488,24 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
       }
       lds_dma16_s(src, a_dst[i] + stage_off);
     }
+    // K order for k x k convolutions: channel chunk OUTER, taps INNER.  Consecutive steps then re-read the same 64-byte
+    // channel slice at shifted pixels (L1/L2 hits); with taps outer a tap's re-use came cchunks steps later, after
+    // the CU's four workgroups had streamed 8 MB through a 4 MB L2 -- PMC: 605 MB FETCH_SIZE per ConvT-k4 parity
+    // launch for a 164 MB input, i.e. every tap fetched from the fabric.  The weight row stays [ky][kx][c].
+    const int64_t wstep = ONE ? (int64_t)ks : (int64_t)(ky * p.kw + kx) * cchunks + cc;
 #pragma unroll
-    for (int i = 0; i < B_I; ++i) lds_dma16_s(b_src[i] + (int64_t)ks * b_step[i], b_dst[i] + stage_off);
+    for (int i = 0; i < B_I; ++i) lds_dma16_s(b_src[i] + wstep * b_step[i], b_dst[i] + stage_off);
     if constexpr (!ONE) {
-      if (++cc == cchunks) {
-        cc = 0;
-        if (++kx == p.kw) { kx = 0; ++ky; }
+      if constexpr (TAPIN) {
+        if (++kx == p.kw) {
+          kx = 0;
+          if (++ky == p.kh) { ky = 0; ++cc; }
+        }
+      } else {  // narrow inputs (<= 256 B per pixel): the chunks of one pixel are neighbours in one or two lines
+        if (++cc == cchunks) {
+          cc = 0;
+          if (++kx == p.kw) { kx = 0; ++ky; }
+        }
       }
     }
   };
@@ -804,12 +819,12 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   }
 }
 
-template <typename T, int BM, int BN, int KB, bool ONE, int NST>
+template <typename T, int BM, int BN, int KB, bool ONE, int NST, bool TAPIN = false>
 inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
   constexpr int STAGES = NST * (BM + BN) * KB;
   constexpr int CT = BM * BN * (int)sizeof(T);
   constexpr int LDS = (STAGES > CT ? STAGES : CT) + 1024 + BM * 8;  // + epilogue parameter block
-  auto kern = conv_gemm_dma_kernel<T, BM, BN, KB, ONE, NST>;
+  auto kern = conv_gemm_dma_kernel<T, BM, BN, KB, ONE, NST, TAPIN>;
   static bool attr_done = false;
   if (!attr_done) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -863,8 +878,10 @@ inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page,
     }
     if (three) launch_conv_gemm_dma_v<T, 128, BN, KB, true, (KB == 64 ? 3 : 2)>(p, zero_page, stream);
     else launch_conv_gemm_dma_v<T, 128, BN, KB, true, 2>(p, zero_page, stream);
+  } else if (p.cin * (int)sizeof(T) / KB >= 8) {
+    launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2, true>(p, zero_page, stream);
   } else {
-    launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2>(p, zero_page, stream);
+    launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2, false>(p, zero_page, stream);
   }
 }
 

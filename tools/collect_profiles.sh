@@ -9,5 +9,5 @@ python tools/prof_summary.py gpurun_out/${tag}_kt > gpurun_out/${tag}_kernel_sta
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pf -o pf -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pw -o pw -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 python tools/pmc_traffic.py gpurun_out/${tag}_pf gpurun_out/${tag}_pw gpurun_out/${tag}_pmc_traffic.json
-rm -rf gpurun_out/${tag}_kt gpurun_out/${tag}_pf gpurun_out/${tag}_pw
+python tools/pmc_traffic.py gpurun_out/${tag}_pf gpurun_out/${tag}_pw gpurun_out/${tag}_pmc_traffic.json > gpurun_out/${tag}_pmc_traffic.txt; rm -rf gpurun_out/${tag}_kt gpurun_out/${tag}_pf gpurun_out/${tag}_pw
 cut -c1-300 gpurun_out/${tag}_bench.json; head -12 gpurun_out/${tag}_kernel_stats.txt

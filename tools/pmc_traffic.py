@@ -12,7 +12,15 @@ import sys
 from collections import defaultdict
 
 
-def load(d, counter):
+def family(name):
+    name = name.replace("void ", "")
+    for key in ("conv_gemm_dma_kernel", "conv_gemm_kernel", "ff_fused_kernel", "window_attn_kernel", "embed_patch_kernel"):
+        if key in name:
+            return "wx::" + key
+    return name.split("(")[0][:60]
+
+
+def load(d, counter, by_grid=False):
     files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     acc = defaultdict(lambda: [0, 0.0])
     for f in files:
@@ -20,17 +28,11 @@ def load(d, counter):
             if r.get("Counter_Name") != counter:
                 continue
             k = r["Kernel_Name"]
+            if by_grid:
+                k = (family(k) + " " + k.split("<")[1].split(">")[0][:40] if "<" in k else family(k), r.get("Grid_Size", "?"))
             acc[k][0] += 1
             acc[k][1] += float(r["Counter_Value"])
     return acc
-
-
-def family(name):
-    name = name.replace("void ", "")
-    for key in ("conv_gemm_dma_kernel", "conv_gemm_kernel", "ff_fused_kernel", "window_attn_kernel", "embed_patch_kernel"):
-        if key in name:
-            return "wx::" + key
-    return name.split("(")[0][:60]
 
 
 def main():
@@ -52,6 +54,12 @@ def main():
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for f, v in list(out["kernels"].items())[:8]:
         print(f, v)
+    # per (kernel variant, grid size): which launches over-fetch
+    fg, wg = load(sys.argv[1], "FETCH_SIZE", True), load(sys.argv[2], "WRITE_SIZE", True)
+    print("\nper (variant, grid): launches, fetch MB/launch (x2 corrected), write MB/launch")
+    for k, (n, v) in sorted(fg.items(), key=lambda kv: -kv[1][1])[:40]:
+        w = wg.get(k, [1, 0.0])
+        print(f"  {k[0]:70s} grid {k[1]:>9s}  n={n:4d}  fetch {2 * v / n / 1024:9.1f}  write {w[1] / max(w[0], 1) / 1024:9.1f}")
 
 
 if __name__ == "__main__":
