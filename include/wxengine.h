@@ -39,8 +39,10 @@ enum wx_status {
 
 enum wx_arch {
   WX_ARCH_CROSSFORMER = 0, /* credit/models/crossformer.py (model.type: crossformer): ConvTranspose decoder */
-  WX_ARCH_WXFORMER = 1     /* credit/models/wxformer/crossformer.py (model.type: wxformer / wxformer_base): sub-pixel conv
+  WX_ARCH_WXFORMER = 1,    /* credit/models/wxformer/crossformer.py (model.type: wxformer / wxformer_base): sub-pixel conv
                               + PixelShuffle decoder, ZeroPad2d-wrapped CrossEmbed branches (keys convs.<i>.1.*) */
+  WX_ARCH_CROSSFORMER_UPCONV = 2 /* credit/models/crossformer.py with upsample_v_conv=True (:87-92, :560-570): every decoder
+                              up-sampling is nn.Upsample(2x bilinear, align_corners=False) + Conv3x3 instead of ConvTranspose */
 };
 
 enum wx_precision {

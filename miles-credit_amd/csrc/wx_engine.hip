@@ -50,7 +50,7 @@ struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1, pack_pp = -1; const
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
 struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmbed branch (wx_embed.h)
 struct StageL { std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks; };
-struct UpL { ConvW convt, convps, sharp, c1, c2; int64_t g1 = -1, b1 = -1, g2 = -1, b2 = -1; int cin = 0, cout = 0; };
+struct UpL { ConvW convt, convps, sharp, upc, c1, c2; int64_t g1 = -1, b1 = -1, g2 = -1, b2 = -1; int cin = 0, cout = 0; };
 
 struct KernelStatAcc { int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
 
@@ -100,7 +100,8 @@ class Engine : public EngineBase {
     if (cfg.abi_version != WX_ABI_VERSION) throw ConfigError("wx_config.abi_version mismatch");
     if (cfg.frames < 1 || cfg.output_frames < 1) throw ConfigError("frames/output_frames must be >= 1");
     if (cfg.dim_head != 32) throw ConfigError("engine supports dim_head == 32 only (reference default)");
-    if (cfg.arch != WX_ARCH_CROSSFORMER && cfg.arch != WX_ARCH_WXFORMER) throw ConfigError("unknown wx_config.arch");
+    if (cfg.arch != WX_ARCH_CROSSFORMER && cfg.arch != WX_ARCH_WXFORMER && cfg.arch != WX_ARCH_CROSSFORMER_UPCONV)
+      throw ConfigError("unknown wx_config.arch");
     C_in = (cfg.channels * cfg.levels + cfg.surface_channels + cfg.input_only_channels) * cfg.frames;
     C_out = (cfg.channels * cfg.levels + cfg.surface_channels + cfg.output_only_channels) * cfg.output_frames;
     Hp = cfg.image_height + (cfg.pad_activate ? cfg.pad_lat[0] + cfg.pad_lat[1] : 0);
@@ -224,6 +225,8 @@ class Engine : public EngineBase {
       if (cfg.arch == WX_ARCH_WXFORMER) {  // UpBlockPS (wxformer/crossformer.py:137-162)
         add_conv(p + ".conv", {4 * ups[i][1], ups[i][0], 3, 3}, true);
         add_conv(p + ".sharp", {ups[i][1], ups[i][1], 3, 3}, true);
+      } else if (cfg.arch == WX_ARCH_CROSSFORMER_UPCONV) {  // nn.Upsample + Conv2d 3x3 (crossformer.py:87-89)
+        add_conv(p + ".conv", {ups[i][1], ups[i][0], 3, 3}, true);
       } else {
         add_conv(p + ".conv", {ups[i][0], ups[i][1], 2, 2}, true, true);
       }
@@ -236,6 +239,8 @@ class Engine : public EngineBase {
     if (cfg.arch == WX_ARCH_WXFORMER) {  // Sequential(conv3x3 -> PixelShuffle -> conv3x3) (wxformer/crossformer.py:817-830)
       add_conv("up_block4.0", {4 * C_out, 2 * (last / 8), 3, 3}, true);
       add_conv("up_block4.2", {C_out, C_out, 3, 3}, true);
+    } else if (cfg.arch == WX_ARCH_CROSSFORMER_UPCONV) {  // Sequential(Upsample, Conv2d) (crossformer.py:560-570)
+      add_conv("up_block4.1", {C_out, 2 * (last / 8), 3, 3}, true);
     } else {
       add_conv("up_block4", {2 * (last / 8), C_out, 4, 4}, true, true);
     }
@@ -631,6 +636,8 @@ class Engine : public EngineBase {
           for (int c = 0; c < u.cout; ++c) src[q * u.cout + c] = c * 4 + q;
         u.convps = make_conv(p + ".conv", 0, 0, u.cin, u.cin, 3, 3, true, nullptr, nullptr, &src);
         u.sharp = make_conv(p + ".sharp", 0, u.cout, u.cout, u.cout, 3, 3, true, nullptr, nullptr);
+      } else if (cfg.arch == WX_ARCH_CROSSFORMER_UPCONV) {
+        u.upc = make_conv(p + ".conv", 0, u.cout, u.cin, u.cin, 3, 3, true, nullptr, nullptr);
       } else {
         u.convt = make_convt2(p + ".conv", u.cin, u.cout);
       }
@@ -647,6 +654,8 @@ class Engine : public EngineBase {
         for (int c = 0; c < C_out; ++c) src[q * cpad4 + c] = c * 4 + q;
       ps4 = make_conv("up_block4.0", 0, 0, 2 * (last / 8), 2 * (last / 8), 3, 3, true, nullptr, nullptr, &src);
       fin4 = make_conv("up_block4.2", 0, C_out, C_out, cpad4, 3, 3, true, nullptr, nullptr);
+    } else if (cfg.arch == WX_ARCH_CROSSFORMER_UPCONV) {
+      up4c = make_conv("up_block4.1", 0, C_out, 2 * (last / 8), 2 * (last / 8), 3, 3, true, nullptr, nullptr);
     } else {
       make_convt4("up_block4", 2 * (last / 8), C_out);
     }
@@ -678,6 +687,8 @@ class Engine : public EngineBase {
   T* scratch = nullptr;      // qkv / FF hidden
   T* attn_o = nullptr;       // attention output before to_out
   T* dtmp[4] = {nullptr, nullptr, nullptr, nullptr};  // decoder temporaries
+  T* upbuf = nullptr;        // upsample_v_conv variant: 2x bilinear up-sampled map feeding the 3x3 conv
+  ConvW up4c;                // ... its up_block4 conv
   T* dec = nullptr;          // up_block4 output [Hd][Wd][ld_dec]
   float2* rowstat = nullptr;
   char* zero_page = nullptr;
@@ -722,6 +733,11 @@ class Engine : public EngineBase {
     for (int i = 0; i < 3; ++i) max_dt = std::max(max_dt, (int64_t)sh[2 - i] * sw[2 - i] * ups[i].cout);
     for (int i = 0; i < 4; ++i) dtmp[i] = (T*)dalloc(max_dt * sizeof(T));
     if (cfg.arch == WX_ARCH_WXFORMER) ps4_buf = (T*)dalloc((int64_t)Hd * Wd * cpad4 * sizeof(T));
+    if (cfg.arch == WX_ARCH_CROSSFORMER_UPCONV) {  // bilinearly up-sampled conv input: largest is up_block4's (Hd x Wd x 2 dim0)
+      int64_t m = (int64_t)Hd * Wd * 2 * cfg.dim[0];
+      for (int i = 0; i < 3; ++i) m = std::max(m, (int64_t)sh[2 - i] * sw[2 - i] * ups[i].cin);
+      upbuf = (T*)dalloc(m * sizeof(T));
+    }
     dec = (T*)dalloc((int64_t)Hd * Wd * ld_dec * sizeof(T));
     WX_HIP(hipMemset(dec, 0, (int64_t)Hd * Wd * ld_dec * sizeof(T)));
     rowstat = (float2*)dalloc(max_hw * sizeof(float2));
@@ -927,6 +943,14 @@ class Engine : public EngineBase {
     timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream, gemm_cfg); });
     return made_stats;
   }
+  void upsample2x(const T* in, int h, int w, int64_t in_ld, int c) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int64_t total = (int64_t)4 * h * w * (c / VEC);
+    timed("upsample2x", 0.0, (double)5 * h * w * c * sizeof(T), [&] {
+      hipLaunchKernelGGL(upsample2x_kernel<T>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, cur_stream, in, h, w, in_ld, c, upbuf);
+      WX_HIP(hipGetLastError());
+    });
+  }
   void ln_stats(const T* x, int64_t ld, int c, int m) {
     constexpr int VEC = 16 / (int)sizeof(T);
     const int pieces = c / VEC;
@@ -1116,6 +1140,9 @@ class Engine : public EngineBase {
              u.cout);
         gemm("gemm_conv3", u.sharp, dtmp[3], sh[so], sw[so], u.cout, 1, 1, 1, sh[so], sw[so], scut, u.cout, nullptr, 0, dtmp[3],
              u.cout);
+      } else if (cfg.arch == WX_ARCH_CROSSFORMER_UPCONV) {
+        upsample2x(in, sh[si], sw[si], in_ld, u.cin);
+        gemm("gemm_conv3", u.upc, upbuf, sh[so], sw[so], u.cin, 1, 1, 1, sh[so], sw[so], scut, u.cout, nullptr, 0, nullptr, 0);
       } else {
         gemm("gemm_convT2", u.convt, in, sh[si], sw[si], in_ld, 1, 0, 0, sh[si], sw[si], scut, u.cout, nullptr, 0, nullptr, 0, 1, u.cout);
       }
@@ -1132,6 +1159,9 @@ class Engine : public EngineBase {
       gemm("gemm_convPS", ps4, cat[0], sh[0], sw[0], 2 * cfg.dim[0], 1, 1, 1, sh[0], sw[0], ps4_buf, cpad4, nullptr, 0, nullptr, 0, 1,
            cpad4);
       gemm("gemm_conv3", fin4, ps4_buf, Hd, Wd, cpad4, 1, 1, 1, Hd, Wd, dec, ld_dec, nullptr, 0, nullptr, 0);
+    } else if (cfg.arch == WX_ARCH_CROSSFORMER_UPCONV) {
+      upsample2x(cat[0], sh[0], sw[0], 2 * cfg.dim[0], 2 * cfg.dim[0]);
+      gemm("gemm_conv3", up4c, upbuf, Hd, Wd, 2 * cfg.dim[0], 1, 1, 1, Hd, Wd, dec, ld_dec, nullptr, 0, nullptr, 0);
     } else {
       for (int q = 0; q < 4; ++q) {
         const int py = q >> 1, px = q & 1;

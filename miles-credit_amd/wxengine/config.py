@@ -91,8 +91,8 @@ class WXConfig:
                              "'wxformer' = PixelShuffle decoder)")
         if self.patch_height != 1 or self.patch_width != 1:
             raise ValueError("patch_height/patch_width > 1 (CubeEmbedding path) is not supported by the engine")
-        if self.upsample_v_conv and self.arch == "crossformer":
-            raise ValueError("upsample_v_conv=True decoder variant is not supported by the engine")
+        if self.upsample_v_conv and self.arch != "crossformer":
+            raise ValueError("upsample_v_conv belongs to model.type crossformer only (credit/models/crossformer.py:397)")
         if self.attention_type is not None:
             raise ValueError("decoder attention_type is not supported by the engine")
         if len(self.dim) != 4 or len(self.depth) != 4:
@@ -262,12 +262,18 @@ class WXConfig:
             conv("up_block4.2", (self.output_channels, self.output_channels, 3, 3))
             return spec
         for i, (ci, co) in enumerate(ups, start=1):
-            conv(f"up_block{i}.conv", (ci, co, 2, 2), transposed=True)
+            if self.upsample_v_conv:  # nn.Upsample + Conv2d 3x3 (credit/models/crossformer.py:87-89)
+                conv(f"up_block{i}.conv", (co, ci, 3, 3))
+            else:
+                conv(f"up_block{i}.conv", (ci, co, 2, 2), transposed=True)
             for j in (0, 3):
                 conv(f"up_block{i}.b.{j}", (co, co, 3, 3))
                 spec[f"up_block{i}.b.{j + 1}.weight"] = (co,)
                 spec[f"up_block{i}.b.{j + 1}.bias"] = (co,)
-        conv("up_block4", (2 * (last // 8), self.output_channels, 4, 4), transposed=True)
+        if self.upsample_v_conv:  # Sequential(Upsample, Conv2d) (credit/models/crossformer.py:560-570)
+            conv("up_block4.1", (self.output_channels, 2 * (last // 8), 3, 3))
+        else:
+            conv("up_block4", (2 * (last // 8), self.output_channels, 4, 4), transposed=True)
         return spec
 
     def num_params(self) -> int:
@@ -312,6 +318,8 @@ def named_config(name: str) -> WXConfig:
                   padding_conf=dict(activate=True, mode="earth", pad_lat=[40, 40], pad_lon=[80, 80]))
     elif name == "T0W":  # T0 geometry with the wxformer (PixelShuffle) decoder
         return WXConfig.from_model_conf(_t0_conf(base), arch="wxformer")
+    elif name == "T0U":  # T0 geometry, upsample_v_conv=True decoder (credit/models/crossformer.py:87-92, 560-570)
+        return WXConfig.from_model_conf(dict(_t0_conf(base), upsample_v_conv=True))
     elif name == "C1W":  # config/gen_2/examples/example-v2026.2.yml-style 1deg wxformer (C1 geometry, PS decoder)
         mc = dict(base, image_height=181, image_width=360, levels=18,
                   dim=[64, 128, 256, 512], depth=[2, 2, 4, 2], global_window_size=[8, 4, 2, 1], local_window_size=3,

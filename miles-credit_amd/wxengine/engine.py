@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwxengine.so")
 
 WX_ABI_VERSION = 2
-ARCH = {"crossformer": 0, "wxformer": 1}
+ARCH = {"crossformer": 0, "wxformer": 1, "crossformer_upconv": 2}
 PREC = {"fp32": 0, "bf16": 1}
 
 
@@ -133,7 +133,10 @@ def make_c_config(cfg: WXConfig, precision: str = "bf16", max_batch: int = 1) ->
     c.use_spectral_norm = int(cfg.use_spectral_norm)
     c.precision = PREC[precision]
     c.max_batch = max_batch
-    c.arch = ARCH[getattr(cfg, "arch", "crossformer")]
+    arch = getattr(cfg, "arch", "crossformer")
+    if arch == "crossformer" and getattr(cfg, "upsample_v_conv", False):
+        arch = "crossformer_upconv"
+    c.arch = ARCH[arch]
     return c
 
 

@@ -36,10 +36,10 @@ def keyed_normal(key: str, shape, seed: int = 0) -> np.ndarray:
     return g.standard_normal(size=shape, dtype=np.float32)
 
 
-def is_transposed_conv(prefix: str, arch: str = "crossformer") -> bool:
+def is_transposed_conv(prefix: str, arch: str = "crossformer", upconv: bool = False) -> bool:
     """ConvTranspose2d modules of the legacy decoder (reference crossformer.py:92,572):
-    their spectral norm is taken over weight dim 1.  The wxformer decoder has none."""
-    if arch == "wxformer":
+    their spectral norm is taken over weight dim 1.  The wxformer decoder and the upsample_v_conv variant have none."""
+    if arch == "wxformer" or upconv:
         return False
     return prefix == "up_block4" or (prefix.startswith("up_block") and prefix.endswith(".conv"))
 
@@ -78,7 +78,7 @@ def synth_state_dict(cfg, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
             continue
         base = key[: -len(".weight_u")]
         w = sd[base + ".weight_orig"]
-        transposed = is_transposed_conv(base, getattr(cfg, "arch", "crossformer"))
+        transposed = is_transposed_conv(base, getattr(cfg, "arch", "crossformer"), bool(getattr(cfg, "upsample_v_conv", False)))
         if transposed:  # ConvTranspose2d: spectral_norm(dim=1)
             w_mat = np.moveaxis(w, 1, 0).reshape(w.shape[1], -1)
         else:

@@ -47,6 +47,9 @@ def is_transposed_conv(prefix: str, sd: Optional[Dict] = None) -> bool:
     # "up_block1.sharp.*", which the legacy decoder never has)
     if sd is not None and any(k.startswith("up_block1.sharp.") for k in sd):
         return False
+    # upsample_v_conv=True (credit/models/crossformer.py:87-89, 560-570): Upsample + Conv2d, up_block4 is a Sequential
+    if sd is not None and any(k.startswith("up_block4.1.") for k in sd):
+        return False
     return prefix == "up_block4" or (prefix.startswith("up_block") and prefix.endswith(".conv"))
 
 
@@ -266,10 +269,30 @@ def group_norm_silu(x: Tensor, weight: Tensor, bias: Tensor, groups: int, eps: f
     return y * torch.sigmoid(y)
 
 
-def up_block(x: Tensor, sd: Dict, prefix: str, groups: int) -> Tensor:
-    """UpBlock.forward (credit/models/crossformer.py:107-122), upsample_v_conv=False, attention None."""
-    x = F.conv_transpose2d(x, folded_weight(sd, prefix + ".conv", x.dtype), _bias(sd, prefix + ".conv", x.dtype),
-                           stride=2)
+def upsample2x(x: Tensor) -> Tensor:
+    """nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False) restated (credit/models/crossformer.py:88):
+    src = max((dst + 0.5) / 2 - 0.5, 0) -> weights 0.75 / 0.25 with the border rows / columns replicated."""
+    def axis(t: Tensor, dim: int) -> Tensor:
+        n = t.shape[dim]
+        idx = torch.arange(n)
+        lo = t.index_select(dim, (idx - 1).clamp(min=0))
+        hi = t.index_select(dim, (idx + 1).clamp(max=n - 1))
+        even = 0.25 * lo + 0.75 * t      # dst 2i   : src = i - 0.25
+        odd = 0.75 * t + 0.25 * hi       # dst 2i+1 : src = i + 0.25
+        out = torch.stack([even, odd], dim=dim + 1)
+        shape = list(t.shape)
+        shape[dim] = 2 * n
+        return out.reshape(shape)
+    return axis(axis(x, x.dim() - 2), x.dim() - 1)
+
+
+def up_block(x: Tensor, sd: Dict, prefix: str, groups: int, upconv: bool = False) -> Tensor:
+    """UpBlock.forward (credit/models/crossformer.py:107-122), attention None; upconv = upsample_v_conv."""
+    if upconv:
+        x = F.conv2d(upsample2x(x), folded_weight(sd, prefix + ".conv", x.dtype), _bias(sd, prefix + ".conv", x.dtype), padding=1)
+    else:
+        x = F.conv_transpose2d(x, folded_weight(sd, prefix + ".conv", x.dtype), _bias(sd, prefix + ".conv", x.dtype),
+                               stride=2)
     shortcut = x
     for j in (0, 3):
         p = f"{prefix}.b.{j}"
@@ -356,7 +379,12 @@ def forward(cfg, sd: Dict, x, dtype=torch.float32, capture: Optional[Dict] = Non
                 capture[f"layers.{s}.1"] = z
             enc.append(z)
         g = cfg.dim[0]
-        ub = up_block_ps if getattr(cfg, "arch", "crossformer") == "wxformer" else up_block
+        upconv = bool(getattr(cfg, "upsample_v_conv", False))
+        if getattr(cfg, "arch", "crossformer") == "wxformer":
+            ub = up_block_ps
+        else:
+            def ub(t, sd_, prefix, groups):
+                return up_block(t, sd_, prefix, groups, upconv)
         z = ub(z, sd, "up_block1", g)
         if capture is not None and bi == 0:
             capture["up_block1"] = z
@@ -370,6 +398,8 @@ def forward(cfg, sd: Dict, x, dtype=torch.float32, capture: Optional[Dict] = Non
         if getattr(cfg, "arch", "crossformer") == "wxformer":  # wxformer/crossformer.py:817-830
             z = pixel_shuffle2(F.conv2d(z, folded_weight(sd, "up_block4.0", dtype), _bias(sd, "up_block4.0", dtype), padding=1))
             z = F.conv2d(z, folded_weight(sd, "up_block4.2", dtype), _bias(sd, "up_block4.2", dtype), padding=1)
+        elif upconv:  # crossformer.py:560-570
+            z = F.conv2d(upsample2x(z), folded_weight(sd, "up_block4.1", dtype), _bias(sd, "up_block4.1", dtype), padding=1)
         else:
             z = F.conv_transpose2d(z, folded_weight(sd, "up_block4", dtype), _bias(sd, "up_block4", dtype), stride=2,
                                    padding=1)

@@ -103,8 +103,10 @@ def test_config_validation_errors():
     WXConfig.from_model_conf(base)
     with pytest.raises(ValueError):  # window does not divide the stage map
         WXConfig.from_model_conf(dict(base, local_window_size=5))
-    with pytest.raises(ValueError):
-        WXConfig.from_model_conf(dict(base, upsample_v_conv=True))
+    up = WXConfig.from_model_conf(dict(base, upsample_v_conv=True))  # Upsample + Conv3x3 decoder (crossformer.py:87-92)
+    assert up.state_spec()["up_block1.conv.weight_orig"] == (128, 256, 3, 3) and "up_block4.1.weight_orig" in up.state_spec()
+    with pytest.raises(ValueError):  # the flag belongs to the legacy class only
+        WXConfig.from_model_conf(dict(base, upsample_v_conv=True), arch="wxformer")
     with pytest.raises(ValueError):
         WXConfig.from_model_conf(dict(base, padding_conf=dict(activate=True, mode="mirror", pad_lat=[6, 6], pad_lon=[12, 12])))
     with pytest.raises(ValueError):
@@ -133,7 +135,7 @@ def test_synthetic_weights_are_deterministic_and_warm():
 @pytest.mark.reference
 def test_state_spec_equals_reference_state_dict():
     import make_goldens
-    for name in ("T0", "T1", "T0W"):
+    for name in ("T0", "T1", "T0W", "T0U"):
         cfg = named_config(name)
         m = make_goldens.reference_model(cfg)
         ref = {k: tuple(v.shape) for k, v in m.state_dict().items()}

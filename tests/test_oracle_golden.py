@@ -45,14 +45,14 @@ def test_earth_pad_asymmetric_181x360():
 _SLOW = os.environ.get("WX_SLOW", "0") == "1"
 
 
-@pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W",
+@pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W", "T0U",
                                   pytest.param("C3", marks=pytest.mark.skipif(
                                       not _SLOW, reason="~1.5 min of CPU; set WX_SLOW=1"))])
 def test_forward_matches_reference_golden(name):
     g = _load(f"model_{name}.npz")
     cfg = named_config(name)
     sd = synth_state_dict(cfg)
-    cap = {} if name in ("T0", "T0W") else None
+    cap = {} if name in ("T0", "T0W", "T0U") else None
     y = O.forward(cfg, sd, synth_input(cfg), capture=cap)
     s = int(g["stride"])
     ys = y[0, :, 0, ::s, ::s].numpy()

@@ -43,6 +43,7 @@ def reference_model(cfg, post_conf=None):
         dim_head=cfg.dim_head, global_window_size=cfg.global_window_size,
         local_window_size=cfg.local_window_size[0], cross_embed_kernel_sizes=cfg.cross_embed_kernel_sizes,
         cross_embed_strides=cfg.cross_embed_strides, use_spectral_norm=cfg.use_spectral_norm, interp=cfg.interp,
+        **({"upsample_v_conv": True} if getattr(cfg, "upsample_v_conv", False) else {}),
         padding_conf={"activate": cfg.pad_activate, "mode": "earth", "pad_lat": list(cfg.pad_lat),
                       "pad_lon": list(cfg.pad_lon)},
         post_conf=post_conf or {"activate": False})
@@ -226,7 +227,7 @@ def fixers_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,C1,C3S,C3,T0W,C1W")
+    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,C1,C3S,C3,T0W,C1W,T0U")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -237,8 +238,8 @@ def main():
             glue_golden()
         elif item == "fixers":
             fixers_golden()
-        elif item in ("T0", "T1", "T0W"):
-            model_golden(item, 1, capture_layers=(item in ("T0", "T0W")))
+        elif item in ("T0", "T1", "T0W", "T0U"):
+            model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "C1W":
             model_golden(item, 8, False)
         elif item == "C1":
