@@ -127,12 +127,15 @@ int wx_step(wx_handle h, const float* x_dev, const float* frc_dev, float* y_dev,
  *   wx_post_set_grid  <-> physics_pressure_level(lon2d, lat2d, p_level, midpoint)   (credit/physics_core.py:75-134)
  *   wx_post_set_stats <-> load_transforms(..., scaler_only=True) for `denorm: True` fixers (per-channel mean/std)
  *   n_seconds = 3600 * data.lead_time_periods; rad_inds = {TOA solar, TOA OLR, surf solar, surf LR, surf SH, surf LH}
- * Hybrid-sigma grids are not built (WX_ERR_INVALID). */
+ *   wx_post_set_grid_sigma <-> physics_hybrid_sigma_level(lon2d, lat2d, coef_a, coef_b, midpoint) (:300-368); the fixers
+ *   added afterwards follow the reference's sigma branches (the mass fixer rescales channel `sp_ind`, gen1.py:355-375). */
 typedef struct wx_post* wx_post_handle;
 int wx_post_create(int H, int W, int c_in, int frames, int c_out, int device, wx_post_handle* out);
 int wx_post_destroy(wx_post_handle p);
 int wx_post_set_grid(wx_post_handle p, const float* lat2d, const float* lon2d, const float* p_levels, int n_levels,
                      int midpoint);
+int wx_post_set_grid_sigma(wx_post_handle p, const float* lat2d, const float* lon2d, const float* coef_a,
+                           const float* coef_b, int n_levels, int midpoint, int sp_ind);
 int wx_post_set_stats(wx_post_handle p, const float* mean_in, const float* std_in, const float* mean_out,
                       const float* std_out);
 int wx_post_add_tracer_fixer(wx_post_handle p, const int32_t* inds, const float* thres, const float* thres_max, int n,

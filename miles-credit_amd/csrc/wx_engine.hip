@@ -1329,6 +1329,14 @@ int wx_post_create(int H, int W, int c_in, int frames, int c_out, int device, wx
   });
 }
 int wx_post_destroy(wx_post_handle p) { return guarded([&] { delete p; }); }
+int wx_post_set_grid_sigma(wx_post_handle p, const float* lat2d, const float* lon2d, const float* coef_a, const float* coef_b,
+                           int n_levels, int midpoint, int sp_ind) {
+  return guarded([&] {
+    WX_NEEDP(p);
+    if (!lat2d || !lon2d || !coef_a || !coef_b) throw wx::ConfigError("wx_post_set_grid_sigma: null argument");
+    p->impl->set_grid_sigma(lat2d, lon2d, coef_a, coef_b, n_levels, midpoint, sp_ind);
+  });
+}
 int wx_post_set_grid(wx_post_handle p, const float* lat2d, const float* lon2d, const float* p_levels, int n_levels, int midpoint) {
   return guarded([&] { WX_NEEDP(p); if (!lat2d || !lon2d || !p_levels) throw wx::ConfigError("wx_post_set_grid: null argument"); p->impl->set_grid(lat2d, lon2d, p_levels, n_levels, midpoint); });
 }

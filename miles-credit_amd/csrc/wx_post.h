@@ -1,6 +1,8 @@
-// Conservation fixers of the reference PostBlock (credit/postblock/gen1.py) on the device, pressure-level grids:
+// Conservation fixers of the reference PostBlock (credit/postblock/gen1.py) on the device:
 //   TracerFixer :136-167, GlobalMassFixer :280-391, GlobalWaterFixer :489-569, GlobalEnergyFixer :704-822,
-// over credit/physics_core.py::physics_pressure_level (:75-297).  SURVEY.md §8(a) a12.
+// on pressure levels (credit/physics_core.py::physics_pressure_level :75-297) and on hybrid sigma-pressure levels
+// (physics_hybrid_sigma_level :300-520: p = a_l + b_l * surface pressure; the mass fixer then rescales the surface
+// pressure instead of q, gen1.py:355-375).  SURVEY.md §8(a) a12.
 //
 // Every global fixer is "column integrals -> a few area-weighted global sums -> one scalar ratio -> elementwise
 // correction".  HBM-bound integer-free float work: one thread per grid cell walks its column (loads are coalesced
@@ -23,7 +25,9 @@ struct FixParams {
   float* y;              // output [c_out][HW], fixed in place
   int hw, c_in, frames, c_out;
   const float* area;     // [HW]
-  const float* p;        // [n_p] pressure levels (Pa)
+  const float* p;        // [n_p] pressure levels (Pa)            (pressure grids)
+  const float *ca, *cb;  // [n_p] hybrid coefficients a (Pa), b    (sigma grids)
+  int sigma, sp_ind;     // sigma grid flag; surface-pressure channel (same index in x and y, gen1.py:306-308)
   int n_p, midpoint;
   const float *mean_in, *std_in, *mean_out, *std_out;  // nullptr unless denorm
   // op
@@ -48,17 +52,19 @@ __device__ inline float fx_out(const FixParams& p, int ch, int cell) {
   const float v = p.y[(int64_t)ch * p.hw + cell];
   return p.mean_out ? v * p.std_out[ch] + p.mean_out[ch] : v;
 }
+// pressure of level l in this column: the level table, or a_l + b_l * sp on hybrid sigma grids (physics_core.py:386)
+__device__ inline float lev_p(const FixParams& p, int l, float sp) { return p.sigma ? p.ca[l] + p.cb[l] * sp : p.p[l]; }
 // pressure integral of f(l) over levels [a, b): trapz over p[a..b-1], or midpoint with thickness diff(p)
 template <typename F>
-__device__ inline float col_integral(const FixParams& p, int a, int b, F f) {
+__device__ inline float col_integral(const FixParams& p, int a, int b, F f, float sp = 0.f) {
   float acc = 0.f;
   if (p.midpoint) {
-    for (int l = a; l < b; ++l) acc += f(l) * (p.p[l + 1] - p.p[l]);
+    for (int l = a; l < b; ++l) acc += f(l) * (lev_p(p, l + 1, sp) - lev_p(p, l, sp));
   } else {
     float prev = f(a);
     for (int l = a; l + 1 < b; ++l) {
       const float cur = f(l + 1);
-      acc += 0.5f * (prev + cur) * (p.p[l + 1] - p.p[l]);
+      acc += 0.5f * (prev + cur) * (lev_p(p, l + 1, sp) - lev_p(p, l, sp));
       prev = cur;
     }
   }
@@ -72,14 +78,33 @@ __global__ __launch_bounds__(256) void fix_reduce_kernel(const FixParams p) {
   if (cell < p.hw) {
     const double a = (double)p.area[cell];
     const int nl = p.nlev;
-    if (p.kind == 1) {
+    const float sp_in = p.sigma ? fx_in(p, p.sp_ind, cell) : 0.f, sp_pr = p.sigma ? fx_out(p, p.sp_ind, cell) : 0.f;
+    if (p.kind == 1 && p.sigma) {
+      // dry mass at t0 with the input surface pressure; at t1 split into the a- and b-parts of dp (gen1.py:357-371)
+      const float i0 = col_integral(p, 0, nl, [&](int l) { return 1.f - fx_in(p, p.q0 + l, cell); }, sp_in) / kGravity;
+      float pa = 0.f, pb = 0.f;
+      if (p.midpoint) {
+        for (int l = 0; l < nl; ++l) {
+          const float dry = 1.f - fx_out(p, p.q0 + l, cell);
+          pa += (p.ca[l + 1] - p.ca[l]) * dry;
+          pb += (p.cb[l + 1] - p.cb[l]) * dry;
+        }
+      } else {
+        for (int l = 0; l + 1 < nl; ++l) {
+          const float dry = 1.f - (fx_out(p, p.q0 + l, cell) + fx_out(p, p.q0 + l + 1, cell)) / 2.f;
+          pa += (p.ca[l + 1] - p.ca[l]) * dry;
+          pb += (p.cb[l + 1] - p.cb[l]) * dry;
+        }
+      }
+      s[0] = i0 * a; s[1] = (double)pa * a / (double)kGravity; s[2] = (double)(pb * sp_pr) * a / (double)kGravity;
+    } else if (p.kind == 1) {
       const float i0 = col_integral(p, 0, nl, [&](int l) { return 1.f - fx_in(p, p.q0 + l, cell); }) / kGravity;
       const float ih = col_integral(p, 0, p.ind_fix, [&](int l) { return 1.f - fx_out(p, p.q0 + l, cell); }) / kGravity;
       const float ifx = col_integral(p, p.ind_fix_start, nl, [&](int l) { return 1.f - fx_out(p, p.q0 + l, cell); }) / kGravity;
       s[0] = i0 * a; s[1] = ih * a; s[2] = ifx * a;
     } else if (p.kind == 2) {
-      const float t_in = col_integral(p, 0, nl, [&](int l) { return fx_in(p, p.q0 + l, cell); }) / kGravity;
-      const float t_pr = col_integral(p, 0, nl, [&](int l) { return fx_out(p, p.q0 + l, cell); }) / kGravity;
+      const float t_in = col_integral(p, 0, nl, [&](int l) { return fx_in(p, p.q0 + l, cell); }, sp_in) / kGravity;
+      const float t_pr = col_integral(p, 0, nl, [&](int l) { return fx_out(p, p.q0 + l, cell); }, sp_pr) / kGravity;
       s[0] = (double)((t_pr - t_in) / p.n_seconds) * a;
       s[1] = (double)(fx_out(p, p.evapor, cell) * kRhoWater / p.n_seconds) * a;
       s[2] = (double)(fx_out(p, p.precip, cell) * kRhoWater / p.n_seconds) * a;
@@ -91,12 +116,12 @@ __global__ __launch_bounds__(256) void fix_reduce_kernel(const FixParams p) {
         const float q = fx_in(p, p.q0 + l, cell), u = fx_in(p, p.U0 + l, cell), v = fx_in(p, p.V0 + l, cell);
         const float cp = (1.f - q) * kCpDry + q * kCpVapor;
         return cp * fx_in(p, p.T0 + l, cell) + (kLhWater * q + gph + 0.5f * (u * u + v * v));
-      }) / kGravity;
+      }, sp_in) / kGravity;
       const float te1 = col_integral(p, 0, nl, [&](int l) {
         const float q = fx_out(p, p.q0 + l, cell), u = fx_out(p, p.U0 + l, cell), v = fx_out(p, p.V0 + l, cell);
         const float cp = (1.f - q) * kCpDry + q * kCpVapor;
         return cp * fx_out(p, p.T0 + l, cell) + (kLhWater * q + gph + 0.5f * (u * u + v * v));
-      }) / kGravity;
+      }, sp_pr) / kGravity;
       s[0] = (double)rt * a; s[1] = (double)fs * a; s[2] = (double)te0 * a; s[3] = (double)te1 * a;
     }
   }
@@ -141,7 +166,9 @@ __global__ __launch_bounds__(256) void fix_apply_kernel(const FixParams p) {
     if (p.mean_out) v = (v - p.mean_out[ch]) / p.std_out[ch];
     p.y[(int64_t)ch * p.hw + cell] = v;
   };
-  if (p.kind == 1) {
+  if (p.kind == 1 && p.sigma) {
+    put(p.sp_ind, fx_out(p, p.sp_ind, cell) * r);   // gen1.py:373-375: sp_pred * sp_correct_ratio
+  } else if (p.kind == 1) {
     for (int l = p.ind_fix_start; l < p.nlev; ++l) put(p.q0 + l, 1.f - (1.f - fx_out(p, p.q0 + l, cell)) * r);
   } else if (p.kind == 2) {
     put(p.precip, fx_out(p, p.precip, cell) * r);
@@ -203,8 +230,8 @@ class PostBlock {
   }
   int h, w, cin, fr, cout, device, n_blocks = 0;
   std::vector<void*> allocs;
-  float *area = nullptr, *plev = nullptr;
-  int n_p = 0, midpoint = 0;
+  float *area = nullptr, *plev = nullptr, *coef_a = nullptr, *coef_b = nullptr;
+  int n_p = 0, midpoint = 0, sigma = 0, sp_ind = -1;
   float *mean_in = nullptr, *std_in = nullptr, *mean_out = nullptr, *std_out = nullptr;
   double *partial = nullptr, *sums = nullptr;
   float* ratio = nullptr;
@@ -227,6 +254,26 @@ class PostBlock {
   void set_grid(const float* lat2d, const float* lon2d, const float* p_levels, int n_levels, int mid) {
     if (n_levels < 2 || n_levels > kMaxLevels) throw std::runtime_error("wx_post_set_grid: 2..64 pressure levels");
     WX_HIP(hipSetDevice(device));
+    set_area(lat2d, lon2d);
+    plev = upload(p_levels, n_levels);
+    n_p = n_levels;
+    midpoint = mid;
+    sigma = 0;
+  }
+  // hybrid sigma-pressure grid: physics_hybrid_sigma_level(lon2d, lat2d, coef_a, coef_b, midpoint) (physics_core.py:314-368)
+  void set_grid_sigma(const float* lat2d, const float* lon2d, const float* ca, const float* cb, int n_levels, int mid, int sp) {
+    if (n_levels < 2 || n_levels > kMaxLevels) throw std::runtime_error("wx_post_set_grid_sigma: 2..64 levels");
+    if (sp < 0 || sp >= cout || sp >= cin) throw std::runtime_error("wx_post_set_grid_sigma: surface-pressure channel out of range");
+    WX_HIP(hipSetDevice(device));
+    set_area(lat2d, lon2d);
+    coef_a = upload(ca, n_levels);
+    coef_b = upload(cb, n_levels);
+    n_p = n_levels;
+    midpoint = mid;
+    sigma = 1;
+    sp_ind = sp;
+  }
+  void set_area(const float* lat2d, const float* lon2d) {
     std::vector<float> a((size_t)h * w);
     const float d2r = 3.14159265358979323846f / 180.f;
     auto sl = [&](int i, int j) { return std::sin(lat2d[(size_t)i * w + j] * d2r); };
@@ -247,9 +294,6 @@ class PostBlock {
         a[(size_t)i * w + j] = std::fabs((float)(kRadEarth * kRadEarth) * dphi * dlam);
       }
     area = upload(a.data(), a.size());
-    plev = upload(p_levels, n_levels);
-    n_p = n_levels;
-    midpoint = mid;
   }
   void set_stats(const float* mi, const float* si, const float* mo, const float* so) {
     WX_HIP(hipSetDevice(device));
@@ -322,7 +366,7 @@ class PostBlock {
       FixParams p;
       std::memset(&p, 0, sizeof(p));
       p.x = x; p.y = y; p.hw = hw; p.c_in = cin; p.frames = fr; p.c_out = cout;
-      p.area = area; p.p = plev; p.n_p = n_p; p.midpoint = midpoint;
+      p.area = area; p.p = plev; p.ca = coef_a; p.cb = coef_b; p.sigma = sigma; p.sp_ind = sp_ind; p.n_p = n_p; p.midpoint = midpoint;
       if (op.denorm) { p.mean_in = mean_in; p.std_in = std_in; p.mean_out = mean_out; p.std_out = std_out; }
       p.kind = op.kind; p.q0 = op.q0; p.nlev = op.nlev;
       p.ind_fix = n_p - op.fix_level_num + 1;                 // gen1.py:224 / :264

@@ -70,6 +70,8 @@ _PROTOTYPES = {
     "wx_post_create": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     "wx_post_destroy": ([C.c_void_p], C.c_int),
     "wx_post_set_grid": ([C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int], C.c_int),
+    "wx_post_set_grid_sigma": ([C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                C.c_int, C.c_int, C.c_int], C.c_int),
     "wx_post_set_stats": ([C.c_void_p] + [C.POINTER(C.c_float)] * 4, C.c_int),
     "wx_post_add_tracer_fixer": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int], C.c_int),
     "wx_post_add_mass_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_int),
@@ -314,6 +316,15 @@ class WXPostBlock:
     def set_grid(self, lat2d, lon2d, p_levels, midpoint: bool = False):
         la, lo, pl = _fp(lat2d), _fp(lon2d), _fp(p_levels)
         _check(self.lib.wx_post_set_grid(self._p, self._ptr(la), self._ptr(lo), self._ptr(pl), pl.size, int(midpoint)))
+
+    def set_grid_sigma(self, lat2d, lon2d, coef_a, coef_b, sp_ind: int, midpoint: bool = False):
+        """Hybrid sigma-pressure levels p = a + b * surface pressure (credit/physics_core.py:300-368); `sp_ind` is the
+        surface-pressure channel (same index in x and y, credit/postblock/gen1.py:306-308)."""
+        la, lo, ca, cb = _fp(lat2d), _fp(lon2d), _fp(coef_a), _fp(coef_b)
+        if ca.size != cb.size:
+            raise ValueError("coef_a and coef_b must have the same length")
+        _check(self.lib.wx_post_set_grid_sigma(self._p, self._ptr(la), self._ptr(lo), self._ptr(ca), self._ptr(cb), ca.size,
+                                               int(midpoint), int(sp_ind)))
 
     def set_stats(self, mean_in, std_in, mean_out, std_out):
         a = [_fp(v).ravel() for v in (mean_in, std_in, mean_out, std_out)]

@@ -90,16 +90,19 @@ class WXFormerHIP(_Base):
         for name in ("global_mass_fixer", "global_water_fixer", "global_energy_fixer"):
             sub = pc.get(name) or {}
             if sub.get("activate", False) and not sub.get("activate_outside_model", False):
-                if sub.get("grid_type", "pressure") != "pressure":
-                    raise ValueError(f"post_conf.{name}: only pressure-level grids are implemented by the HIP engine")
+                if sub.get("grid_type", "pressure") not in ("pressure", "sigma"):
+                    raise ValueError(f"post_conf.{name}: grid_type must be 'pressure' or 'sigma'")
                 out.append((name, sub))
         return out
 
-    def set_physics(self, lat2d, lon2d, p_levels, gph_surf=None, mean_in=None, std_in=None):
-        """What the reference reads from `post_conf.data.save_loc_physics` (lat/lon/levels, surface geopotential)
-        and, for `denorm: True` fixers, the INPUT-channel statistics (the output ones come from set_denorm)."""
+    def set_physics(self, lat2d, lon2d, p_levels=None, gph_surf=None, mean_in=None, std_in=None, coef_a=None, coef_b=None):
+        """What the reference reads from `post_conf.data.save_loc_physics` (lat/lon, pressure levels OR the hybrid
+        coefficients a/b of `grid_type: sigma`, surface geopotential) and, for `denorm: True` fixers, the INPUT-channel
+        statistics (the output ones come from set_denorm)."""
         self._physics = dict(lat2d=np.asarray(lat2d, np.float32), lon2d=np.asarray(lon2d, np.float32),
-                             p=np.asarray(p_levels, np.float32),
+                             p=None if p_levels is None else np.asarray(p_levels, np.float32),
+                             coef_a=None if coef_a is None else np.asarray(coef_a, np.float32),
+                             coef_b=None if coef_b is None else np.asarray(coef_b, np.float32),
                              gph=None if gph_surf is None else np.asarray(gph_surf, np.float32),
                              mean_in=mean_in, std_in=std_in)
         self._dirty = True
@@ -116,7 +119,20 @@ class WXFormerHIP(_Base):
         pb = WXPostBlock(cfg.out_hw[0], cfg.out_hw[1], cfg.base_input_channels, cfg.frames, cfg.base_output_channels,
                          device_index)
         midpoint = bool(fixers[0][1].get("midpoint", False))
-        pb.set_grid(ph["lat2d"], ph["lon2d"], ph["p"], midpoint)
+        sigma = fixers[0][1].get("grid_type", "pressure") == "sigma"
+        if any((c.get("grid_type", "pressure") == "sigma") != sigma for _, c in fixers):
+            raise ValueError("all global fixers must agree on `grid_type`")
+        if sigma:
+            if ph["coef_a"] is None or ph["coef_b"] is None:
+                raise WXEngineError("grid_type sigma: set_physics(..., coef_a=, coef_b=) first")
+            sp = {int(c["sp_inds"]) for _, c in fixers}
+            if len(sp) != 1:
+                raise ValueError("all global fixers must name the same surface-pressure channel (`sp_inds`)")
+            pb.set_grid_sigma(ph["lat2d"], ph["lon2d"], ph["coef_a"], ph["coef_b"], sp.pop(), midpoint)
+        else:
+            if ph["p"] is None:
+                raise WXEngineError("grid_type pressure: set_physics(..., p_levels=) first")
+            pb.set_grid(ph["lat2d"], ph["lon2d"], ph["p"], midpoint)
         if any(c.get("denorm", False) for _, c in fixers):
             if self._denorm is None or ph["mean_in"] is None:
                 raise WXEngineError("denorm fixers need set_denorm(mean, std) and set_physics(..., mean_in=, std_in=)")

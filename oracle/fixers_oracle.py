@@ -7,7 +7,10 @@ torch CPU; `dtype` selects fp32 (what the engine computes in, with fp64 global s
 Pinned by tests/golden/fixers_demo.npz (the reference classes run on their own `simple_demo` grid,
 tools/make_goldens.py --only fixers).
 
-Not reproduced (documented): hybrid-sigma grids; `concat_fix`'s quirk that DROPS the channels after the
+Hybrid sigma-pressure grids (physics_hybrid_sigma_level :300-520; fixer branches gen1.py:306-375, 527-533, 783-788) are
+restated by SigmaGrid + the *_sigma functions and pinned by tests/golden/fixers_sigma.npz.
+
+Not reproduced (documented): `concat_fix`'s quirk that DROPS the channels after the
 fixed block when it ends at N_vars-2 (gen1.py:1063-1071) — this restatement always keeps every channel.
 """
 from __future__ import annotations
@@ -150,6 +153,119 @@ def energy_fixer(y: torch.Tensor, x: torch.Tensor, grid: Grid, T_start: int, q_s
     e1 = cp1 * T1 + eq1
     te0 = grid.wsum(column_integral(e0, grid.p, grid.midpoint) / GRAVITY)
     te1 = grid.wsum(column_integral(e1, grid.p, grid.midpoint) / GRAVITY)
+    ratio = ((n_seconds * (r_t - f_s) + te0) / te1).to(y.dtype)
+    T_new = (e1 * ratio - eq1) / cp1
+    sl = slice(T_start, T_start + n_lev)
+    if stats:
+        mean, std = stats["out"]
+        T_new = (T_new - mean[sl].view(-1, 1, 1)) / std[sl].view(-1, 1, 1)
+    y[sl] = T_new
+    return y
+
+
+# --------------------------------------------------------------------------------------------------------------- #
+# hybrid sigma-pressure levels: p(l, cell) = a_l + b_l * surface_pressure(cell)   (credit/physics_core.py:300-368)
+# --------------------------------------------------------------------------------------------------------------- #
+class SigmaGrid:
+    def __init__(self, lat2d, lon2d, coef_a, coef_b, midpoint: bool = False, dtype=torch.float32):
+        self.area = cell_area(torch.as_tensor(lat2d).to(dtype), torch.as_tensor(lon2d).to(dtype))
+        self.a = torch.as_tensor(coef_a).to(dtype)
+        self.b = torch.as_tensor(coef_b).to(dtype)
+        self.midpoint = midpoint
+        self.dtype = dtype
+
+    def wsum(self, field: torch.Tensor) -> torch.Tensor:
+        return (field.double() * self.area.double()).sum()
+
+    def integral(self, q: torch.Tensor, sp: torch.Tensor) -> torch.Tensor:
+        """pressure_integral_midpoint / _trapz (physics_core.py:369-454): q [L or L-1, H, W], sp [H, W]."""
+        pressure = self.a.view(-1, 1, 1) + self.b.view(-1, 1, 1) * sp.unsqueeze(0)
+        dp = pressure.diff(dim=0)
+        if self.midpoint:
+            return (q * dp).sum(0)
+        return (0.5 * (q[:-1] + q[1:]) * dp).sum(0)
+
+
+def mass_fixer_sigma(y, x, grid: SigmaGrid, q_start: int, n_q: int, sp_ind: int, stats: Optional[Dict] = None):
+    """GlobalMassFixer, sigma grid (gen1.py:306-313, 355-375): the surface pressure is rescaled, q is untouched."""
+    y = y.clone()
+    qi = slice(q_start, q_start + n_q)
+    si = slice(sp_ind, sp_ind + 1)
+    if stats:
+        q_in, q_pr = _den(x[qi], *stats["in"], qi), _den(y[qi], *stats["out"], qi)
+        sp_in, sp_pr = _den(x[si], *stats["in"], si)[0], _den(y[si], *stats["out"], si)[0]
+    else:
+        q_in, q_pr, sp_in, sp_pr = x[qi], y[qi], x[sp_ind], y[sp_ind]
+    m0 = grid.wsum(grid.integral(1 - q_in, sp_in) / GRAVITY)
+    da, db = grid.a.diff().view(-1, 1, 1), grid.b.diff().view(-1, 1, 1)
+    dry = (1 - q_pr) if grid.midpoint else 1 - (q_pr[:-1] + q_pr[1:]) / 2
+    p_dry_a, p_dry_b = (da * dry).sum(0), (db * dry).sum(0)
+    mass_a = grid.wsum(p_dry_a) / GRAVITY
+    mass_b = grid.wsum(p_dry_b * sp_pr) / GRAVITY
+    ratio = ((m0 - mass_a) / mass_b).to(y.dtype)
+    sp_new = sp_pr * ratio
+    if stats:
+        mean, std = stats["out"]
+        sp_new = (sp_new - mean[sp_ind]) / std[sp_ind]
+    y[sp_ind] = sp_new
+    return y
+
+
+def water_fixer_sigma(y, x, grid: SigmaGrid, q_start: int, n_q: int, precip_ind: int, evapor_ind: int, sp_ind: int,
+                      n_seconds: float, stats: Optional[Dict] = None):
+    """GlobalWaterFixer, sigma grid (gen1.py:515-533): column water with each state's own surface pressure."""
+    y = y.clone()
+    qi = slice(q_start, q_start + n_q)
+    pi_, ei, si = slice(precip_ind, precip_ind + 1), slice(evapor_ind, evapor_ind + 1), slice(sp_ind, sp_ind + 1)
+    if stats:
+        q_in, q_pr = _den(x[qi], *stats["in"], qi), _den(y[qi], *stats["out"], qi)
+        precip, evapor = _den(y[pi_], *stats["out"], pi_)[0], _den(y[ei], *stats["out"], ei)[0]
+        sp_in, sp_pr = _den(x[si], *stats["in"], si)[0], _den(y[si], *stats["out"], si)[0]
+    else:
+        q_in, q_pr, precip, evapor, sp_in, sp_pr = x[qi], y[qi], y[precip_ind], y[evapor_ind], x[sp_ind], y[sp_ind]
+    twc_in = grid.integral(q_in, sp_in) / GRAVITY
+    twc_pr = grid.integral(q_pr, sp_pr) / GRAVITY
+    twc_sum = grid.wsum((twc_pr - twc_in) / n_seconds)
+    e_sum = grid.wsum(evapor * RHO_WATER / n_seconds)
+    p_sum = grid.wsum(precip * RHO_WATER / n_seconds)
+    ratio = ((p_sum + (-twc_sum - e_sum - p_sum)) / p_sum).to(y.dtype)
+    precip = precip * ratio
+    if stats:
+        mean, std = stats["out"]
+        precip = (precip - mean[precip_ind]) / std[precip_ind]
+    y[precip_ind] = precip
+    return y
+
+
+def energy_fixer_sigma(y, x, grid: SigmaGrid, T_start: int, q_start: int, U_start: int, V_start: int, n_lev: int,
+                       toa_inds: Sequence[int], surf_rad_inds: Sequence[int], surf_flux_inds: Sequence[int], sp_ind: int,
+                       gph_surf: torch.Tensor, n_seconds: float, stats: Optional[Dict] = None):
+    """GlobalEnergyFixer, sigma grid (gen1.py:744-788)."""
+    y = y.clone()
+
+    def lev(t, s, which):
+        sl = slice(s, s + n_lev)
+        return _den(t[sl], *stats[which], sl) if stats else t[sl]
+
+    def one(t, i, which):
+        sl = slice(i, i + 1)
+        return (_den(t[sl], *stats[which], sl) if stats else t[sl])[0]
+
+    T0, q0, U0, V0 = (lev(x, s, "in") for s in (T_start, q_start, U_start, V_start))
+    T1, q1, U1, V1 = (lev(y, s, "out") for s in (T_start, q_start, U_start, V_start))
+    sp_in, sp_pr = one(x, sp_ind, "in"), one(y, sp_ind, "out")
+    cp0 = (1 - q0) * CP_DRY + q0 * CP_VAPOR
+    cp1 = (1 - q1) * CP_DRY + q1 * CP_VAPOR
+    g = gph_surf.to(y.dtype)
+    eq0 = LH_WATER * q0 + g + 0.5 * (U0 ** 2 + V0 ** 2)
+    eq1 = LH_WATER * q1 + g + 0.5 * (U1 ** 2 + V1 ** 2)
+    r_t = grid.wsum((one(y, toa_inds[0], "out") + one(y, toa_inds[1], "out")) / n_seconds)
+    f_s = grid.wsum((one(y, surf_rad_inds[0], "out") + one(y, surf_rad_inds[1], "out") + one(y, surf_flux_inds[0], "out")
+                     + one(y, surf_flux_inds[1], "out")) / n_seconds)
+    e0 = cp0 * T0 + eq0
+    e1 = cp1 * T1 + eq1
+    te0 = grid.wsum(grid.integral(e0, sp_in) / GRAVITY)
+    te1 = grid.wsum(grid.integral(e1, sp_pr) / GRAVITY)
     ratio = ((n_seconds * (r_t - f_s) + te0) / te1).to(y.dtype)
     T_new = (e1 * ratio - eq1) / cp1
     sl = slice(T_start, T_start + n_lev)

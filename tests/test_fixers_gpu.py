@@ -147,3 +147,43 @@ def test_post_errors():
         pb.add_mass_fixer(7, 3, denorm=True)
     with pytest.raises(WXEngineError, match="out of range"):
         pb.add_water_fixer(7, 99, 35, 21600.0)
+
+
+@pytest.mark.parametrize("midpoint", [False, True])
+def test_sigma_fixers_match_reference_golden(midpoint):
+    """Hybrid sigma-pressure grid (wx_post_set_grid_sigma) against the reference's sigma branches (fixers_sigma.npz)."""
+    from test_fixers_oracle import SIGMA_GOLD, sigma_variant
+    g = np.load(SIGMA_GOLD)
+    tag = "mid" if midpoint else "trapz"
+    x, y, nl = sigma_variant(g, midpoint)
+    lat2d, lon2d, _ = demo_latlon()
+    ns, sp = 6 * 3600.0, 4 * nl + 8
+    rad = [4 * nl + k for k in range(6)]
+    xd = x[:, None].contiguous().cuda()
+
+    def run(build):
+        pb = WXPostBlock(10, 18, x.shape[0], 1, y.shape[0])
+        pb.set_grid_sigma(lat2d, lon2d, g["coef_a"], g["coef_b"], sp, midpoint)
+        build(pb)
+        yd = y.clone().cuda()
+        pb.apply(xd, yd)
+        torch.cuda.synchronize()
+        return yd.cpu().numpy()
+
+    ym = run(lambda pb: pb.add_mass_fixer(nl, 3))
+    yw = run(lambda pb: pb.add_water_fixer(nl, 4 * nl + 6, 4 * nl + 7, ns))
+    ye = run(lambda pb: pb.add_energy_fixer(0, nl, 2 * nl, 3 * nl, rad, g["gph"], ns))
+
+    def chain(pb):
+        pb.add_mass_fixer(nl, 3)
+        pb.add_water_fixer(nl, 4 * nl + 6, 4 * nl + 7, ns)
+        pb.add_energy_fixer(0, nl, 2 * nl, 3 * nl, rad, g["gph"], ns)
+    yc = run(chain)
+    assert rel(ym[sp], g[f"{tag}_mass"][sp]) < 5e-6
+    np.testing.assert_array_equal(ym[:sp], y[:sp].numpy())   # on sigma grids the mass fixer leaves q alone
+    assert rel(yw[4 * nl + 6], g[f"{tag}_water"][4 * nl + 6]) < 5e-5
+    assert rel(ye[:nl], g[f"{tag}_energy"][:nl]) < 5e-5
+    for blk, tol in ((slice(0, nl), 1e-4), (slice(sp, sp + 1), 1e-5), (slice(4 * nl + 6, 4 * nl + 7), 2e-3)):
+        assert rel(yc[blk], g[f"{tag}_chain"][blk]) < tol
+    with pytest.raises(WXEngineError):  # the surface-pressure channel must exist
+        WXPostBlock(10, 18, x.shape[0], 1, y.shape[0]).set_grid_sigma(lat2d, lon2d, g["coef_a"], g["coef_b"], 999, midpoint)

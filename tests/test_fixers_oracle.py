@@ -90,3 +90,40 @@ def test_cell_area_matches_torch_gradient():
     d_lam = (d_lam + torch.pi) % (2 * torch.pi) - torch.pi
     want = torch.abs(F.RAD_EARTH ** 2 * d_phi * d_lam)
     np.testing.assert_allclose(F.cell_area(lat, lon).numpy(), want.numpy(), rtol=2e-5)  # fp32 edge stencils
+
+
+# ---- hybrid sigma-pressure grid (tests/golden/fixers_sigma.npz, tools/make_goldens.py --only sigma) -----------------
+SIGMA_GOLD = os.path.join(os.path.dirname(__file__), "golden", "fixers_sigma.npz")
+
+
+def sigma_variant(g, midpoint):
+    L = 7
+    nl = L - 1 if midpoint else L
+    H, W = g["gph"].shape
+    x = np.concatenate([g["x"][b * L:b * L + nl] for b in range(4)] + [np.zeros((8, 2, H, W), np.float32), g["sp_x"]], 0)[:, -1]
+    y = np.concatenate([g["y"][b * L:b * L + nl] for b in range(4)] + [g["y"][28:], g["sp_y"]], 0)
+    return torch.from_numpy(x), torch.from_numpy(y), nl
+
+
+@pytest.mark.parametrize("midpoint", [False, True])
+def test_sigma_fixers_match_reference(midpoint):
+    g = np.load(SIGMA_GOLD)
+    tag = "mid" if midpoint else "trapz"
+    x, y, nl = sigma_variant(g, midpoint)
+    lat = np.array([90, 70, 50, 30, 10, -10, -30, -50, -70, -90], dtype=np.float64)
+    lon2d, lat2d = np.meshgrid(np.arange(0, 360, 20, dtype=np.float64), lat)
+    grid = F.SigmaGrid(lat2d, lon2d, g["coef_a"], g["coef_b"], midpoint=midpoint)
+    gph = torch.from_numpy(g["gph"])
+    ns, sp = 6 * 3600.0, 4 * nl + 8
+    rad = ((4 * nl, 4 * nl + 1), (4 * nl + 2, 4 * nl + 3), (4 * nl + 4, 4 * nl + 5))
+    ym = F.mass_fixer_sigma(y, x, grid, nl, nl, sp)
+    yw = F.water_fixer_sigma(y, x, grid, nl, nl, 4 * nl + 6, 4 * nl + 7, sp, ns)
+    ye = F.energy_fixer_sigma(y, x, grid, 0, nl, 2 * nl, 3 * nl, nl, *rad, sp, gph, ns)
+    yc = F.energy_fixer_sigma(F.water_fixer_sigma(F.mass_fixer_sigma(y, x, grid, nl, nl, sp), x, grid, nl, nl, 4 * nl + 6,
+                                                  4 * nl + 7, sp, ns), x, grid, 0, nl, 2 * nl, 3 * nl, nl, *rad, sp, gph, ns)
+    assert rel(ym[sp].numpy(), g[f"{tag}_mass"][sp]) < 5e-6          # surface pressure rescaled
+    np.testing.assert_array_equal(ym[:sp].numpy(), y[:sp].numpy())  # q untouched on sigma grids
+    assert rel(yw[4 * nl + 6].numpy(), g[f"{tag}_water"][4 * nl + 6]) < 5e-5
+    assert rel(ye[:nl].numpy(), g[f"{tag}_energy"][:nl]) < 5e-5
+    for blk, tol in ((slice(0, nl), 1e-4), (slice(sp, sp + 1), 1e-5), (slice(4 * nl + 6, 4 * nl + 7), 2e-3)):
+        assert rel(yc[blk].numpy(), g[f"{tag}_chain"][blk]) < tol

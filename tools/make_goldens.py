@@ -225,9 +225,72 @@ def fixers_golden():
     np.savez_compressed(os.path.join(GOLD, "fixers_demo.npz"), **out)
 
 
+SIGMA_A = np.array([200.0, 5000.0, 12000.0, 14000.0, 9000.0, 3000.0, 0.0], dtype=np.float32)       # Pa
+SIGMA_B = np.array([0.0, 0.0, 0.08, 0.3, 0.6, 0.88, 1.0], dtype=np.float32)
+
+
+def fixers_sigma_golden():
+    """The same three fixers on a hybrid sigma-pressure grid (gen1.py sigma branches).  The reference reads its grid
+    from `save_loc_physics` through xarray (absent here): `get_forward_data` is replaced by an in-memory stand-in that
+    serves the arrays this script defines -- the fixer classes and physics_hybrid_sigma_level run unmodified."""
+    import credit.postblock.gen1 as G
+    x_np, y_np = fixer_inputs(seed=12)
+    g = np.random.Generator(np.random.Philox(key=[12, 5]))
+    H, W, L = 10, 18, 7
+    sp_x = (1.0e5 + 2.0e3 * g.standard_normal((1, 2, H, W))).astype(np.float32)
+    sp_y = (1.0e5 + 2.0e3 * g.standard_normal((1, H, W))).astype(np.float32)
+    gph = (50.0 + 20.0 * g.standard_normal((H, W))).astype(np.float32)
+    lat = np.array([90, 70, 50, 30, 10, -10, -30, -50, -70, -90], dtype=np.float64)
+    lon = np.arange(0, 360, 20, dtype=np.float64)
+    lon2d, lat2d = np.meshgrid(lon, lat)
+
+    class _V:
+        def __init__(self, a):
+            self.values = a
+    fake = {"lon2d": _V(lon2d), "lat2d": _V(lat2d), "coef_a": _V(SIGMA_A), "coef_b": _V(SIGMA_B), "gph": _V(gph)}
+    G.get_forward_data = lambda _f: fake
+    out = {"x": x_np, "y": y_np, "sp_x": sp_x, "sp_y": sp_y, "gph": gph, "coef_a": SIGMA_A, "coef_b": SIGMA_B}
+    for midpoint in (False, True):
+        nl = L - 1 if midpoint else L
+        tag = "mid" if midpoint else "trapz"
+        xs = np.concatenate([x_np[b * L:b * L + nl] for b in range(4)] + [sp_x], 0)            # [4 nl + 1, 2, H, W]
+        ys = np.concatenate([y_np[b * L:b * L + nl] for b in range(4)] + [y_np[28:], sp_y], 0)  # [4 nl + 8 + 1, H, W]
+        # SP sits at the same index in x and y (gen1.py:306-308): pad x with zero channels up to y's SP index
+        sp_ind = 4 * nl + 8
+        xs = np.concatenate([xs[:4 * nl], np.zeros((8, 2, H, W), np.float32), xs[4 * nl:]], 0)
+        x = torch.from_numpy(xs)[None]
+        y = torch.from_numpy(ys)[None, :, None]
+        base = {"simple_demo": False, "denorm": False, "grid_type": "sigma", "midpoint": midpoint, "activate": True,
+                "activate_outside_model": False, "lon_lat_level_name": ["lon2d", "lat2d", "coef_a", "coef_b"],
+                "sp_inds": sp_ind}
+        q0 = nl
+        mass = dict(base, fix_level_num=3, q_inds=list(range(q0, q0 + nl)))
+        data = {"lead_time_periods": 6, "save_loc_physics": "in-memory.nc"}
+        conf_m = {"global_mass_fixer": mass, "data": data}
+        conf_w = {"global_mass_fixer": mass, "data": data,
+                  "global_water_fixer": dict(base, q_inds=list(range(q0, q0 + nl)), precip_ind=4 * nl + 6, evapor_ind=4 * nl + 7)}
+        conf_e = {"global_mass_fixer": mass, "data": data,
+                  "global_energy_fixer": dict(base, T_inds=list(range(0, nl)), q_inds=list(range(q0, q0 + nl)),
+                                              U_inds=list(range(2 * nl, 3 * nl)), V_inds=list(range(3 * nl, 4 * nl)),
+                                              TOA_rad_inds=[4 * nl, 4 * nl + 1], surf_rad_inds=[4 * nl + 2, 4 * nl + 3],
+                                              surf_flux_inds=[4 * nl + 4, 4 * nl + 5], surface_geopotential_name=["gph"])}
+        with torch.no_grad():
+            ym = G.GlobalMassFixer(conf_m)({"y_pred": y.clone(), "x": x.clone()})["y_pred"]
+            yw = G.GlobalWaterFixer(conf_w)({"y_pred": y.clone(), "x": x.clone()})["y_pred"]
+            ye = G.GlobalEnergyFixer(conf_e)({"y_pred": y.clone(), "x": x.clone()})["y_pred"]
+            yc = G.GlobalEnergyFixer(conf_e)(G.GlobalWaterFixer(conf_w)(G.GlobalMassFixer(conf_m)(
+                {"y_pred": y.clone(), "x": x.clone()})))["y_pred"]
+        for name, t in (("mass", ym), ("water", yw), ("energy", ye), ("chain", yc)):
+            assert t.shape == y.shape, (name, t.shape)
+            out[f"{tag}_{name}"] = t[0, :, 0].double().numpy()
+        print(f"[golden] sigma fixers {tag}: mass dSP max {float((ym - y).abs().max()):.3e}  water dP max "
+              f"{float((yw - y).abs().max()):.3e}  energy dT max {float((ye - y).abs().max()):.3e}")
+    np.savez_compressed(os.path.join(GOLD, "fixers_sigma.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,C1,C3S,C3,T0W,C1W,T0U")
+    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,C1,C3S,C3,T0W,C1W,T0U")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -238,6 +301,8 @@ def main():
             glue_golden()
         elif item == "fixers":
             fixers_golden()
+        elif item == "sigma":
+            fixers_sigma_golden()
         elif item in ("T0", "T1", "T0W", "T0U"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "C1W":
