@@ -144,6 +144,10 @@ int wx_post_add_mass_fixer(wx_post_handle p, int q_start, int fix_level_num, int
 int wx_post_add_water_fixer(wx_post_handle p, int q_start, int precip_ind, int evapor_ind, float n_seconds, int denorm);
 int wx_post_add_energy_fixer(wx_post_handle p, int T_start, int q_start, int U_start, int V_start,
                              const int32_t rad_inds[6], const float* gph_surf, float n_seconds, int denorm);
+/* GlobalEnergyFixerUpDown (credit/postblock/gen1.py:825-1030): flux_inds = [TOA down solar, TOA up solar, TOA up OLR,
+ * surface down solar, surface up solar, surface down LW, surface up LW, SH, LH]. */
+int wx_post_add_energy_fixer_updown(wx_post_handle p, int T_start, int q_start, int U_start, int V_start,
+                                    const int32_t flux_inds[9], const float* gph_surf, float n_seconds, int denorm);
 int wx_post_apply(wx_post_handle p, const float* x_dev, float* y_dev, void* stream);
 /* Run `p` inside wx_forward / wx_step (after the tail, before y_phys and x_next); NULL detaches.  The engine does not
  * take ownership. */

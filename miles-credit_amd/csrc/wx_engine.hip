@@ -1352,6 +1352,14 @@ int wx_post_add_mass_fixer(wx_post_handle p, int q_start, int fix_level_num, int
 int wx_post_add_water_fixer(wx_post_handle p, int q_start, int precip_ind, int evapor_ind, float n_seconds, int denorm) {
   return guarded([&] { WX_NEEDP(p); p->impl->add_water(q_start, precip_ind, evapor_ind, n_seconds, denorm); });
 }
+int wx_post_add_energy_fixer_updown(wx_post_handle p, int T_start, int q_start, int U_start, int V_start, const int32_t flux_inds[9],
+                                    const float* gph_surf, float n_seconds, int denorm) {
+  return guarded([&] {
+    WX_NEEDP(p);
+    if (!flux_inds || !gph_surf) throw wx::ConfigError("wx_post_add_energy_fixer_updown: null argument");
+    p->impl->add_energy_updown(T_start, q_start, U_start, V_start, flux_inds, gph_surf, n_seconds, denorm);
+  });
+}
 int wx_post_add_energy_fixer(wx_post_handle p, int T_start, int q_start, int U_start, int V_start, const int32_t rad_inds[6],
                              const float* gph_surf, float n_seconds, int denorm) {
   return guarded([&] { WX_NEEDP(p); if (!rad_inds || !gph_surf) throw wx::ConfigError("wx_post_add_energy_fixer: null argument"); p->impl->add_energy(T_start, q_start, U_start, V_start, rad_inds, gph_surf, n_seconds, denorm); });

@@ -35,7 +35,11 @@ struct FixParams {
   int q0, nlev;          // q block start / levels carried per 3-D variable
   int ind_fix, ind_fix_start;
   int precip, evapor;
-  int T0, U0, V0, toa0, toa1, sr0, sr1, sf0, sf1;
+  int T0, U0, V0;
+  // energy fixers: R_T = sum_k toa_s[k] * y[toa_i[k]], F_S = sum_k srf_s[k] * y[srf_i[k]] (left to right, as the reference
+  // writes them: GlobalEnergyFixer gen1.py:762-768 all +; GlobalEnergyFixerUpDown :982-994 with the up/down signs)
+  int toa_n, srf_n, toa_i[4], srf_i[8];
+  float toa_s[4], srf_s[8];
   const float* gph;      // [HW]
   float n_seconds;
   double* partial;       // [blocks][4]
@@ -110,8 +114,11 @@ __global__ __launch_bounds__(256) void fix_reduce_kernel(const FixParams p) {
       s[2] = (double)(fx_out(p, p.precip, cell) * kRhoWater / p.n_seconds) * a;
     } else {
       const float gph = p.gph[cell];
-      const float rt = (fx_out(p, p.toa0, cell) + fx_out(p, p.toa1, cell)) / p.n_seconds;
-      const float fs = (fx_out(p, p.sr0, cell) + fx_out(p, p.sr1, cell) + fx_out(p, p.sf0, cell) + fx_out(p, p.sf1, cell)) / p.n_seconds;
+      float rt = p.toa_s[0] * fx_out(p, p.toa_i[0], cell), fs = p.srf_s[0] * fx_out(p, p.srf_i[0], cell);
+      for (int k = 1; k < p.toa_n; ++k) rt += p.toa_s[k] * fx_out(p, p.toa_i[k], cell);
+      for (int k = 1; k < p.srf_n; ++k) fs += p.srf_s[k] * fx_out(p, p.srf_i[k], cell);
+      rt /= p.n_seconds;
+      fs /= p.n_seconds;
       const float te0 = col_integral(p, 0, nl, [&](int l) {
         const float q = fx_in(p, p.q0 + l, cell), u = fx_in(p, p.U0 + l, cell), v = fx_in(p, p.V0 + l, cell);
         const float cp = (1.f - q) * kCpDry + q * kCpVapor;
@@ -205,7 +212,8 @@ struct PostOp {
   int kind = 0;  // 0 tracer, 1 mass, 2 water, 3 energy
   int denorm = 0;
   int q0 = 0, nlev = 0, fix_level_num = 0, precip = 0, evapor = 0, T0 = 0, U0 = 0, V0 = 0;
-  int toa0 = 0, toa1 = 0, sr0 = 0, sr1 = 0, sf0 = 0, sf1 = 0;
+  int toa_n = 0, srf_n = 0, toa_i[4] = {0, 0, 0, 0}, srf_i[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float toa_s[4] = {0, 0, 0, 0}, srf_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float n_seconds = 0.f;
   float* gph = nullptr;
   int n_tr = 0;
@@ -345,10 +353,29 @@ class PostBlock {
     WX_HIP(hipSetDevice(device));
     PostOp op;
     op.kind = 3; op.denorm = denorm; op.T0 = T0; op.q0 = q0; op.U0 = U0; op.V0 = V0; op.nlev = levels_carried();
-    op.toa0 = rad[0]; op.toa1 = rad[1]; op.sr0 = rad[2]; op.sr1 = rad[3]; op.sf0 = rad[4]; op.sf1 = rad[5];
+    op.toa_n = 2; op.srf_n = 4;
+    for (int k = 0; k < 2; ++k) { op.toa_i[k] = rad[k]; op.toa_s[k] = 1.f; }
+    for (int k = 0; k < 4; ++k) { op.srf_i[k] = rad[2 + k]; op.srf_s[k] = 1.f; }
+    finish_energy(op, T0, q0, U0, V0, gph_surf, n_seconds);
+  }
+  // GlobalEnergyFixerUpDown (gen1.py:825-1030): flux = [TOA down solar, TOA up solar, TOA up OLR, surf down solar, surf up solar,
+  // surf down LW, surf up LW, SH, LH];  R_T = d - u - olr,  F_S = ds - us + dl - ul - sh - lh
+  void add_energy_updown(int T0, int q0, int U0, int V0, const int32_t flux[9], const float* gph_surf, float n_seconds, int denorm) {
+    need_grid(); need_stats(denorm);
+    WX_HIP(hipSetDevice(device));
+    PostOp op;
+    op.kind = 3; op.denorm = denorm; op.T0 = T0; op.q0 = q0; op.U0 = U0; op.V0 = V0; op.nlev = levels_carried();
+    const float ts[3] = {1.f, -1.f, -1.f}, ss[6] = {1.f, -1.f, 1.f, -1.f, -1.f, -1.f};
+    op.toa_n = 3; op.srf_n = 6;
+    for (int k = 0; k < 3; ++k) { op.toa_i[k] = flux[k]; op.toa_s[k] = ts[k]; }
+    for (int k = 0; k < 6; ++k) { op.srf_i[k] = flux[3 + k]; op.srf_s[k] = ss[k]; }
+    finish_energy(op, T0, q0, U0, V0, gph_surf, n_seconds);
+  }
+  void finish_energy(PostOp& op, int T0, int q0, int U0, int V0, const float* gph_surf, float n_seconds) {
     op.n_seconds = n_seconds;
     for (int s : {T0, q0, U0, V0}) { check_block(s, op.nlev, cout, "3-D block (output)"); check_block(s, op.nlev, cin, "3-D block (input)"); }
-    for (int k = 0; k < 6; ++k) check_block(rad[k], 1, cout, "flux channel");
+    for (int k = 0; k < op.toa_n; ++k) check_block(op.toa_i[k], 1, cout, "flux channel");
+    for (int k = 0; k < op.srf_n; ++k) check_block(op.srf_i[k], 1, cout, "flux channel");
     op.gph = upload(gph_surf, (size_t)h * w);
     ops.push_back(op);
   }
@@ -373,7 +400,9 @@ class PostBlock {
       p.ind_fix_start = midpoint ? p.ind_fix : p.ind_fix - 1;  // gen1.py:267-270
       p.precip = op.precip; p.evapor = op.evapor;
       p.T0 = op.T0; p.U0 = op.U0; p.V0 = op.V0;
-      p.toa0 = op.toa0; p.toa1 = op.toa1; p.sr0 = op.sr0; p.sr1 = op.sr1; p.sf0 = op.sf0; p.sf1 = op.sf1;
+      p.toa_n = op.toa_n; p.srf_n = op.srf_n;
+      for (int k = 0; k < 4; ++k) { p.toa_i[k] = op.toa_i[k]; p.toa_s[k] = op.toa_s[k]; }
+      for (int k = 0; k < 8; ++k) { p.srf_i[k] = op.srf_i[k]; p.srf_s[k] = op.srf_s[k]; }
       p.gph = op.gph; p.n_seconds = op.n_seconds;
       p.partial = partial; p.sums = sums; p.ratio = ratio; p.n_blocks = n_blocks;
       hipLaunchKernelGGL(fix_reduce_kernel, dim3(n_blocks), dim3(256), 0, stream, p);

@@ -76,6 +76,8 @@ _PROTOTYPES = {
     "wx_post_add_tracer_fixer": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int], C.c_int),
     "wx_post_add_mass_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_int),
     "wx_post_add_water_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int], C.c_int),
+    "wx_post_add_energy_fixer_updown": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                         C.c_float, C.c_int], C.c_int),
     "wx_post_add_energy_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_int], C.c_int),
     "wx_post_apply": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "wx_attach_postblock": ([C.c_void_p, C.c_void_p], C.c_int),
@@ -349,6 +351,16 @@ class WXPostBlock:
         g = _fp(gph_surf)
         _check(self.lib.wx_post_add_energy_fixer(self._p, T_start, q_start, U_start, V_start,
                                                  r.ctypes.data_as(C.POINTER(C.c_int32)), self._ptr(g), float(n_seconds), int(denorm)))
+
+    def add_energy_fixer_updown(self, T_start, q_start, U_start, V_start, flux_inds, gph_surf, n_seconds, denorm=False):
+        """GlobalEnergyFixerUpDown (credit/postblock/gen1.py:825-1030); flux_inds = [TOA down solar, TOA up solar, TOA up OLR,
+        surf down solar, surf up solar, surf down LW, surf up LW, SH, LH]."""
+        r = np.ascontiguousarray(flux_inds, dtype=np.int32)
+        assert r.size == 9
+        g = _fp(gph_surf)
+        _check(self.lib.wx_post_add_energy_fixer_updown(self._p, T_start, q_start, U_start, V_start,
+                                                        r.ctypes.data_as(C.POINTER(C.c_int32)), self._ptr(g), float(n_seconds),
+                                                        int(denorm)))
 
     def apply(self, x, y):
         """x [C_in, frames, H, W], y [C_out, H, W] float32 CUDA tensors (leading batch dim of 1 allowed); y is fixed in place."""

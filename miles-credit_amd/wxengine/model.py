@@ -71,8 +71,6 @@ class WXFormerHIP(_Base):
             return None
         if (post_conf.get("skebs") or {}).get("activate", False):
             raise ValueError("post_conf.skebs is not implemented by the HIP engine")
-        if (post_conf.get("global_energy_fixer_updown") or {}).get("activate", False):
-            raise ValueError("post_conf.global_energy_fixer_updown is not implemented by the HIP engine")
         tf = post_conf.get("tracer_fixer") or {}
         if not tf.get("activate", False):
             return None
@@ -87,7 +85,7 @@ class WXFormerHIP(_Base):
         out = []
         if not pc.get("activate", False):
             return out
-        for name in ("global_mass_fixer", "global_water_fixer", "global_energy_fixer"):
+        for name in ("global_mass_fixer", "global_water_fixer", "global_energy_fixer", "global_energy_fixer_updown"):
             sub = pc.get(name) or {}
             if sub.get("activate", False) and not sub.get("activate_outside_model", False):
                 if sub.get("grid_type", "pressure") not in ("pressure", "sigma"):
@@ -146,6 +144,13 @@ class WXFormerHIP(_Base):
                 pb.add_mass_fixer(int(c["q_inds"][0]), int(c["fix_level_num"]), dn)
             elif name == "global_water_fixer":
                 pb.add_water_fixer(int(c["q_inds"][0]), int(c["precip_ind"]), int(c["evapor_ind"]), n_seconds, dn)
+            elif name == "global_energy_fixer_updown":
+                if ph["gph"] is None:
+                    raise WXEngineError("global_energy_fixer_updown needs the surface geopotential: set_physics(..., gph_surf=)")
+                flux = [int(c[k]) for k in ("TOA_down_solar_ind", "TOA_up_solar_ind", "TOA_up_OLR_ind", "surf_down_solar_ind",
+                                            "surf_up_solar_ind", "surf_down_LW_ind", "surf_up_LW_ind", "surf_SH_ind", "surf_LH_ind")]
+                pb.add_energy_fixer_updown(int(c["T_inds"][0]), int(c["q_inds"][0]), int(c["U_inds"][0]), int(c["V_inds"][0]),
+                                           flux, ph["gph"], n_seconds, dn)
             else:
                 if ph["gph"] is None:
                     raise WXEngineError("global_energy_fixer needs the surface geopotential: set_physics(..., gph_surf=)")

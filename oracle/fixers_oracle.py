@@ -274,3 +274,42 @@ def energy_fixer_sigma(y, x, grid: SigmaGrid, T_start: int, q_start: int, U_star
         T_new = (T_new - mean[sl].view(-1, 1, 1)) / std[sl].view(-1, 1, 1)
     y[sl] = T_new
     return y
+
+
+def energy_fixer_updown(y, x, grid: Grid, T_start: int, q_start: int, U_start: int, V_start: int, n_lev: int,
+                        flux_inds: Sequence[int], gph_surf: torch.Tensor, n_seconds: float, stats: Optional[Dict] = None):
+    """GlobalEnergyFixerUpDown, pressure levels (gen1.py:944-1025): the energy fixer with explicit up/down fluxes,
+    flux_inds = [TOA down solar, TOA up solar, TOA up OLR, surf down solar, surf up solar, surf down LW, surf up LW, SH, LH]:
+    R_T = (d - u - olr) / dt,  F_S = (ds - us + dl - ul - sh - lh) / dt."""
+    y = y.clone()
+
+    def lev(t, s, which):
+        sl = slice(s, s + n_lev)
+        return _den(t[sl], *stats[which], sl) if stats else t[sl]
+
+    def one(i):
+        sl = slice(i, i + 1)
+        return (_den(y[sl], *stats["out"], sl) if stats else y[sl])[0]
+
+    T0, q0, U0, V0 = (lev(x, s, "in") for s in (T_start, q_start, U_start, V_start))
+    T1, q1, U1, V1 = (lev(y, s, "out") for s in (T_start, q_start, U_start, V_start))
+    cp0 = (1 - q0) * CP_DRY + q0 * CP_VAPOR
+    cp1 = (1 - q1) * CP_DRY + q1 * CP_VAPOR
+    g = gph_surf.to(y.dtype)
+    eq0 = LH_WATER * q0 + g + 0.5 * (U0 ** 2 + V0 ** 2)
+    eq1 = LH_WATER * q1 + g + 0.5 * (U1 ** 2 + V1 ** 2)
+    f = [one(i) for i in flux_inds]
+    r_t = grid.wsum((f[0] - f[1] - f[2]) / n_seconds)
+    f_s = grid.wsum((f[3] - f[4] + f[5] - f[6] - f[7] - f[8]) / n_seconds)
+    e0 = cp0 * T0 + eq0
+    e1 = cp1 * T1 + eq1
+    te0 = grid.wsum(column_integral(e0, grid.p, grid.midpoint) / GRAVITY)
+    te1 = grid.wsum(column_integral(e1, grid.p, grid.midpoint) / GRAVITY)
+    ratio = ((n_seconds * (r_t - f_s) + te0) / te1).to(y.dtype)
+    T_new = (e1 * ratio - eq1) / cp1
+    sl = slice(T_start, T_start + n_lev)
+    if stats:
+        mean, std = stats["out"]
+        T_new = (T_new - mean[sl].view(-1, 1, 1)) / std[sl].view(-1, 1, 1)
+    y[sl] = T_new
+    return y

@@ -187,3 +187,21 @@ def test_sigma_fixers_match_reference_golden(midpoint):
         assert rel(yc[blk], g[f"{tag}_chain"][blk]) < tol
     with pytest.raises(WXEngineError):  # the surface-pressure channel must exist
         WXPostBlock(10, 18, x.shape[0], 1, y.shape[0]).set_grid_sigma(lat2d, lon2d, g["coef_a"], g["coef_b"], 999, midpoint)
+
+
+@pytest.mark.parametrize("midpoint", [False, True])
+def test_energy_updown_matches_reference_golden(midpoint):
+    from test_fixers_oracle import UPDOWN_GOLD, updown_variant
+    g = np.load(UPDOWN_GOLD)
+    tag = "mid" if midpoint else "trapz"
+    x, y, nl = updown_variant(g, midpoint)
+    lat2d, lon2d, p = demo_latlon()
+    pb = WXPostBlock(10, 18, 4 * nl, 1, 4 * nl + 9)
+    pb.set_grid(lat2d, lon2d, p, midpoint)
+    pb.add_energy_fixer_updown(0, nl, 2 * nl, 3 * nl, [4 * nl + k for k in range(9)], np.ones((10, 18), np.float32), 6 * 3600.0)
+    yd = y.clone().cuda()
+    pb.apply(x[:, None].contiguous().cuda(), yd)
+    torch.cuda.synchronize()
+    ye = yd.cpu().numpy()
+    assert rel(ye[:nl], g[f"{tag}_updown"][:nl]) < 5e-5
+    np.testing.assert_array_equal(ye[nl:], y[nl:].numpy())

@@ -127,3 +127,25 @@ def test_sigma_fixers_match_reference(midpoint):
     assert rel(ye[:nl].numpy(), g[f"{tag}_energy"][:nl]) < 5e-5
     for blk, tol in ((slice(0, nl), 1e-4), (slice(sp, sp + 1), 1e-5), (slice(4 * nl + 6, 4 * nl + 7), 2e-3)):
         assert rel(yc[blk].numpy(), g[f"{tag}_chain"][blk]) < tol
+
+
+UPDOWN_GOLD = os.path.join(os.path.dirname(__file__), "golden", "fixers_updown.npz")
+
+
+def updown_variant(g, midpoint):
+    L = 7
+    nl = L - 1 if midpoint else L
+    x = np.concatenate([g["x"][b * L:b * L + nl] for b in range(4)], 0)[:, -1]
+    y = np.concatenate([g["y"][b * L:b * L + nl] for b in range(4)] + [g["flux"]], 0)
+    return torch.from_numpy(x), torch.from_numpy(y), nl
+
+
+@pytest.mark.parametrize("midpoint", [False, True])
+def test_energy_updown_matches_reference(midpoint):
+    g = np.load(UPDOWN_GOLD)
+    tag = "mid" if midpoint else "trapz"
+    x, y, nl = updown_variant(g, midpoint)
+    ye = F.energy_fixer_updown(y, x, demo_grid(midpoint), 0, nl, 2 * nl, 3 * nl, nl, [4 * nl + k for k in range(9)],
+                               torch.ones(10, 18), 6 * 3600.0)
+    assert rel(ye[:nl].numpy(), g[f"{tag}_updown"][:nl]) < 5e-5
+    np.testing.assert_array_equal(ye[nl:].numpy(), y[nl:].numpy())

@@ -225,6 +225,38 @@ def fixers_golden():
     np.savez_compressed(os.path.join(GOLD, "fixers_demo.npz"), **out)
 
 
+def fixers_updown_golden():
+    """GlobalEnergyFixerUpDown of the reference on its simple_demo grid (gen1.py:866-879), trapz and midpoint.
+    Channel layout of y: [T|q|U|V] + 9 flux channels [TOA dn solar, TOA up solar, OLR, surf dn solar, surf up solar, surf dn LW,
+    surf up LW, SH, LH]."""
+    from credit.postblock.gen1 import GlobalEnergyFixerUpDown
+    x_np, y_np = fixer_inputs(seed=13)
+    g = np.random.Generator(np.random.Philox(key=[13, 9]))
+    L, H, W = 7, 10, 18
+    flux = np.abs(3.0e6 * g.standard_normal((9, H, W))).astype(np.float32)
+    out = {"x": x_np, "y": y_np[:28], "flux": flux}
+    for midpoint in (False, True):
+        nl = L - 1 if midpoint else L
+        tag = "mid" if midpoint else "trapz"
+        xs = np.concatenate([x_np[b * L:b * L + nl] for b in range(4)], 0)
+        ys = np.concatenate([y_np[b * L:b * L + nl] for b in range(4)] + [flux], 0)
+        x = torch.from_numpy(xs)[None]
+        y = torch.from_numpy(ys)[None, :, None]
+        f0 = 4 * nl
+        cfg = {"simple_demo": True, "denorm": False, "grid_type": "pressure", "midpoint": midpoint, "activate": True,
+               "activate_outside_model": False, "T_inds": list(range(0, nl)), "q_inds": list(range(nl, 2 * nl)),
+               "U_inds": list(range(2 * nl, 3 * nl)), "V_inds": list(range(3 * nl, 4 * nl)),
+               "TOA_down_solar_ind": f0, "TOA_up_solar_ind": f0 + 1, "TOA_up_OLR_ind": f0 + 2, "surf_down_solar_ind": f0 + 3,
+               "surf_up_solar_ind": f0 + 4, "surf_down_LW_ind": f0 + 5, "surf_up_LW_ind": f0 + 6, "surf_SH_ind": f0 + 7,
+               "surf_LH_ind": f0 + 8}
+        with torch.no_grad():
+            ye = GlobalEnergyFixerUpDown({"global_energy_fixer_updown": cfg, "data": {"lead_time_periods": 6}})(
+                {"y_pred": y.clone(), "x": x.clone()})["y_pred"]
+        out[f"{tag}_updown"] = ye[0, :, 0].double().numpy()
+        print(f"[golden] updown energy fixer {tag}: dT max {float((ye - y).abs().max()):.3e}")
+    np.savez_compressed(os.path.join(GOLD, "fixers_updown.npz"), **out)
+
+
 SIGMA_A = np.array([200.0, 5000.0, 12000.0, 14000.0, 9000.0, 3000.0, 0.0], dtype=np.float32)       # Pa
 SIGMA_B = np.array([0.0, 0.0, 0.08, 0.3, 0.6, 0.88, 1.0], dtype=np.float32)
 
@@ -290,7 +322,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,C1,C3S,C3,T0W,C1W,T0U")
+    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,updown,C1,C3S,C3,T0W,C1W,T0U")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -303,6 +335,8 @@ def main():
             fixers_golden()
         elif item == "sigma":
             fixers_sigma_golden()
+        elif item == "updown":
+            fixers_updown_golden()
         elif item in ("T0", "T1", "T0W", "T0U"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "C1W":
