@@ -130,6 +130,20 @@ int wx_step(wx_handle h, const float* x_dev, const float* frc_dev, float* y_dev,
  *   wx_post_set_grid_sigma <-> physics_hybrid_sigma_level(lon2d, lat2d, coef_a, coef_b, midpoint) (:300-368); the fixers
  *   added afterwards follow the reference's sigma branches (the mass fixer rescales channel `sp_ind`, gen1.py:355-375). */
 typedef struct wx_post* wx_post_handle;
+
+/* ---- input side on the device -------------------------------------------------------------
+ * credit/preblock/norm.py:78-98 (ERA5Normalizer: (t - mean) / clamp(std, 1e-12) per variable and level) and
+ * credit/preblock/concat.py:96-207 (ConcatToTensor: torch.cat of the named fields along the channel dim) in one pass.
+ * Field f is a device tensor [batch, n_levels[f], frames, H, W] (fp32); they are written, normalised, into
+ * x [batch, sum(n_levels), frames, H, W] in the order given.  mean/std: host arrays with one entry per OUTPUT channel, or
+ * both NULL (concatenate only).  The order itself (field-type rank, 3d before 2d, stable) is host logic, see
+ * wxengine/preblock.py which mirrors `_channel_sort_key`. */
+typedef struct wx_pre* wx_pre_handle;
+int wx_pre_create(int n_fields, const int32_t* n_levels, int frames, int H, int W, const float* mean, const float* std,
+                  int device, wx_pre_handle* out);
+int wx_pre_destroy(wx_pre_handle p);
+int wx_pre_channels(wx_pre_handle p, int* channels);
+int wx_pre_apply(wx_pre_handle p, const float* const* fields_dev, float* x_dev, int batch, void* stream);
 int wx_post_create(int H, int W, int c_in, int frames, int c_out, int device, wx_post_handle* out);
 int wx_post_destroy(wx_post_handle p);
 int wx_post_set_grid(wx_post_handle p, const float* lat2d, const float* lon2d, const float* p_levels, int n_levels,

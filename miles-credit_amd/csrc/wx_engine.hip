@@ -21,6 +21,7 @@
 #include "wx_embed.h"
 #include "wx_gemm.h"
 #include "wx_post.h"
+#include "wx_pre.h"
 
 namespace wx {
 
@@ -1311,6 +1312,32 @@ int wx_profile(wx_handle h, int enable) { return guarded([&] { WX_NEED(h); h->im
 int wx_profile_reset(wx_handle h) { return guarded([&] { WX_NEED(h); h->impl->profile_reset(); }); }
 int wx_profile_read(wx_handle h, wx_kernel_stat* out, int capacity, int* count) {
   return guarded([&] { WX_NEED(h); if (!out || !count) throw wx::ConfigError("wx_profile_read: null argument"); *count = h->impl->profile_read(out, capacity); });
+}
+// ---- pre block (input normalisation + channel concatenation) ---------------------------------------------------------
+struct wx_pre {
+  std::unique_ptr<wx::PreBlock> impl;
+};
+int wx_pre_create(int n_fields, const int32_t* n_levels, int frames, int H, int W, const float* mean, const float* stdv, int device,
+                  wx_pre_handle* out) {
+  return guarded([&] {
+    if (!out || !n_levels) throw wx::ConfigError("wx_pre_create: null argument");
+    int ndev = 0;
+    WX_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) throw wx::ConfigError("wx_pre_create: no such GPU device");
+    std::unique_ptr<wx_pre> p(new wx_pre);
+    p->impl.reset(new wx::PreBlock(n_fields, n_levels, frames, H, W, mean, stdv, device));
+    *out = p.release();
+  });
+}
+int wx_pre_destroy(wx_pre_handle p) { return guarded([&] { delete p; }); }
+int wx_pre_channels(wx_pre_handle p, int* channels) {
+  return guarded([&] { if (!p || !p->impl || !channels) throw wx::ConfigError("wx_pre_channels: null argument"); *channels = p->impl->channels(); });
+}
+int wx_pre_apply(wx_pre_handle p, const float* const* fields_dev, float* x_dev, int batch, void* stream) {
+  return guarded([&] {
+    if (!p || !p->impl || !fields_dev || !x_dev) throw wx::ConfigError("wx_pre_apply: null argument");
+    p->impl->apply(fields_dev, x_dev, batch, (hipStream_t)stream);
+  });
 }
 // ---- post block ------------------------------------------------------------------------------------------------
 struct wx_post {

@@ -69,6 +69,11 @@ _PROTOTYPES = {
     "wx_profile_read": ([C.c_void_p, C.POINTER(wx_kernel_stat), C.c_int, C.POINTER(C.c_int)], C.c_int),
     "wx_post_create": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     "wx_post_destroy": ([C.c_void_p], C.c_int),
+    "wx_pre_create": ([C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                       C.POINTER(C.c_void_p)], C.c_int),
+    "wx_pre_destroy": ([C.c_void_p], C.c_int),
+    "wx_pre_channels": ([C.c_void_p, C.POINTER(C.c_int)], C.c_int),
+    "wx_pre_apply": ([C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     "wx_post_set_grid": ([C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int], C.c_int),
     "wx_post_set_grid_sigma": ([C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                 C.c_int, C.c_int, C.c_int], C.c_int),

@@ -257,6 +257,27 @@ def fixers_updown_golden():
     np.savez_compressed(os.path.join(GOLD, "fixers_updown.npz"), **out)
 
 
+def preblock_golden():
+    """ERA5Normalizer (stats injected, the NetCDF reading bypassed: xarray is absent) -> ConcatToTensor of the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth_batches import preblock_batch
+    from credit.preblock.concat import ConcatToTensor
+    from credit.preblock.norm import ERA5Normalizer
+    batch, mean, std = preblock_batch()
+    n = ERA5Normalizer.__new__(ERA5Normalizer)
+    torch.nn.Module.__init__(n)
+    n._mean = {k: torch.tensor(np.array(v), dtype=torch.float32) for k, v in mean.items()}
+    n._std = {k: torch.tensor(np.array(v), dtype=torch.float32) for k, v in std.items()}
+    x, meta = ConcatToTensor()(n(batch))
+    cmap = meta["input"]["_channel_map"]
+    out = {"x": x.numpy(), "keys": np.array(list(cmap.keys())), "starts": np.array([v["slice"].start for v in cmap.values()]),
+           "stops": np.array([v["slice"].stop for v in cmap.values()])}
+    x2, _ = ConcatToTensor()(batch)   # concatenation only
+    out["x_raw"] = x2.numpy()
+    np.savez_compressed(os.path.join(GOLD, "preblock.npz"), **out)
+    print(f"[golden] preblock: x {tuple(x.shape)} order {list(cmap.keys())}")
+
+
 SIGMA_A = np.array([200.0, 5000.0, 12000.0, 14000.0, 9000.0, 3000.0, 0.0], dtype=np.float32)       # Pa
 SIGMA_B = np.array([0.0, 0.0, 0.08, 0.3, 0.6, 0.88, 1.0], dtype=np.float32)
 
@@ -322,7 +343,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,updown,C1,C3S,C3,T0W,C1W,T0U")
+    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,updown,pre,C1,C3S,C3,T0W,C1W,T0U")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -337,6 +358,8 @@ def main():
             fixers_sigma_golden()
         elif item == "updown":
             fixers_updown_golden()
+        elif item == "pre":
+            preblock_golden()
         elif item in ("T0", "T1", "T0W", "T0U"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "C1W":
