@@ -1,0 +1,95 @@
+"""Output side of the step.
+
+The reference hands every forecast step to its writer pool with `y_pred_phys.cpu().numpy()`
+(credit/applications/rollout_to_netcdf.py:289-301): a blocking, pageable-memory device-to-host copy of the whole state
+(266 MB per step at 0.25 deg) on the compute stream, then `split_and_reshape` (credit/output.py:53-86) inside the worker.
+Here the de-normalised state is copied by a second HIP stream into a ring of PINNED host buffers while the engine already
+computes the next step; the consumer gets numpy views of a slot, split exactly like the reference (views, no copy).
+NetCDF / xarray writing stays in Python, as in the reference.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def split_and_reshape(y: np.ndarray, levels: int, n_upper_vars: int, n_single: int) -> Tuple[np.ndarray, np.ndarray]:
+    """credit/output.py:53-86 on a host array [B, C, H, W]: (upper air [B, vars, levels, H, W], single level [B, n_single, H, W])."""
+    up = y[:, : n_upper_vars * levels]
+    up = up.reshape(up.shape[0], n_upper_vars, levels, up.shape[-2], up.shape[-1])
+    return up, y[:, -n_single:]
+
+
+class PinnedOutputRing:
+    """Double- (n-) buffered asynchronous device-to-host transfer of the per-step output.
+
+    push(t) never blocks the compute stream: the copy stream waits on an event recorded after the producer kernels and
+    copies into the next pinned slot; pop() blocks only until THAT slot's copy has finished and returns the host array
+    (valid until the slot is reused, i.e. for `slots - 1` further pushes).
+    """
+
+    def __init__(self, shape: Sequence[int], slots: int = 2, device: Optional[torch.device] = None):
+        if slots < 2:
+            raise ValueError("at least two slots (one being filled, one being read)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("PinnedOutputRing needs a GPU")
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.host = [torch.empty(tuple(shape), dtype=torch.float32, pin_memory=True) for _ in range(slots)]
+        self.done = [torch.cuda.Event() for _ in range(slots)]
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._head = 0       # next slot to fill
+        self._pending: List[int] = []
+
+    def push(self, y_dev: torch.Tensor) -> None:
+        if len(self._pending) == len(self.host):
+            raise RuntimeError("ring full: pop() a slot before pushing again")
+        slot = self._head
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))       # after the kernels that produced y_dev
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(ready)
+            self.host[slot].copy_(y_dev.reshape(self.host[slot].shape), non_blocking=True)
+            self.done[slot].record(self.copy_stream)
+        y_dev.record_stream(self.copy_stream)                        # keep the device buffer alive for the copy
+        self._pending.append(slot)
+        self._head = (slot + 1) % len(self.host)
+
+    def pop(self) -> np.ndarray:
+        if not self._pending:
+            raise RuntimeError("nothing in flight")
+        slot = self._pending.pop(0)
+        self.done[slot].synchronize()
+        return self.host[slot].numpy()
+
+    def __len__(self) -> int:
+        return len(self._pending)
+
+
+def rollout_to_host(engine, x0: torch.Tensor, forcings, consume, slots: int = 2) -> int:
+    """The reference's loop (rollout_to_netcdf.py:274-310) with each step's physical-space output handed to
+    `consume(step_index, host_array [1, C_out, H, W])` -- e.g. the NetCDF worker pool -- from pinned memory: while the host
+    consumes step t-2 and step t-1 crosses PCIe, the engine computes step t.  `host_array` is a view of a ring slot, valid
+    until `consume` returns.  forcings[t] feeds the input of step t+2 (None on the last step).  Returns the number of steps."""
+    n = len(forcings)
+    cfg = engine.cfg
+    oh, ow = cfg.out_hw
+    dev = [torch.empty((1, cfg.base_output_channels, oh, ow), dtype=torch.float32, device=x0.device) for _ in range(slots)]
+    xb = [torch.empty_like(x0), torch.empty_like(x0)]
+    ring = PinnedOutputRing(tuple(dev[0].shape), slots, x0.device)
+    x, consumed = x0, 0
+    for t in range(n):
+        if len(ring) == slots:  # slot t % slots (pinned AND device buffer) is about to be reused: drain step t - slots
+            consume(consumed, ring.pop())
+            consumed += 1
+        want_next = t < n - 1 or forcings[t] is not None
+        _y, yp, xn = engine.step(x, forcings[t], want_y=False, want_phys=True, want_next=want_next, phys_out=dev[t % slots],
+                                 next_out=xb[t % 2] if want_next else None)
+        ring.push(yp)
+        if xn is not None:
+            x = xn
+    while len(ring):
+        consume(consumed, ring.pop())
+        consumed += 1
+    return n
