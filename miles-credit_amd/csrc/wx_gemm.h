@@ -530,6 +530,11 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   //   s_par[0..127] bias, [128..255] colsum (one DMA instruction), [256..511] (mean, rstd) of the tile's 128 rows
   constexpr int PARAM_OFF = (NST * STAGE > BM * RB) ? NST * STAGE : BM * RB;
   float* s_par = reinterpret_cast<float*>(smem + PARAM_OFF);
+  // the first K stages go out FIRST: the parameter staging below (global loads the compiler waits on before its LDS
+  // writes) then overlaps their flight instead of delaying their issue by an L2 round trip
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j)
+    if (j < nk) issue((unsigned)(j * STAGE), j);
   if (wave == 0) {
     const int idx = lane & 31;
     const float* srcf = lane < 32 ? p.bias : (p.rowstat ? p.colsum : nullptr);
@@ -540,10 +545,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
     const int m = m_blk + tid;
     *reinterpret_cast<float2*>(s_par + 256 + 2 * tid) = (p.rowstat && m < M) ? row_stats(p, m) : make_float2(0.f, 1.f);
   }
-#pragma unroll
-  for (int j = 0; j < NST - 1; ++j)
-    if (j < nk) issue((unsigned)(j * STAGE), j);
-  if (NST == 3 && nk > 1) dma_wait_allow<PER_STEP>(); else dma_wait_all();
+  dma_wait_all();
   __syncthreads();
   const int nk_run = (p.dbg & 4) ? 0 : nk;
   trace_stamp(p, 1);
