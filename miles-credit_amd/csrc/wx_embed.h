@@ -46,18 +46,19 @@ struct EmbedPatchParams {
   int out_h, out_w;
   int n32, n16, n8;    // real channels per branch (multiples of 4; <= 16, 16, 32)
   int dbg;
+  int row0;            // first output row of this launch (the launcher may split the map into two launches)
 };
 
 // NW waves share one patch: NW = 8 (512 threads, 2 waves per SIMD, 4 fragments each) lets one wave's LDS/L1
 // latency hide under its partner's MFMAs; NW = 4 (8 fragments each) halves the weight-fragment L1 traffic.
-template <typename T, int NW>
+template <typename T, int NW, int TH>
 __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatchParams p, const char* __restrict__ zero_page) {
-  constexpr int KS = 32, TH = 16, TW = 32;
+  constexpr int KS = 32, TW = 32;
   constexpr int PH = 2 * TH + KS - 2, PW = 2 * TW + KS - 2;
   constexpr int NPIX = PH * PW;
   constexpr int NT = NW * 64;
-  constexpr int NF = 32 / NW;                    // pixel fragments per wave (rows 16/NW, two 16-column halves)
-  constexpr int RPW = 16 / NW;                   // output rows per wave
+  constexpr int RPW = TH / NW;                   // output rows per wave
+  constexpr int NF = 2 * RPW;                    // pixel fragments per wave (RPW rows, two 16-column halves)
   constexpr int NPIX_PAD = ((NPIX + NT - 1) / NT) * NT;
   constexpr int CC = 16 / (int)sizeof(T);        // channels per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NPIX_PAD][16 B]
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
   const int li = lane & 15, g = lane >> 4;
   const int tiles_x = (p.out_w + TW - 1) / TW;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int oy0 = p.row0 + ty * TH, ox0 = tx * TW;
   const int by0 = 2 * oy0 + p.org, bx0 = 2 * ox0 + p.org;  // patch origin in buffer coordinates
   const int chunks = p.cpad / CC;
   const char* __restrict__ xin = reinterpret_cast<const char*>(p.xin);
@@ -206,25 +207,38 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
   }
 }
 
-template <typename T, int NW>
-inline void launch_embed_patch_nw(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream) {
-  constexpr int PH = 2 * 16 + 30, PW = 2 * 32 + 30;
+template <typename T, int NW, int TH>
+inline void launch_embed_patch_part(EmbedPatchParams p, int row0, int rows, const void* zero_page, hipStream_t stream) {
+  constexpr int PH = 2 * TH + 30, PW = 2 * 32 + 30;
   constexpr int NT = NW * 64;
   constexpr int LDS = (((PH * PW) + NT - 1) / NT) * NT * 16;
-  auto kern = embed_patch_kernel<T, NW>;
+  auto kern = embed_patch_kernel<T, NW, TH>;
   static bool attr_done = false;
   if (!attr_done) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
-  const int blocks = cdiv(p.out_h, 16) * cdiv(p.out_w, 32);
+  p.row0 = row0;
+  const int blocks = cdiv(rows, TH) * cdiv(p.out_w, 32);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
   WX_HIP(hipGetLastError());
 }
+// One workgroup (8 waves, 93 KB of LDS) per CU: a 16-row launch of the C3 map is 625 tiles = 2.44 rounds of 256 CUs, the
+// third round 44 % full.  The tail rows are therefore done by a second launch of half-height tiles that fits ONE round
+// (C3: 500 tiles of 16 rows + 250 tiles of 8 rows = 2 + ~0.6 rounds instead of 3).
 template <typename T>
-inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream) {
-  if (p.dbg & 256) launch_embed_patch_nw<T, 4>(p, zero_page, stream);  // A/B switch
-  else launch_embed_patch_nw<T, 8>(p, zero_page, stream);
+inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream, int n_cu = 256) {
+  if (p.dbg & 256) { launch_embed_patch_part<T, 4, 16>(p, 0, p.out_h, zero_page, stream); return; }  // A/B switch
+  const int tiles_x = cdiv(p.out_w, 32), tile_rows = cdiv(p.out_h, 16);
+  const int full_rounds = (tile_rows * tiles_x) / n_cu;
+  const int r1 = (full_rounds * n_cu) / tiles_x;            // tile rows that fill whole rounds
+  const int rem = p.out_h - 16 * r1;
+  if (!(p.dbg & 8192) && full_rounds >= 1 && r1 < tile_rows && rem > 0 && cdiv(rem, 8) * tiles_x <= n_cu) {
+    launch_embed_patch_part<T, 8, 16>(p, 0, 16 * r1, zero_page, stream);
+    launch_embed_patch_part<T, 8, 8>(p, 16 * r1, rem, zero_page, stream);
+  } else {
+    launch_embed_patch_part<T, 8, 16>(p, 0, p.out_h, zero_page, stream);
+  }
 }
 
 }  // namespace wx
