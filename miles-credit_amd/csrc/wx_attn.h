@@ -24,8 +24,11 @@ struct AttnParams {
   void* out;        // [H*W][ld_out]
   int64_t ld_out;
   const float* bias;  // [NP][NP] fp32, NP = 16*NKF; padded keys hold -1e30
+  const float* tb;    // the same bias as its generating table [(2w-1)^2] (bias[i][j] depends on (row, col) offsets only):
+                      // BT kernels keep it in LDS and never touch `bias` (49 KB of L2 reads per task otherwise)
   int H, W, C, heads, wsz, kind;  // kind 0 short, 1 long
   float scale;                    // bf16 engine: scale * log2(e), and the bias table is pre-multiplied by log2(e)
+  unsigned long long* trace;      // tools/attn_probe only (WX_ATTN_TRACE builds): [tasks][8] phase ticks
   int pack;                       // windows per 16-token tile (1, or 16 / wsz^2 for the 2x2 windows of the long
                                   // attention at stage 2: four windows share one MFMA tile, the bias table is
                                   // block-diagonal with -1e30 between windows)
@@ -35,8 +38,9 @@ struct AttnParams {
 // SPLIT = true : the workgroup's four waves share one task -- V^T is staged once by all 256 threads and the query
 //                blocks are dealt round-robin to the waves.  Same work, a quarter of the per-task latency: the
 //                stage-2/3 launches have only 3-6 tasks per SIMD and were bound by the length of one task.
-template <typename T, int NKF, bool SPLIT>
+template <typename T, int NKF, bool SPLIT, bool BT>
 __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
+  constexpr int TBN = 1024;  // LDS bias table: [0, (2w-1)^2) the offsets, the rest -1e30 (padded keys index there)
   constexpr int D = 32;
   constexpr int NP = NKF * 16;
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -80,31 +84,49 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
     return (int64_t)py * p.W + px;
   };
 
+#ifdef WX_ATTN_TRACE
+#define AT_TICK(v) const unsigned long long v = trace_tick()
+#define AT_ACC(a, x, y) a += (y) - (x)
+  unsigned long long at_s = 0, at_sm = 0, at_pv = 0, at_st = 0;
+#else
+#define AT_TICK(v)
+#define AT_ACC(a, x, y)
+#endif
+  AT_TICK(at0);
   const T* __restrict__ qkv = reinterpret_cast<const T*>(p.qkv);
   T* vt = reinterpret_cast<T*>(smem + (SPLIT ? 0 : wave) * VT_BYTES);
-
-  // ---- V^T into this wave's LDS slice (zero-filled beyond N) -------------------------------
-  {
-    constexpr int PIECES = D / VEC;  // 16-byte pieces per token row
-    constexpr int COLS_FILL = (sizeof(T) == 2) ? NKB * 32 : NP;
-    for (int idx = SPLIT ? (int)threadIdx.x : lane; idx < COLS_FILL * PIECES; idx += SPLIT ? 256 : 64) {
-      const int t = idx % COLS_FILL, piece = idx / COLS_FILL;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      const int64_t tp = (active && t < N) ? token_pixel(t) : -1;
-      if (tp >= 0) v = *reinterpret_cast<const uint4*>(qkv + tp * p.ld_qkv + 2 * p.C + head * D + piece * VEC);
-      const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) vt[(piece * VEC + i) * VT_COLS + t] = e[i];
+  float* s_tb = reinterpret_cast<float*>(smem + (SPLIT ? 1 : 4) * VT_BYTES);
+  int* s_bk = reinterpret_cast<int*>(s_tb + TBN);   // [NP] byte offset 4*(ty*(2w-1)+tx) of token t, or -2048 when padded
+  if constexpr (BT) {
+    const int side = 2 * p.wsz - 1;
+    for (int i = threadIdx.x; i < TBN; i += 256) s_tb[i] = i < side * side ? p.tb[i] : -1.0e30f;
+    if (threadIdx.x < NP) {
+      const int t = threadIdx.x, ty = t / p.wsz, tx = t - ty * p.wsz;
+      s_bk[t] = t < N ? 4 * (ty * side + tx) : -2048;
     }
   }
-  __syncthreads();
-  if (!active) return;
 
+  // ---- V rows -> registers; K fragments are requested BEFORE the V^T scatter waits on them --------------------
+  constexpr int PIECES = D / VEC;  // 16-byte pieces per token row
+  constexpr int COLS_FILL = (sizeof(T) == 2) ? NKB * 32 : NP;
+  // all loads of the tile first, THEN the LDS scatter: a rolled loop waited for each 16-byte load before issuing
+  // the next one -- 8 serial L2 round trips, a third of a task's lifetime (tools/attn_probe)
+  constexpr int STEP = SPLIT ? 256 : 64;
+  constexpr int ITER = (COLS_FILL * PIECES + STEP - 1) / STEP;
+  uint4 vv[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = it * STEP + (SPLIT ? (int)threadIdx.x : lane);
+    const int t = idx % COLS_FILL, piece = idx / COLS_FILL;
+    vv[it] = make_uint4(0u, 0u, 0u, 0u);
+    const int64_t tp = (active && idx < COLS_FILL * PIECES && t < N) ? token_pixel(t) : -1;
+    if (tp >= 0) vv[it] = *reinterpret_cast<const uint4*>(qkv + tp * p.ld_qkv + 2 * p.C + head * D + piece * VEC);
+  }
   // pixel of token j*16 + li (key rows of fragment j == query rows of query block j): computed once, the window
   // decomposition costs two integer divisions per token
   int tokpix[NKF];
 #pragma unroll
-  for (int j = 0; j < NKF; ++j) tokpix[j] = (j * 16 + li < N) ? (int)token_pixel(j * 16 + li) : -1;
+  for (int j = 0; j < NKF; ++j) tokpix[j] = (active && j * 16 + li < N) ? (int)token_pixel(j * 16 + li) : -1;
 
   // ---- K fragments (A operand of S^T) and V^T fragments (A operand of O^T) ------------------
   uint4 kf[NKF][QK_SUBS];
@@ -118,6 +140,23 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
         kf[j][s] = *reinterpret_cast<const uint4*>(qkv + kp * p.ld_qkv + p.C + head * D + (s * 64 + g * 16) / (int)sizeof(T));
     }
   }
+  // ---- V^T into this wave's LDS slice (zero-filled beyond N) -------------------------------
+  {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = it * STEP + (SPLIT ? (int)threadIdx.x : lane);
+      const int t = idx % COLS_FILL, piece = idx / COLS_FILL;
+      if (idx < COLS_FILL * PIECES) {
+        const T* e = reinterpret_cast<const T*>(&vv[it]);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) vt[(piece * VEC + i) * VT_COLS + t] = e[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  AT_TICK(at1);
+
   constexpr int NVF = (sizeof(T) == 2) ? NKB : NKF;
   uint4 vf[2][NVF];
 #pragma unroll
@@ -137,31 +176,60 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
 
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
   const int nqb = (N + 15) / 16;
-  for (int qb = SPLIT ? wave : 0; qb < nqb; qb += SPLIT ? 4 : 1) {
-    const int query = qb * 16 + li;
+  AT_TICK(at2);
+  // query fragments are fetched one block ahead: the load of block qb+1 flies during block qb's MFMAs and softmax
+  auto tok_of = [&](int qb_) {
     int qp = -1;
 #pragma unroll
-    for (int j = 0; j < NKF; ++j) qp = (j == qb) ? tokpix[j] : qp;  // constant indices only (no scratch)
-    const int64_t qpix_ = qp;
+    for (int j = 0; j < NKF; ++j) qp = (j == qb_) ? tokpix[j] : qp;  // constant indices only (no scratch)
+    return qp;
+  };
+  auto load_q = [&](int qb_, uint4* dst) {
+    const int qp = qb_ < nqb ? tok_of(qb_) : -1;
+#pragma unroll
+    for (int s = 0; s < QK_SUBS; ++s) {
+      dst[s] = make_uint4(0u, 0u, 0u, 0u);
+      if (qp >= 0) dst[s] = *reinterpret_cast<const uint4*>(qkv + (int64_t)qp * p.ld_qkv + head * D + (s * 64 + g * 16) / (int)sizeof(T));
+    }
+  };
+  constexpr int QSTEP = SPLIT ? 4 : 1;
+  uint4 qnext[QK_SUBS];
+  load_q(SPLIT ? wave : 0, qnext);
+  for (int qb = SPLIT ? wave : 0; qb < nqb; qb += QSTEP) {
+    AT_TICK(q0);
+    const int query = qb * 16 + li;
+    const int64_t qpix_ = tok_of(qb);
     const bool qok = qpix_ >= 0;
     const int64_t qpix = qok ? qpix_ : 0;
     uint4 qf[QK_SUBS];
 #pragma unroll
-    for (int s = 0; s < QK_SUBS; ++s) {
-      qf[s] = make_uint4(0u, 0u, 0u, 0u);
-      if (qok) qf[s] = *reinterpret_cast<const uint4*>(qkv + qpix * p.ld_qkv + head * D + (s * 64 + g * 16) / (int)sizeof(T));
-    }
+    for (int s = 0; s < QK_SUBS; ++s) qf[s] = qnext[s];
+    load_q(qb + QSTEP, qnext);
     // Scores/probabilities live in plain float arrays (not ext-vector elements): hipcc (ROCm 7.2) was
     // observed to fold element writes `vec[r] = expf(..)` so that all four PV B-operands read element 0.
     float sv[NKF][4];
     float mx = -3.0e38f;
     const float* brow = p.bias + (int64_t)query * NP + g * 4;  // query < NP always
+    float4 bt[BT ? NKF : 1];
+    if constexpr (BT) {
+      // bias[q][k] = tb[(qy - ky + w - 1) * (2w - 1) + (qx - kx + w - 1)]: one subtraction and one 4-byte LDS read per pair
+      const int aq = max(s_bk[query], 0) + 4 * ((p.wsz - 1) * (2 * p.wsz - 1) + (p.wsz - 1));
+      const char* tbb = reinterpret_cast<const char*>(s_tb) + aq;
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+        const int4 bk = *reinterpret_cast<const int4*>(s_bk + j * 16 + g * 4);
+        bt[j] = make_float4(*reinterpret_cast<const float*>(tbb - bk.x), *reinterpret_cast<const float*>(tbb - bk.y),
+                            *reinterpret_cast<const float*>(tbb - bk.z), *reinterpret_cast<const float*>(tbb - bk.w));
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NKF; ++j) {
       f32x4_t a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < QK_SUBS; ++s) a = mma_sub<T>(kf[j][s], qf[s], a);
-      const float4 bb = *reinterpret_cast<const float4*>(brow + j * 16);
+      float4 bb;
+      if constexpr (BT) bb = bt[j];
+      else bb = *reinterpret_cast<const float4*>(brow + j * 16);
       sv[j][0] = a[0] * p.scale + bb.x;
       sv[j][1] = a[1] * p.scale + bb.y;
       sv[j][2] = a[2] * p.scale + bb.z;
@@ -170,6 +238,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    AT_TICK(q1);
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < NKF; ++j) {
@@ -185,6 +254,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
+    AT_TICK(q2);
 
     f32x4_t oacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
     if constexpr (sizeof(T) == 2) {
@@ -217,6 +287,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
         }
       }
     }
+    AT_TICK(q3);
     if (qok) {
 #pragma unroll
       for (int df = 0; df < 2; ++df) {
@@ -226,15 +297,23 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
         store4<T>(out + qpix * p.ld_out + head * D + df * 16 + g * 4, v);
       }
     }
+    AT_TICK(q4);
+    AT_ACC(at_s, q0, q1); AT_ACC(at_sm, q1, q2); AT_ACC(at_pv, q2, q3); AT_ACC(at_st, q3, q4);
   }
+#ifdef WX_ATTN_TRACE
+  if (p.trace && lane == 0) {
+    unsigned long long* t = p.trace + (size_t)task * 8;
+    t[0] = at1 - at0; t[1] = at2 - at1; t[2] = at_s; t[3] = at_sm; t[4] = at_pv; t[5] = at_st; t[6] = trace_tick() - at0;
+  }
+#endif
 }
 
-template <typename T, int NKF, bool SPLIT>
+template <typename T, int NKF, bool SPLIT, bool BT = false>
 inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
   constexpr int NKB = (NKF + 1) / 2;
   constexpr int VT_COLS = (sizeof(T) == 2) ? (NKB * 32 + 8) : (NKF * 16 + 4);
-  constexpr int LDS = (SPLIT ? 1 : 4) * 32 * VT_COLS * (int)sizeof(T);
-  auto kern = window_attn_kernel<T, NKF, SPLIT>;
+  constexpr int LDS = (SPLIT ? 1 : 4) * 32 * VT_COLS * (int)sizeof(T) + (BT ? 1024 * 4 + NKF * 16 * 4 : 0);
+  auto kern = window_attn_kernel<T, NKF, SPLIT, BT>;
   static bool attr_done = false;
   if (!attr_done) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -264,14 +343,27 @@ inline void launch_window_attn(const AttnParams& p, hipStream_t stream, int spli
   const int n_win = (p.H / p.wsz) * (p.W / p.wsz);
   const int64_t tasks = (int64_t)((n_win + p.pack - 1) / p.pack) * p.heads;
   const int nkf = attn_nkf_tokens(p.wsz * p.wsz * p.pack);
+  const bool bt = p.tb != nullptr && p.pack == 1 && split_mode != 3;   // split_mode 3: A/B switch back to the [NP][NP] table
   const bool split = nkf >= 4 && split_mode == 2;  // measured slower on every C3 launch (0.535 vs 0.471 ms at stage 2): experiment only
   (void)tasks;
   switch (nkf) {
     case 1: launch_window_attn_n<T, 1, false>(p, stream); break;
     case 2: launch_window_attn_n<T, 2, false>(p, stream); break;
-    case 4: if (split) launch_window_attn_n<T, 4, true>(p, stream); else launch_window_attn_n<T, 4, false>(p, stream); break;
-    case 7: if (split) launch_window_attn_n<T, 7, true>(p, stream); else launch_window_attn_n<T, 7, false>(p, stream); break;
-    case 8: if (split) launch_window_attn_n<T, 8, true>(p, stream); else launch_window_attn_n<T, 8, false>(p, stream); break;
+    case 4:
+      if (split) launch_window_attn_n<T, 4, true>(p, stream);
+      else if (bt) launch_window_attn_n<T, 4, false, true>(p, stream);
+      else launch_window_attn_n<T, 4, false>(p, stream);
+      break;
+    case 7:
+      if (split) launch_window_attn_n<T, 7, true>(p, stream);
+      else if (bt) launch_window_attn_n<T, 7, false, true>(p, stream);
+      else launch_window_attn_n<T, 7, false>(p, stream);
+      break;
+    case 8:
+      if (split) launch_window_attn_n<T, 8, true>(p, stream);
+      else if (bt) launch_window_attn_n<T, 8, false, true>(p, stream);
+      else launch_window_attn_n<T, 8, false>(p, stream);
+      break;
     default: throw std::runtime_error("window attention supports at most 128 tokens per window (wsz <= 11)");
   }
 }

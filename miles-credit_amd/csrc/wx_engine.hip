@@ -46,7 +46,7 @@ struct ConvW {          // one repacked GEMM operand in the weight arena
   int64_t colsum = -1;
   int cin_true = 0;     // unpadded channels (flop accounting)
 };
-struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1; int wsz = 0, kind = 0; };
+struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1, bias_tb = -1; int wsz = 0, kind = 0; };
 struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1, pack_pp = -1; const AttnL* next = nullptr; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset; pack_pre: the same preceded by the attention's Wout blocks
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
 struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmbed branch (wx_embed.h)
@@ -458,7 +458,7 @@ class Engine : public EngineBase {
   }
   // DynamicPositionBias (crossformer.py:158-176) evaluated on the (2w+1)^2 offsets, gathered with the
   // reference's stride-(2w-1) indices (crossformer.py:238-245, :284), padded to [NP][NP].
-  int64_t make_bias_table(const std::string& p, int wsz, int dq) {
+  int64_t make_bias_table(const std::string& p, int wsz, int dq, int64_t* tb_off = nullptr) {
     const int side = 2 * wsz + 1, npos = side * side;
     std::vector<double> w0 = folded(p + ".layers.0", false), w3 = folded(p + ".layers.3", false),
                         w6 = folded(p + ".layers.6", false), w9 = folded(p + ".layers.9", false);
@@ -511,6 +511,11 @@ class Engine : public EngineBase {
         }
         padded[(size_t)i * NP + j] = v;
       }
+    if (tb_off) {  // the generating table itself (flat, first (2w-1)^2 entries are the ones the reference's indices reach)
+      std::vector<float> tb((size_t)(2 * wsz - 1) * (2 * wsz - 1));
+      for (size_t i = 0; i < tb.size(); ++i) tb[i] = (float)(pre * table[i]);
+      *tb_off = push_f(tb);
+    }
     return push_f(padded);
   }
   AttnL make_attn(const std::string& p, int c, int wsz, int kind) {
@@ -522,7 +527,7 @@ class Engine : public EngineBase {
       a.vonly = make_conv(p + ".to_qkv", 2 * c, 3 * c, c, c, 1, 1, false, g.data.data(), b.data.data());
     } else {
       a.qkv = make_conv(p + ".to_qkv", 0, 3 * c, c, c, 1, 1, false, g.data.data(), b.data.data());
-      a.bias_tab = make_bias_table(p + ".dpb", wsz, c / 4);
+      a.bias_tab = make_bias_table(p + ".dpb", wsz, c / 4, &a.bias_tb);
     }
     a.out = make_conv(p + ".to_out", 0, c, c, c, 1, 1, true, nullptr, nullptr);
     return a;
@@ -982,7 +987,7 @@ class Engine : public EngineBase {
     } else {
       if (!qkv_ready) gemm("gemm_qkv", a.qkv, x, h, w, ld, 1, 0, 0, h, w, scratch, 3 * c, rs, 0, nullptr, 0);
       AttnParams p;
-      p.qkv = scratch; p.ld_qkv = 3 * c; p.out = attn_o; p.ld_out = c; p.bias = f_dev + a.bias_tab;
+      p.qkv = scratch; p.ld_qkv = 3 * c; p.out = attn_o; p.ld_out = c; p.bias = f_dev + a.bias_tab; p.tb = a.bias_tb >= 0 ? f_dev + a.bias_tb : nullptr;
       p.H = h; p.W = w; p.C = c; p.heads = c / 32; p.wsz = a.wsz; p.kind = a.kind;
       p.scale = (float)((sizeof(T) == 2 ? 1.4426950408889634 : 1.0) / std::sqrt(32.0));
       p.pack = attn_pack(a.wsz);
