@@ -50,6 +50,7 @@ struct FFParams {
   int64_t ld_qkv;
   const float* csq;     // [3C] column sums of the rounded gain-folded Wqkv rows
   const float* bq;      // [3C] folded bias (LayerNorm shift through Wqkv)
+  unsigned long long* trace;  // tools/ff_probe only (WX_FF_TRACE builds): [workgroups*4][8] phase ticks
 };
 
 // k-slot permutation shared by x fragments, W1 and (through the accumulator layout) W2:
@@ -72,6 +73,15 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   float* s_par = reinterpret_cast<float*>(smem + 2 * CB);  // [hidden] cs1 | [hidden] b1
 
   const int px0 = (blockIdx.x * 4 + wave) * PXW;
+#ifdef WX_FF_TRACE
+#define FF_TICK(v) const unsigned long long v = trace_tick()
+#define FF_ACC(a, x, y) a += (y) - (x)
+  unsigned long long ft_g1 = 0, ft_gelu = 0, ft_g2 = 0, ft_bar = 0;
+#else
+#define FF_TICK(v)
+#define FF_ACC(a, x, y)
+#endif
+  FF_TICK(ff0);
 
   // ---- chunk 0 -> stage 0; parameters -> LDS ---------------------------------------------------
   unsigned dst[DMA_I];
@@ -86,6 +96,12 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   for (int i = tid; i < p.hidden; i += 256) {
     s_par[i] = p.cs1[i];
     s_par[p.hidden + i] = p.b1[i];
+  }
+  // [C] b2 | [C] bo at the very end of the parameter block (offset 2*hidden + 6C whether or not POST is built)
+  float* s_b2 = s_par + 2 * p.hidden + 6 * C;
+  for (int i = tid; i < C; i += 256) {
+    s_b2[i] = p.b2[i];
+    s_b2[C + i] = PRE ? p.bo[i] : 0.f;
   }
   if constexpr (POST) {  // [3C] csq | [3C] bq behind them: a global load inside the block loop would wait on vmcnt = on the DMA
     for (int i = tid; i < 3 * C; i += 256) {
@@ -141,16 +157,24 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
     for (int i = 0; i < NPRE; ++i) {
       const char* cur = smem + (i & 1) * CB;
       issue(i + 1, (unsigned)(((i + 1) & 1) * CB));  // the first feed-forward chunk follows the last block
+      // 16 fragment reads in flight per batch (the accumulators of the later phases are not live yet): one exposed LDS
+      // round trip per 8-16 MFMAs instead of one per 2-4 (tools/ff_probe: the head and tail phases were 8x off the MFMA rate)
+      constexpr int MLB = 16 / KS;  // 64-row block in batches of MLB 16-row fragments
 #pragma unroll
-      for (int ml = 0; ml < 4; ++ml) {
-        uint4 a[KS];
+      for (int m0 = 0; m0 < 4; m0 += MLB) {
+        uint4 a[MLB][KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const uint4*>(cur + w1_off + ml * 16 * 2 * C + (((ks * 4 + g) ^ li) * 16));
+        for (int ml = 0; ml < MLB; ++ml)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            a[ml][ks] = *reinterpret_cast<const uint4*>(cur + w1_off + (m0 + ml) * 16 * 2 * C + (((ks * 4 + g) ^ li) * 16));
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-          for (int f = 0; f < PXF; ++f) y[i * 4 + ml][f] = mma_sub<bf16_t>(a[ks], ob[ks][f], y[i * 4 + ml][f]);
+          for (int ml = 0; ml < MLB; ++ml)
+#pragma unroll
+            for (int f = 0; f < PXF; ++f) y[i * 4 + m0 + ml][f] = mma_sub<bf16_t>(a[ml][ks], ob[ks][f], y[i * 4 + m0 + ml][f]);
       }
       dma_wait_all();
       __syncthreads();
@@ -158,7 +182,7 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
     // x1 -> bf16, into the x registers (accumulator layout == the permuted-k B layout); y back to zero
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
-      const float4 bb = *reinterpret_cast<const float4*>(p.bo + m * 16 + 4 * g);
+      const float4 bb = *reinterpret_cast<const float4*>(s_b2 + C + m * 16 + 4 * g);
 #pragma unroll
       for (int f = 0; f < PXF; ++f) {
         uint4& xr = xb[m / 2][f];
@@ -204,7 +228,9 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   };
   row_statistics();
 
+  FF_TICK(ff1);
   for (int ch = 0; ch < nch; ++ch) {  // NPRE is even: the ring parity of chunk ch is ch & 1 either way
+    FF_TICK(tc0);
     const char* cur = smem + (ch & 1) * CB;
     if (ch + 1 < nch + NPOST) issue(NPRE + ch + 1, (unsigned)(((ch + 1) & 1) * CB));
     // GEMM1, K steps in batches of 4: the 8 fragment reads of a batch are all in flight before its first MFMA.
@@ -231,6 +257,7 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
           h[1][f] = mma_sub<bf16_t>(a1[k], xb[k0 + k][f], h[1][f]);
         }
     }
+    FF_TICK(tc1);
     // first batch of W2 fragments + this chunk's parameters: their latency hides under the GELU arithmetic
     uint4 a2[4];
 #pragma unroll
@@ -259,6 +286,7 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
         hb[f] = make_uint4(pack_bf16x2(v[f * 4].x, v[f * 4].y), pack_bf16x2(v[f * 4 + 1].x, v[f * 4 + 1].y),
                            pack_bf16x2(v[f * 4 + 2].x, v[f * 4 + 2].y), pack_bf16x2(v[f * 4 + 3].x, v[f * 4 + 3].y));
     }
+    FF_TICK(tc2);
     // GEMM2, output fragments in batches of 4; the next batch is read while the current one multiplies
 #pragma unroll
     for (int m0 = 0; m0 < MF; m0 += 4) {
@@ -277,9 +305,13 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
         for (int m = 0; m < 4; ++m) a2[m] = an[m];
       }
     }
+    FF_TICK(tc3);
     dma_wait_all();
     __syncthreads();
+    FF_TICK(tc4);
+    FF_ACC(ft_g1, tc0, tc1); FF_ACC(ft_gelu, tc1, tc2); FF_ACC(ft_g2, tc2, tc3); FF_ACC(ft_bar, tc3, tc4);
   }
+  FF_TICK(ff2);
 
   // ---- epilogue: + b2 + residual -> bf16, statistics, stores ----------------------------------------
   // Pixel / pointer arithmetic is redone from an opaque copy of the thread id: otherwise hipcc keeps the prologue's
@@ -297,7 +329,7 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
-      const float4 bb = *reinterpret_cast<const float4*>(p.b2 + m * 16 + 4 * g2);
+      const float4 bb = *reinterpret_cast<const float4*>(s_b2 + m * 16 + 4 * g2);
       const uint4 xr = xb[m / 2][f];
       const uint32_t r01 = (m & 1) ? xr.z : xr.x, r23 = (m & 1) ? xr.w : xr.y;
       const float v0 = y[m][f][0] + bb.x + __builtin_bit_cast(float, r01 << 16);
@@ -336,16 +368,22 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
       for (int ml = 0; ml < 4; ++ml)
 #pragma unroll
         for (int f = 0; f < PXF; ++f) qa[ml][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      constexpr int MLB = 16 / KS;
 #pragma unroll
-      for (int ml = 0; ml < 4; ++ml) {
-        uint4 a[KS];
+      for (int m0 = 0; m0 < 4; m0 += MLB) {
+        uint4 a[MLB][KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const uint4*>(cur + w1_off + ml * 16 * 2 * C + (((ks * 4 + g) ^ li) * 16));
+        for (int ml = 0; ml < MLB; ++ml)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            a[ml][ks] = *reinterpret_cast<const uint4*>(cur + w1_off + (m0 + ml) * 16 * 2 * C + (((ks * 4 + g) ^ li) * 16));
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-          for (int f = 0; f < PXF; ++f) qa[ml][f] = mma_sub<bf16_t>(a[ks], xb[ks][f], qa[ml][f]);
+          for (int ml = 0; ml < MLB; ++ml)
+#pragma unroll
+            for (int f = 0; f < PXF; ++f) qa[m0 + ml][f] = mma_sub<bf16_t>(a[ml][ks], xb[ks][f], qa[m0 + ml][f]);
       }
 #pragma unroll
       for (int ml = 0; ml < 4; ++ml) {
@@ -366,11 +404,17 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
       __syncthreads();
     }
   }
+#ifdef WX_FF_TRACE
+  if (p.trace && (threadIdx.x & 63) == 0) {
+    unsigned long long* t = p.trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    t[0] = ff1 - ff0; t[1] = ft_g1; t[2] = ft_gelu; t[3] = ft_g2; t[4] = ft_bar; t[5] = trace_tick() - ff2; t[6] = trace_tick() - ff0;
+  }
+#endif
 }
 
 template <int C, int PXF, int OCC, int GP, bool PRE, bool POST>
 inline void launch_ff_fused_v(const FFParams& p, const void* zero_page, hipStream_t stream) {
-  const int LDS = 2 * 128 * C + 8 * p.hidden + (POST ? 24 * C : 0);
+  const int LDS = 2 * 128 * C + 8 * p.hidden + 24 * C + 8 * C;  // ring | cs1,b1 | csq,bq | b2,bo
   auto kern = ff_fused_kernel<C, PXF, OCC, GP, PRE, POST>;
   static int attr_lds = 0;
   if (LDS > attr_lds) {
