@@ -162,6 +162,11 @@ int wx_post_add_energy_fixer(wx_post_handle p, int T_start, int q_start, int U_s
  * surface down solar, surface up solar, surface down LW, surface up LW, SH, LH]. */
 int wx_post_add_energy_fixer_updown(wx_post_handle p, int T_start, int q_start, int U_start, int V_start,
                                     const int32_t flux_inds[9], const float* gph_surf, float n_seconds, int denorm);
+/* The general energy fixer: R_T = sum toa_sign[k] * y[toa_ind[k]] (<= 4 terms), F_S = sum srf_sign[k] * y[srf_ind[k]] (<= 8).
+ * The gen-2 name-keyed fixer (credit/postblock/conservation.py:239-376) maps onto this one (wxengine/conservation.py). */
+int wx_post_add_energy_fixer_signed(wx_post_handle p, int T_start, int q_start, int U_start, int V_start, int n_toa,
+                                    const int32_t* toa_inds, const float* toa_signs, int n_srf, const int32_t* srf_inds,
+                                    const float* srf_signs, const float* gph_surf, float n_seconds, int denorm);
 int wx_post_apply(wx_post_handle p, const float* x_dev, float* y_dev, void* stream);
 /* Run `p` inside wx_forward / wx_step (after the tail, before y_phys and x_next); NULL detaches.  The engine does not
  * take ownership. */

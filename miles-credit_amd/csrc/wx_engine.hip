@@ -1384,6 +1384,16 @@ int wx_post_add_mass_fixer(wx_post_handle p, int q_start, int fix_level_num, int
 int wx_post_add_water_fixer(wx_post_handle p, int q_start, int precip_ind, int evapor_ind, float n_seconds, int denorm) {
   return guarded([&] { WX_NEEDP(p); p->impl->add_water(q_start, precip_ind, evapor_ind, n_seconds, denorm); });
 }
+int wx_post_add_energy_fixer_signed(wx_post_handle p, int T_start, int q_start, int U_start, int V_start, int n_toa,
+                                    const int32_t* toa_inds, const float* toa_signs, int n_srf, const int32_t* srf_inds,
+                                    const float* srf_signs, const float* gph_surf, float n_seconds, int denorm) {
+  return guarded([&] {
+    WX_NEEDP(p);
+    if (!toa_inds || !toa_signs || !srf_inds || !srf_signs || !gph_surf) throw wx::ConfigError("wx_post_add_energy_fixer_signed: null argument");
+    p->impl->add_energy_signed(T_start, q_start, U_start, V_start, n_toa, toa_inds, toa_signs, n_srf, srf_inds, srf_signs, gph_surf,
+                               n_seconds, denorm);
+  });
+}
 int wx_post_add_energy_fixer_updown(wx_post_handle p, int T_start, int q_start, int U_start, int V_start, const int32_t flux_inds[9],
                                     const float* gph_surf, float n_seconds, int denorm) {
   return guarded([&] {

@@ -371,6 +371,20 @@ class PostBlock {
     for (int k = 0; k < 6; ++k) { op.srf_i[k] = flux[3 + k]; op.srf_s[k] = ss[k]; }
     finish_energy(op, T0, q0, U0, V0, gph_surf, n_seconds);
   }
+  // generic form: R_T = sum_k toa_sign[k] * y[toa_ind[k]], F_S = sum_k srf_sign[k] * y[srf_ind[k]] (the gen-2 fixer,
+  // credit/postblock/conservation.py:344-358, uses yet another sign convention than the two gen-1 classes)
+  void add_energy_signed(int T0, int q0, int U0, int V0, int n_toa, const int32_t* toa_i, const float* toa_s, int n_srf,
+                         const int32_t* srf_i, const float* srf_s, const float* gph_surf, float n_seconds, int denorm) {
+    need_grid(); need_stats(denorm);
+    if (n_toa < 1 || n_toa > 4 || n_srf < 1 || n_srf > 8) throw std::runtime_error("wx_post: 1..4 TOA and 1..8 surface flux terms");
+    WX_HIP(hipSetDevice(device));
+    PostOp op;
+    op.kind = 3; op.denorm = denorm; op.T0 = T0; op.q0 = q0; op.U0 = U0; op.V0 = V0; op.nlev = levels_carried();
+    op.toa_n = n_toa; op.srf_n = n_srf;
+    for (int k = 0; k < n_toa; ++k) { op.toa_i[k] = toa_i[k]; op.toa_s[k] = toa_s[k]; }
+    for (int k = 0; k < n_srf; ++k) { op.srf_i[k] = srf_i[k]; op.srf_s[k] = srf_s[k]; }
+    finish_energy(op, T0, q0, U0, V0, gph_surf, n_seconds);
+  }
   void finish_energy(PostOp& op, int T0, int q0, int U0, int V0, const float* gph_surf, float n_seconds) {
     op.n_seconds = n_seconds;
     for (int s : {T0, q0, U0, V0}) { check_block(s, op.nlev, cout, "3-D block (output)"); check_block(s, op.nlev, cin, "3-D block (input)"); }

@@ -81,6 +81,8 @@ _PROTOTYPES = {
     "wx_post_add_tracer_fixer": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int], C.c_int),
     "wx_post_add_mass_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_int),
     "wx_post_add_water_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int], C.c_int),
+    "wx_post_add_energy_fixer_signed": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                         C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int], C.c_int),
     "wx_post_add_energy_fixer_updown": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float),
                                          C.c_float, C.c_int], C.c_int),
     "wx_post_add_energy_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_int], C.c_int),
@@ -356,6 +358,18 @@ class WXPostBlock:
         g = _fp(gph_surf)
         _check(self.lib.wx_post_add_energy_fixer(self._p, T_start, q_start, U_start, V_start,
                                                  r.ctypes.data_as(C.POINTER(C.c_int32)), self._ptr(g), float(n_seconds), int(denorm)))
+
+    def add_energy_fixer_signed(self, T_start, q_start, U_start, V_start, toa, surf, gph_surf, n_seconds, denorm=False):
+        """toa / surf: lists of (channel, sign): R_T = sum sign * y[channel] (<= 4 terms), F_S likewise (<= 8)."""
+        ti = np.ascontiguousarray([c for c, _ in toa], dtype=np.int32)
+        ts = np.ascontiguousarray([s for _, s in toa], dtype=np.float32)
+        si = np.ascontiguousarray([c for c, _ in surf], dtype=np.int32)
+        ss = np.ascontiguousarray([s for _, s in surf], dtype=np.float32)
+        g = _fp(gph_surf)
+        ip, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        _check(self.lib.wx_post_add_energy_fixer_signed(self._p, T_start, q_start, U_start, V_start, ti.size, ti.ctypes.data_as(ip),
+                                                        ts.ctypes.data_as(fp), si.size, si.ctypes.data_as(ip), ss.ctypes.data_as(fp),
+                                                        self._ptr(g), float(n_seconds), int(denorm)))
 
     def add_energy_fixer_updown(self, T_start, q_start, U_start, V_start, flux_inds, gph_surf, n_seconds, denorm=False):
         """GlobalEnergyFixerUpDown (credit/postblock/gen1.py:825-1030); flux_inds = [TOA down solar, TOA up solar, TOA up OLR,

@@ -18,3 +18,30 @@ def preblock_batch(seed=21):
     std = {"T": np.array([8., 9., 12., 15.], np.float32), "Q": np.array([1e-6, 2e-4, 0.0, 5e-3], np.float32),   # a zero std: clamp path
            "U": np.array([20., 15., 10., 6.], np.float32), "SP": np.float32(9.0e3), "t2m": np.float32(15.), "tsi": np.float32(9.0e5)}
     return {"input": {"era5": variables}}, mean, std
+
+
+def conservation_batch(seed=31, midpoint=True):
+    """A gen-2 style `batch_dict` on the reference's 10 x 18 demo grid with 7 hybrid levels (6 mid-level values when
+    `midpoint`): y_processed (t1) and x_physical (t0, two frames), physical units, B = 2."""
+    g = np.random.Generator(np.random.Philox(key=[seed, 2]))
+    B, H, W, L = 2, 10, 18, 6 if midpoint else 7
+
+    def t(a):
+        return torch.from_numpy(np.asarray(a, np.float32))
+
+    def state(T):
+        return {"cam/prognostic/3d/T": t(250.0 + 30.0 * g.standard_normal((B, L, T, H, W))),
+                "cam/prognostic/3d/Qtot": t(np.abs(0.004 + 0.004 * g.standard_normal((B, L, T, H, W)))),
+                "cam/prognostic/3d/U": t(12.0 * g.standard_normal((B, L, T, H, W))),
+                "cam/prognostic/3d/V": t(8.0 * g.standard_normal((B, L, T, H, W))),
+                "cam/prognostic/2d/PS": t(1.0e5 + 2.0e3 * g.standard_normal((B, 1, T, H, W)))}
+    y = state(1)
+    for k in ("FSUTOA", "FLUT", "FSDS", "FSUS", "FLDS", "FLUS", "SHFLX", "LHFLX"):
+        scale = 200.0 if k in ("FSUTOA", "FLUT") else 3.0e6        # TOA terms in W/m2, surface terms in J/m2 (conservation.py)
+        y[f"cam/diagnostic/2d/{k}"] = t(np.abs(scale * g.standard_normal((B, 1, 1, H, W))))
+    y["cam/diagnostic/2d/PRECT"] = t(np.abs(2e-3 * g.standard_normal((B, 1, 1, H, W))))
+    y["cam/diagnostic/2d/QFLX"] = t(-np.abs(1e-3 * g.standard_normal((B, 1, 1, H, W))))
+    x = state(2)
+    x["cam/dynamic_forcing/2d/SOLIN"] = t(np.abs(300.0 * g.standard_normal((B, 1, 2, H, W))))
+    gph = (50.0 + 20.0 * g.standard_normal((H, W))).astype(np.float32)
+    return {"y_processed": {"cam": y}, "x_physical": {"cam": x}}, gph

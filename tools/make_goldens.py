@@ -278,6 +278,44 @@ def preblock_golden():
     print(f"[golden] preblock: x {tuple(x.shape)} order {list(cmap.keys())}")
 
 
+def conservation_golden():
+    """Gen-2 name-keyed fixers (credit/postblock/conservation.py) on a hybrid sigma grid; `get_forward_data` (xarray) is
+    replaced by an in-memory provider of the arrays defined here, the classes and physics core run unmodified."""
+    import credit.postblock.conservation as G2
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth_batches import conservation_batch
+    lat = np.array([90, 70, 50, 30, 10, -10, -30, -50, -70, -90], dtype=np.float64)
+    lon2d, lat2d = np.meshgrid(np.arange(0, 360, 20, dtype=np.float64), lat)
+
+    class _V:
+        def __init__(self, a):
+            self.values = a
+    out = {}
+    for midpoint in (True, False):
+        tag = "mid" if midpoint else "trapz"
+        batch, gph = conservation_batch(midpoint=midpoint)
+        fake = {"lon2d": _V(lon2d), "lat2d": _V(lat2d), "coef_a": _V(SIGMA_A), "coef_b": _V(SIGMA_B), "PHIS": _V(gph)}
+        G2.get_forward_data = lambda _f: fake
+        phys = dict(save_loc_physics="in-memory.nc", lon_lat_level_name=["lon2d", "lat2d", "coef_a", "coef_b"], grid_type="sigma",
+                    midpoint=midpoint)
+        P = "cam/prognostic/"
+        D = "cam/diagnostic/2d/"
+        fixers = [
+            G2.TracerFixer([P + "3d/Qtot", D + "PRECT"], [1e-9, 0.0], [None, 1.0]),
+            G2.GlobalMassFixer(P + "3d/Qtot", P + "2d/PS", **phys),
+            G2.GlobalWaterFixer(P + "3d/Qtot", P + "2d/PS", D + "PRECT", D + "QFLX", 6, **phys),
+            G2.GlobalEnergyFixerUpDown(P + "3d/T", P + "3d/Qtot", P + "3d/U", P + "3d/V", P + "2d/PS", ["PHIS"],
+                                       "cam/dynamic_forcing/2d/SOLIN", D + "FSUTOA", D + "FLUT", D + "FSDS", D + "FSUS", D + "FLDS",
+                                       D + "FLUS", D + "SHFLX", D + "LHFLX", 6, **phys)]
+        with torch.no_grad():
+            for f in fixers:
+                batch = f(batch)
+        for k in (P + "2d/PS", D + "PRECT", P + "3d/T", P + "3d/Qtot"):
+            out[f"{tag}:{k}"] = batch["y_processed"]["cam"][k].numpy()
+        print(f"[golden] gen-2 conservation chain {tag}: done")
+    np.savez_compressed(os.path.join(GOLD, "conservation_gen2.npz"), **out)
+
+
 SIGMA_A = np.array([200.0, 5000.0, 12000.0, 14000.0, 9000.0, 3000.0, 0.0], dtype=np.float32)       # Pa
 SIGMA_B = np.array([0.0, 0.0, 0.08, 0.3, 0.6, 0.88, 1.0], dtype=np.float32)
 
@@ -343,7 +381,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,updown,pre,C1,C3S,C3,T0W,C1W,T0U")
+    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,updown,pre,gen2,C1,C3S,C3,T0W,C1W,T0U")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -360,6 +398,8 @@ def main():
             fixers_updown_golden()
         elif item == "pre":
             preblock_golden()
+        elif item == "gen2":
+            conservation_golden()
         elif item in ("T0", "T1", "T0W", "T0U"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "C1W":
