@@ -316,6 +316,29 @@ def conservation_golden():
     np.savez_compressed(os.path.join(GOLD, "conservation_gen2.npz"), **out)
 
 
+def reconstruct_golden():
+    """Reconstruct -> FlattenToTensor of the reference (no scaler) on a synthetic y_pred + channel map."""
+    from credit.postblock.reconstruct import FlattenToTensor, Reconstruct
+    g = np.random.Generator(np.random.Philox(key=[41, 1]))
+    B, H, W = 2, 9, 14
+    y = torch.from_numpy(g.standard_normal((B, 11, 1, H, W)).astype(np.float32))
+    cmap = {"era5/prognostic/3d/T": {"slice": slice(0, 4), "orig_shape": (4, 1)},
+            "era5/prognostic/3d/Q": {"slice": slice(4, 8), "orig_shape": (4, 1)},
+            "era5/prognostic/2d/SP": {"slice": slice(8, 9), "orig_shape": (1, 1)},
+            "era5/diagnostic/2d/tp": {"slice": slice(9, 10), "orig_shape": (1, 1)},
+            "era5/diagnostic/2d/evap": {"slice": slice(10, 11), "orig_shape": (1, 1)}}
+    bd = {"y_pred": y.clone(), "metadata": {"target": {"_channel_map": cmap}}}
+    bd = Reconstruct()(bd)
+    out = {"y": y.numpy()}
+    for k, v in bd["y_processed"]["era5"].items():
+        out["rec:" + k] = v.numpy()
+    bd["y_processed"]["era5"]["era5/prognostic/2d/SP"] = bd["y_processed"]["era5"]["era5/prognostic/2d/SP"] * 2.0
+    bd = FlattenToTensor()(bd)
+    out["flat"] = bd["y_pred"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "reconstruct.npz"), **out)
+    print("[golden] reconstruct / flatten:", tuple(bd["y_pred"].shape))
+
+
 SIGMA_A = np.array([200.0, 5000.0, 12000.0, 14000.0, 9000.0, 3000.0, 0.0], dtype=np.float32)       # Pa
 SIGMA_B = np.array([0.0, 0.0, 0.08, 0.3, 0.6, 0.88, 1.0], dtype=np.float32)
 
@@ -381,7 +404,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,updown,pre,gen2,C1,C3S,C3,T0W,C1W,T0U")
+    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,updown,pre,gen2,rec,C1,C3S,C3,T0W,C1W,T0U")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -400,6 +423,8 @@ def main():
             preblock_golden()
         elif item == "gen2":
             conservation_golden()
+        elif item == "rec":
+            reconstruct_golden()
         elif item in ("T0", "T1", "T0W", "T0U"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "C1W":
