@@ -339,6 +339,23 @@ def reconstruct_golden():
     print("[golden] reconstruct / flatten:", tuple(bd["y_pred"].shape))
 
 
+def assemble_golden():
+    """assemble_rollout_batch of the reference (rollout_utils.py:322-430): which tensor object each key is routed to."""
+    from credit.trainers.rollout_utils import assemble_rollout_batch
+    def t(v):
+        return torch.full((1, 1, 1, 2, 2), float(v))
+    keys_ic = ["era5/prognostic/3d/T", "era5/prognostic/2d/SP", "era5/static/2d/LSM", "era5/dynamic_forcing/2d/tsi",
+               "era5/dynamic_forcing/2d/sza", "era5/diagnostic/2d/tp"]
+    ic = {"input": {"era5": {k: t(100 + i) for i, k in enumerate(keys_ic)}, "empty": {}}}
+    pred = {"era5": {"era5/prognostic/3d/T": t(200), "era5/prognostic/2d/SP": t(201), "era5/diagnostic/2d/tp": t(202)}}
+    cur = {"input": {"era5": {"era5/dynamic_forcing/2d/tsi": t(300)}}, "target": None}   # sza missing -> carried forward
+    out = assemble_rollout_batch({"y_processed": pred, "ic_preprocessed": ic}, cur, 1)
+    res = {"keys": np.array(list(out["input"]["era5"].keys())), "vals": np.array([float(v.flatten()[0]) for v in out["input"]["era5"].values()]),
+           "sources": np.array(list(out["input"].keys()))}
+    np.savez_compressed(os.path.join(GOLD, "assemble_rollout.npz"), **res)
+    print("[golden] assemble_rollout_batch:", dict(zip(res["keys"], res["vals"])))
+
+
 SIGMA_A = np.array([200.0, 5000.0, 12000.0, 14000.0, 9000.0, 3000.0, 0.0], dtype=np.float32)       # Pa
 SIGMA_B = np.array([0.0, 0.0, 0.08, 0.3, 0.6, 0.88, 1.0], dtype=np.float32)
 
@@ -404,7 +421,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,updown,pre,gen2,rec,C1,C3S,C3,T0W,C1W,T0U")
+    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -425,6 +442,8 @@ def main():
             conservation_golden()
         elif item == "rec":
             reconstruct_golden()
+        elif item == "asm":
+            assemble_golden()
         elif item in ("T0", "T1", "T0W", "T0U"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "C1W":
