@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
     const int ky_end = (p.dbg & 32) ? 1 : KS;
     for (int ky = 0; ky < ky_end; ++ky) {
       uint4 n32[8];
-      const uint4* wn = w32 + (int64_t)(ky + 1 < KS ? ky + 1 : ky) * 8 * 64;
+      const uint4* wn = w32 + (int64_t)((p.dbg & 64) ? 0 : (ky + 1 < KS ? ky + 1 : ky)) * 8 * 64;  // dbg 64: timing experiment, same weights every row (L1-hot)
 #pragma unroll
       for (int k4 = 0; k4 < 8; ++k4) n32[k4] = wn[k4 * 64];
       const bool in16 = f16 && ky >= 8 && ky < 24;
