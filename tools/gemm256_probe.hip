@@ -37,8 +37,8 @@ struct G256 {
 };
 
 // WM x WN = wave tile in 16-row fragments (8 x 8 = 128 x 128); waves 2 x 2
-template <int NST, int FM, int FN>
-__global__ __launch_bounds__(256, 1) void gemm256_kernel(const G256 p, const char* __restrict__ zero_page) {
+template <int NST, int FM, int FN, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void gemm256_kernel(const G256 p, const char* __restrict__ zero_page) {
   constexpr int KB = 64;                       // bytes of K per step = one v_mfma_f32_16x16x32_bf16
   constexpr int BM = 2 * FM * 16, BN = 2 * FN * 16;
   constexpr int STAGE = (BM + BN) * KB;
@@ -183,17 +183,17 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(const G256 p, const cha
   }
 }
 
-template <int NST, int FM, int FN>
+template <int NST, int FM, int FN, int OCC = 1>
 static void launch(const G256& p, const char* zero, hipStream_t st) {
   constexpr int BM = 2 * FM * 16, BN = 2 * FN * 16;
   constexpr int lds = NST * (BM + BN) * 64;
   static bool once = false;
   if (!once) {
-    WX_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<NST, FM, FN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    WX_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<NST, FM, FN, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     once = true;
   }
   const int blocks = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm256_kernel<NST, FM, FN>), dim3(blocks), dim3(256), lds, st, p, zero);
+  hipLaunchKernelGGL((gemm256_kernel<NST, FM, FN, OCC>), dim3(blocks), dim3(256), lds, st, p, zero);
 }
 
 static void* dalloc(size_t n) {
@@ -230,6 +230,9 @@ int main(int argc, char** argv) {
       case 1: launch<3, 8, 8>(p, zero, st); break;   // 256 x 256, 3 stages
       case 2: launch<4, 8, 4>(p, zero, st); break;   // 256 px x 128 ch
       case 3: launch<4, 4, 8>(p, zero, st); break;   // 128 px x 256 ch
+      case 4: launch<3, 8, 4, 2>(p, zero, st); break;   // 256 px x 128 ch, 2 workgroups / CU
+      case 5: launch<3, 4, 8, 2>(p, zero, st); break;   // 128 px x 256 ch, 2 workgroups / CU
+      case 6: launch<3, 4, 4, 4>(p, zero, st); break;   // 128 x 128, 4 workgroups / CU (the engine's tile, this pipeline)
       default: printf("bad cfg\n"); exit(1);
     }
   };
