@@ -172,9 +172,48 @@ int wx_post_apply(wx_post_handle p, const float* x_dev, float* y_dev, void* stre
  * take ownership. */
 int wx_attach_postblock(wx_handle h, wx_post_handle p);
 
-/* ---- lat-band sharding; optional -------------------------
- * wx_set_comm <-> DomainParallelManager (credit/domain_parallel/manager.py:22).  `nccl_comm` is an
- * ncclComm_t (RCCL) passed as void*.  Not required for single-GPU or replica runs. */
+/* ---- lat-band sharding of ONE forecast (BASELINE config 4) -----------------------------------------
+ * Replaces credit/domain_parallel (manager.py:22 DomainParallelManager, halo_exchange.py:21-79, layers.py:29-626,
+ * sharding.py:13-68) and credit/parallel/domain.py:25-110 (shard_spatial / gather_spatial) for the inference path.
+ * Rank r of n owns a window-aligned band of latitude rows of every stage map (csrc/wx_band.h).  A forecast step is a
+ * sequence of compute segments separated by EXCHANGES (conv halos, the row redistribution that keeps the dilated "long"
+ * attention exact, the GroupNorm sums); the engine packs what it must send into a staging buffer and returns, the
+ * caller moves bytes between ranks (torch.distributed P2P over RCCL/xGMI, or any other transport) and resumes:
+ *
+ *     wx_band_enable(h, rank, n);  wx_band_info(...);  wx_band_set_staging(h, send, sb, recv, rb);
+ *     xid = wx_band_begin(h, x_band, frc_band, y_band, y_phys_band, x_next_band, stream, &xid);
+ *     while (xid >= 0) { wx_band_exchange(h, xid, sends, ..., recvs, ...);  <move the bytes>;  wx_band_resume(h, &xid); }
+ *
+ * x / frc / y / y_phys / x_next are BANDS: [channels][own_rows][W] float32, rows own_row0 .. own_row0+own_rows-1 of the grid.
+ * Semantics of the step are those of wx_step.  The result equals the unsharded engine's up to fp32 summation order of
+ * the GroupNorm statistics (summed in rank order: identical on every rank). */
+typedef struct wx_band_msg {
+  int32_t peer;      /* the other rank */
+  int64_t offset;    /* byte offset in the send (resp. receive) staging buffer */
+  int64_t bytes;
+} wx_band_msg;
+int wx_band_enable(wx_handle h, int rank, int nranks);
+int wx_band_info(wx_handle h, int* own_row0, int* own_rows, int64_t* send_bytes, int64_t* recv_bytes, int* n_exchanges);
+int wx_band_set_staging(wx_handle h, void* send_dev, int64_t send_bytes, void* recv_dev, int64_t recv_bytes);
+/* messages of exchange `xid` for this rank: at most nranks-1 each way */
+int wx_band_exchange(wx_handle h, int xid, wx_band_msg* sends, int cap_sends, int* n_sends, wx_band_msg* recvs, int cap_recvs,
+                     int* n_recvs);
+int wx_band_begin(wx_handle h, const float* x_band, const float* frc_band, float* y_band, float* y_phys_band, float* x_next_band,
+                  void* stream, int* next_xid);
+int wx_band_resume(wx_handle h, int* next_xid);   /* *next_xid = -1 when the step is complete */
+/* Host-only view of the same plan (no GPU needed: the CPU tests check it for every rank of a world):
+ * rows owned per stage and the (peer, offset, bytes) messages of every exchange. */
+typedef struct wx_band_plan_s* wx_band_plan;
+int wx_band_plan_create(const wx_config* cfg, int nranks, wx_band_plan* out);
+int wx_band_plan_destroy(wx_band_plan p);
+int wx_band_plan_num_exchanges(wx_band_plan p, int* n);
+int wx_band_plan_exchange_name(wx_band_plan p, int xid, const char** name);
+int wx_band_plan_messages(wx_band_plan p, int xid, int rank, wx_band_msg* sends, int cap_sends, int* n_sends, wx_band_msg* recvs,
+                          int cap_recvs, int* n_recvs);
+/* which: 0..3 = first row of the short layout at that stage, 4..7 = first PHASE of the long layout, 8 = input/output rows;
+ * starts[nranks+1] */
+int wx_band_plan_partition(wx_band_plan p, int which, int32_t* starts);
+/* legacy name kept for callers that probe for sharding support: nranks == 1 is a no-op, anything else points at wx_band_* */
 int wx_set_comm(wx_handle h, void* nccl_comm, int rank, int nranks);
 
 /* ---- introspection for parity tests and the roofline report ----------------

@@ -26,7 +26,7 @@ struct AttnParams {
   const float* bias;  // [NP][NP] fp32, NP = 16*NKF; padded keys hold -1e30
   const float* tb;    // the same bias as its generating table [(2w-1)^2] (bias[i][j] depends on (row, col) offsets only):
                       // BT kernels keep it in LDS and never touch `bias` (49 KB of L2 reads per task otherwise)
-  int H, W, C, heads, wsz, kind;  // kind 0 short, 1 long
+  int H, W, C, heads, wsz, kind;  // kind 0 short, 1 long, 2 long windows whose rows were made contiguous (lat-band layout)
   float scale;                    // bf16 engine: scale * log2(e), and the bias table is pre-multiplied by log2(e)
   unsigned long long* trace;      // tools/attn_probe only (WX_ATTN_TRACE builds): [tasks][8] phase ticks
   int pack;                       // windows per 16-token tile (1, or 16 / wsz^2 for the 2x2 windows of the long
@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
     if (p.kind == 0) {
       py = wy * p.wsz + ty;
       px = wx_ * p.wsz + tx;
+    } else if (p.kind == 2) {  // wx_band.h long layout: phase-major rows, columns still dilated
+      py = wy * p.wsz + ty;
+      px = tx * wins_x + wx_;
     } else {
       py = ty * wins_y + wy;
       px = tx * wins_x + wx_;

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -19,6 +20,7 @@
 #include "wx_common.h"
 #include "wx_elem.h"
 #include "wx_embed.h"
+#include "wx_band.h"
 #include "wx_gemm.h"
 #include "wx_post.h"
 #include "wx_pre.h"
@@ -73,6 +75,12 @@ class EngineBase {
   virtual void profile_reset() = 0;
   virtual int profile_read(wx_kernel_stat* out, int cap) = 0;
   virtual void attach_post(PostBlock* p) = 0;
+  virtual void band_enable(int rank, int nranks) = 0;
+  virtual void band_info(int* own_row0, int* own_rows, int64_t* send_bytes, int64_t* recv_bytes, int* n_exchanges) = 0;
+  virtual void band_set_staging(void* send, int64_t send_bytes, void* recv, int64_t recv_bytes) = 0;
+  virtual int band_messages_of(int xid, wx_band_msg* sends, int cap_s, int* n_s, wx_band_msg* recvs, int cap_r, int* n_r) = 0;
+  virtual int band_begin(const float* x_own, const float* frc_own, float* y, float* y_phys, float* x_next, hipStream_t s) = 0;
+  virtual int band_resume() = 0;
   int device = 0;
 };
 
@@ -85,6 +93,7 @@ class Engine : public EngineBase {
     build_spec();
   }
   ~Engine() override {
+    if (device < 0) return;   // host-only instance (wx_band_plan_create): nothing was allocated
     (void)hipSetDevice(device);
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -774,8 +783,14 @@ class Engine : public EngineBase {
     acts_ready = true;
   }
 
-  T* stream_ptr(int s) { return s < 3 ? cat[s] + cfg.dim[s] : x3; }
-  int64_t stream_ld(int s) { return s < 3 ? 2 * cfg.dim[s] : cfg.dim[s]; }
+  T* stream_ptr(int s) {
+    if (band_on) {   // lat-band mode: the long layout has its own buffer; the short one sits behind 1 halo row of the concat buffer
+      if (b_long[s]) return blong[s];
+      return s < 3 ? bcat[s] + (int64_t)sw[s] * 2 * cfg.dim[s] + cfg.dim[s] : bx3;
+    }
+    return s < 3 ? cat[s] + cfg.dim[s] : x3;
+  }
+  int64_t stream_ld(int s) { return (s < 3 && !(band_on && b_long[s])) ? 2 * cfg.dim[s] : cfg.dim[s]; }
 
   // ------------------------------------------------------------------ step glue state
   void set_denorm(const float* mean, const float* stdv, int n) override {
@@ -988,7 +1003,7 @@ class Engine : public EngineBase {
       if (!qkv_ready) gemm("gemm_qkv", a.qkv, x, h, w, ld, 1, 0, 0, h, w, scratch, 3 * c, rs, 0, nullptr, 0);
       AttnParams p;
       p.qkv = scratch; p.ld_qkv = 3 * c; p.out = attn_o; p.ld_out = c; p.bias = f_dev + a.bias_tab; p.tb = a.bias_tb >= 0 ? f_dev + a.bias_tb : nullptr;
-      p.H = h; p.W = w; p.C = c; p.heads = c / 32; p.wsz = a.wsz; p.kind = a.kind;
+      p.H = h; p.W = w; p.C = c; p.heads = c / 32; p.wsz = a.wsz; p.kind = attn_kind_override >= 0 ? attn_kind_override : a.kind;
       p.scale = (float)((sizeof(T) == 2 ? 1.4426950408889634 : 1.0) / std::sqrt(32.0));
       p.pack = attn_pack(a.wsz);
       const double n = (double)a.wsz * a.wsz;
@@ -1002,7 +1017,7 @@ class Engine : public EngineBase {
     capture(dbg_name, x, h, w, c, ld, w);
   }
   bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on; }
-  bool ff_makes_qkv(const FFL& f) const { return ff_takes_out(f) && fuse_qkv && f.pack_pp >= 0; }
+  bool ff_makes_qkv(const FFL& f) const { return ff_takes_out(f) && fuse_qkv && f.pack_pp >= 0 && !band_on; }
   void feedforward(const FFL& f, int s, const std::string& dbg_name, const AttnL* pre = nullptr) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
@@ -1030,8 +1045,7 @@ class Engine : public EngineBase {
     stat_tiles_ready = st ? conv_gemm_n_tiles(c) : 0;
     capture(dbg_name, x, h, w, c, ld, w);
   }
-  void group_norm_silu(const T* x, int c, int64_t m, int64_t g_off, int64_t b_off, const T* res, int64_t res_ld, T* out,
-                       int64_t out_ld, bool have_partials) {
+  void gn_local_stats(const T* x, int c, int64_t m, bool have_partials) {   // -> gn_acc[2c] (sum, sum sq) in fp64
     constexpr int VEC = 16 / (int)sizeof(T);
     if (c / VEC > 256) throw ConfigError("GroupNorm width unsupported");
     if (have_partials) {  // the producing conv's epilogue left per-tile (sum, sum sq): just fold them
@@ -1048,8 +1062,13 @@ class Engine : public EngineBase {
         WX_HIP(hipGetLastError());
       });
     }
+  }
+  // gn_acc over m_count pixels (the whole map) -> per-channel affine; applied to the m rows at x
+  void gn_finalize_apply(const T* x, int c, int64_t m, int64_t m_count, int64_t g_off, int64_t b_off, const T* res, int64_t res_ld, T* out,
+                         int64_t out_ld) {
+    constexpr int VEC = 16 / (int)sizeof(T);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(c, 128)), dim3(128), 0, cur_stream, gn_acc, f_dev + g_off, f_dev + b_off, c,
-                       cfg.dim[0], (double)m, 1e-5f, gn_scale, gn_shift);
+                       cfg.dim[0], (double)m_count, 1e-5f, gn_scale, gn_shift);
     WX_HIP(hipGetLastError());
     const int64_t total = m * (c / VEC);
     const int ablocks = (int)std::min<int64_t>(4096, (total + 255) / 256);
@@ -1058,76 +1077,109 @@ class Engine : public EngineBase {
       WX_HIP(hipGetLastError());
     });
   }
+  void group_norm_silu(const T* x, int c, int64_t m, int64_t g_off, int64_t b_off, const T* res, int64_t res_ld, T* out,
+                       int64_t out_ld, bool have_partials) {
+    gn_local_stats(x, c, m, have_partials);
+    gn_finalize_apply(x, c, m, m, g_off, b_off, res, res_ld, out, out_ld);
+  }
 
   // ------------------------------------------------------------------ forward
+  // a1: padded rows [row0, row0 + nrows) of the earth-padded grid -> buffer rows dst_row.. of `dst` (Hb buffer rows);
+  // `x` holds input rows [src_row0, src_row0 + src_rows) of every channel (the whole grid outside lat-band mode)
+  void pack_input(const float* x, T* dst, T* dst_planar, int Hb, int row0, int nrows, int dst_row, int src_row0, int src_rows) {
+    PackParams p;
+    p.x = x; p.dst = dst; p.C = C_in; p.H = cfg.image_height; p.W = cfg.image_width;
+    p.p0 = cfg.pad_activate ? cfg.pad_lat[0] : 0; p.p1 = cfg.pad_activate ? cfg.pad_lat[1] : 0;
+    p.pl = cfg.pad_activate ? cfg.pad_lon[0] : 0; p.pr = cfg.pad_activate ? cfg.pad_lon[1] : 0;
+    p.halo = halo; p.cpad = cpad0; p.dst_planar = dst_planar; p.Hb = Hb;
+    p.row0 = row0; p.src_row0 = src_row0; p.src_rows = src_rows; p.dst_row = dst_row;
+    if (nrows <= 0) return;
+    timed("pack_input", 0.0, (double)C_in * nrows * cfg.image_width * 4.0 + (double)nrows * Wp * cpad0 * sizeof(T), [&] {
+      hipLaunchKernelGGL(pack_input_kernel<T>, dim3(cdiv(Wp, 64), nrows), dim3(256), 0, cur_stream, p);
+      WX_HIP(hipGetLastError());
+    });
+  }
+  // a2: the CrossEmbed of stage s.  `in` = stage-0: packed input buffer of Hb rows (xin layout); later stages: rows of the
+  // previous stream, in_h of them, whose first row is row `in_row0` relative to stride*first-output-row (0 for the whole map,
+  // -emb_lo in lat-band mode where the conv halo is materialised).
+  void cross_embed(int s, const T* in, const T* in_planar, int in_h, int in_row0, int64_t in_ld_s) {
+    const StageL& st = stages[s];
+    T* x = stream_ptr(s);
+    const int64_t ld = stream_ld(s);
+    if (sh[s] <= 0) return;
+    int choff = 0;
+    for (size_t b = 0; b < st.embed.size(); ++b) {
+      const int k = st.embed_k[b], stv = cfg.embed_strides[s], pd = (k - stv) / 2;
+      if (s == 0 && st.patch[b].wt >= 0 && use_patch && st.embed_k.back() == 32 && st.patch.back().wt >= 0) {
+        if (k != 32) { choff += st.embed[b].n; continue; }  // rides along in the fused launch issued with k = 32
+        EmbedPatchParams ep;
+        std::memset(&ep, 0, sizeof(ep));
+        ep.xin = in; ep.xin_planar = in_planar; ep.Hb = in_h; ep.Wb = Wp + 2 * halo; ep.cpad = cpad0; ep.org = halo - 15;
+        ep.out_ld = ld; ep.out_h = sh[0]; ep.out_w = sw[0]; ep.dbg = dbg_flags;
+        double fl = 0.0;
+        int off = 0;
+        for (size_t j = 0; j < st.embed.size(); ++j) {
+          const PatchW& pw = st.patch[j];
+          const int kj = st.embed_k[j];
+          if (pw.wt >= 0) {
+            fl += 2.0 * sh[0] * sw[0] * pw.n * kj * kj * C_in;
+            if (kj == 32) { ep.wt32 = wt_dev + pw.wt; ep.bias32 = f_dev + pw.bias; ep.out32 = x + off; ep.n32 = pw.n; }
+            if (kj == 16) { ep.wt16 = wt_dev + pw.wt; ep.bias16 = f_dev + pw.bias; ep.out16 = x + off; ep.n16 = pw.n; }
+            if (kj == 8) { ep.wt8 = wt_dev + pw.wt; ep.bias8 = f_dev + pw.bias; ep.out8 = x + off; ep.n8 = pw.n; }
+          }
+          off += st.embed[j].n;
+        }
+        timed("embed_patch", fl, (double)(in_h * Wp) * cpad0 * sizeof(T) + (double)sh[0] * sw[0] * 64 * sizeof(T), [&] {
+          launch_embed_patch<T>(ep, zero_page, cur_stream);
+        });
+      } else if (s == 0)
+        gemm("gemm_embed", st.embed[b], in, in_h, Wp + 2 * halo, cpad0, stv, pd - halo, pd - halo, sh[0], sw[0],
+             x + choff, ld, nullptr, 0, nullptr, 0);
+      else
+        gemm("gemm_embed", st.embed[b], in, in_h, sw[s - 1], in_ld_s, stv, pd + in_row0, pd, sh[s], sw[s],
+             x + choff, ld, nullptr, 0, nullptr, 0);
+      choff += st.embed[b].n;
+    }
+  }
+  // a4-a7: the transformer blocks of stage s on the rows the stream currently holds
+  void stage_blocks(int s) {
+    const StageL& st = stages[s];
+    const std::string sp = "layers." + std::to_string(s);
+    bool qkv_made = false;  // the previous fused kernel already produced this attention's q|k|v
+    for (size_t d = 0; d < st.blocks.size(); ++d) {
+      const std::string bp = sp + ".1.layers." + std::to_string(d);
+      const BlockL& bl = st.blocks[d];
+      const bool ds = ff_takes_out(bl.sf), dl = ff_takes_out(bl.lf);
+      attention(bl.sa, s, bp + ".0", ds, qkv_made);
+      feedforward(bl.sf, s, bp + ".1", ds ? &bl.sa : nullptr);
+      attention(bl.la, s, bp + ".2", dl, ds && ff_makes_qkv(bl.sf));
+      feedforward(bl.lf, s, bp + ".3", dl ? &bl.la : nullptr);
+      qkv_made = dl && ff_makes_qkv(bl.lf);
+    }
+  }
+  void block_half(int s, int d, bool long_half) {   // lat-band mode: one (attention, feed-forward) pair
+    if (sh[s] <= 0) return;
+    const BlockL& bl = stages[s].blocks[d];
+    const AttnL& a = long_half ? bl.la : bl.sa;
+    const FFL& f = long_half ? bl.lf : bl.sf;
+    const bool df = ff_takes_out(f);
+    attention(a, s, "", df, false);
+    feedforward(f, s, "", df ? &a : nullptr);
+  }
   void core(const float* x_item) {
     // a1: pack + earth halo
-    {
-      PackParams p;
-      p.x = x_item; p.dst = xin; p.C = C_in; p.H = cfg.image_height; p.W = cfg.image_width;
-      p.p0 = cfg.pad_activate ? cfg.pad_lat[0] : 0; p.p1 = cfg.pad_activate ? cfg.pad_lat[1] : 0;
-      p.pl = cfg.pad_activate ? cfg.pad_lon[0] : 0; p.pr = cfg.pad_activate ? cfg.pad_lon[1] : 0;
-      p.halo = halo; p.cpad = cpad0; p.dst_planar = xin_planar; p.Hb = Hp + 2 * halo;
-      timed("pack_input", 0.0, (double)C_in * cfg.image_height * cfg.image_width * 4.0 + (double)Hp * Wp * cpad0 * sizeof(T), [&] {
-        hipLaunchKernelGGL(pack_input_kernel<T>, dim3(cdiv(Wp, 64), Hp), dim3(256), 0, cur_stream, p);
-        WX_HIP(hipGetLastError());
-      });
-      capture("pad", xin + ((int64_t)halo * (Wp + 2 * halo) + halo) * cpad0, Hp, Wp, C_in, cpad0, Wp + 2 * halo);
-    }
+    pack_input(x_item, xin, xin_planar, Hp + 2 * halo, 0, Hp, halo, 0, cfg.image_height);
+    capture("pad", xin + ((int64_t)halo * (Wp + 2 * halo) + halo) * cpad0, Hp, Wp, C_in, cpad0, Wp + 2 * halo);
     // encoder
     for (int s = 0; s < 4; ++s) {
       cur_stage = s;
       stat_tiles_ready = 0;  // the CrossEmbed output has no partials yet
-      const StageL& st = stages[s];
-      T* x = stream_ptr(s);
-      const int64_t ld = stream_ld(s);
-      int choff = 0;
-      for (size_t b = 0; b < st.embed.size(); ++b) {
-        const int k = st.embed_k[b], stv = cfg.embed_strides[s], pd = (k - stv) / 2;
-        if (s == 0 && st.patch[b].wt >= 0 && use_patch && st.embed_k.back() == 32 && st.patch.back().wt >= 0) {
-          if (k != 32) { choff += st.embed[b].n; continue; }  // rides along in the fused launch issued with k = 32
-          EmbedPatchParams ep;
-          std::memset(&ep, 0, sizeof(ep));
-          ep.xin = xin; ep.xin_planar = xin_planar; ep.Hb = Hp + 2 * halo; ep.Wb = Wp + 2 * halo; ep.cpad = cpad0; ep.org = halo - 15;
-          ep.out_ld = ld; ep.out_h = sh[0]; ep.out_w = sw[0]; ep.dbg = dbg_flags;
-          double fl = 0.0;
-          int off = 0;
-          for (size_t j = 0; j < st.embed.size(); ++j) {
-            const PatchW& pw = st.patch[j];
-            const int kj = st.embed_k[j];
-            if (pw.wt >= 0) {
-              fl += 2.0 * sh[0] * sw[0] * pw.n * kj * kj * C_in;
-              if (kj == 32) { ep.wt32 = wt_dev + pw.wt; ep.bias32 = f_dev + pw.bias; ep.out32 = x + off; ep.n32 = pw.n; }
-              if (kj == 16) { ep.wt16 = wt_dev + pw.wt; ep.bias16 = f_dev + pw.bias; ep.out16 = x + off; ep.n16 = pw.n; }
-              if (kj == 8) { ep.wt8 = wt_dev + pw.wt; ep.bias8 = f_dev + pw.bias; ep.out8 = x + off; ep.n8 = pw.n; }
-            }
-            off += st.embed[j].n;
-          }
-          timed("embed_patch", fl, (double)(Hp * Wp) * cpad0 * sizeof(T) + (double)sh[0] * sw[0] * 64 * sizeof(T), [&] {
-            launch_embed_patch<T>(ep, zero_page, cur_stream);
-          });
-        } else if (s == 0)
-          gemm("gemm_embed", st.embed[b], xin, Hp + 2 * halo, Wp + 2 * halo, cpad0, stv, pd - halo, pd - halo, sh[0], sw[0],
-               x + choff, ld, nullptr, 0, nullptr, 0);
-        else
-          gemm("gemm_embed", st.embed[b], stream_ptr(s - 1), sh[s - 1], sw[s - 1], stream_ld(s - 1), stv, pd, pd, sh[s], sw[s],
-               x + choff, ld, nullptr, 0, nullptr, 0);
-        choff += st.embed[b].n;
-      }
+      if (s == 0) cross_embed(0, xin, xin_planar, Hp + 2 * halo, 0, 0);
+      else cross_embed(s, stream_ptr(s - 1), nullptr, sh[s - 1], 0, stream_ld(s - 1));
       const std::string sp = "layers." + std::to_string(s);
-      capture(sp + ".0", x, sh[s], sw[s], cfg.dim[s], ld, sw[s]);
-      bool qkv_made = false;  // the previous fused kernel already produced this attention's q|k|v
-      for (size_t d = 0; d < st.blocks.size(); ++d) {
-        const std::string bp = sp + ".1.layers." + std::to_string(d);
-        const BlockL& bl = st.blocks[d];
-        const bool ds = ff_takes_out(bl.sf), dl = ff_takes_out(bl.lf);
-        attention(bl.sa, s, bp + ".0", ds, qkv_made);
-        feedforward(bl.sf, s, bp + ".1", ds ? &bl.sa : nullptr);
-        attention(bl.la, s, bp + ".2", dl, ds && ff_makes_qkv(bl.sf));
-        feedforward(bl.lf, s, bp + ".3", dl ? &bl.la : nullptr);
-        qkv_made = dl && ff_makes_qkv(bl.lf);
-      }
-      capture(sp + ".1", x, sh[s], sw[s], cfg.dim[s], ld, sw[s]);
+      capture(sp + ".0", stream_ptr(s), sh[s], sw[s], cfg.dim[s], stream_ld(s), sw[s]);
+      stage_blocks(s);
+      capture(sp + ".1", stream_ptr(s), sh[s], sw[s], cfg.dim[s], stream_ld(s), sw[s]);
     }
     // decoder
     stat_tiles_ready = 0;
@@ -1186,6 +1238,7 @@ class Engine : public EngineBase {
     p.mean = have_denorm ? d_mean : nullptr; p.stdv = have_denorm ? d_std : nullptr;
     p.thr_lo = have_tracer ? d_lo : nullptr; p.thr_hi = have_tracer ? d_hi : nullptr;
     p.tracer_denorm = tracer_denorm;
+    p.oy0 = 0; p.dec_row0 = 0; p.Hloc = Ho;
     const size_t lds = (size_t)C_out * 65 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -1199,12 +1252,484 @@ class Engine : public EngineBase {
       WX_HIP(hipGetLastError());
     });
   }
+  // ------------------------------------------------------------------ lat-band mode (wx_band.h)
+  // One forecast sharded over n ranks by latitude.  A step is a PROGRAM of ops separated by exchanges; the driver
+  // (wxengine/latband.py: torch.distributed P2P over RCCL, gloo, or in-process copies between virtual ranks) calls
+  // band_begin / band_resume and moves the bytes of the staging buffers in between -- the engine packs the row runs of
+  // the plan into `b_send` before handing control back and unpacks `b_recv` when it is resumed.
+  bool band_on = false;
+  int b_rank = 0, b_n = 1;
+  BandPlan bplan;
+  int gsh[4] = {0, 0, 0, 0};           // global stage rows; sh[] holds the LOCAL rows of the current layout while a band step runs
+  T *bcat[3] = {nullptr, nullptr, nullptr}, *bx3 = nullptr, *blong[4] = {nullptr, nullptr, nullptr, nullptr};
+  T *bxin = nullptr, *bxin_planar = nullptr, *bemb_in = nullptr, *bdec_in = nullptr, *bscut = nullptr, *bta = nullptr, *btb = nullptr,
+    *bdec = nullptr;
+  float* bxneed = nullptr;
+  double* gn_all = nullptr;
+  bool b_long[4] = {false, false, false, false};
+  char *b_send = nullptr, *b_recv = nullptr;
+  int64_t b_send_need = 0, b_recv_need = 0;
+  std::vector<std::function<void()>> b_ops;
+  std::vector<int> b_xid;              // exchange that follows op i, or -1
+  size_t b_pc = 0;
+  int b_pending = -1;
+  const float *bx_own = nullptr, *bfrc_own = nullptr;
+  float *by = nullptr, *by_phys = nullptr, *bx_next = nullptr;
+  int attn_kind_override = -1;
+
+  int b_rows(int s) const { return bplan.g.rows_short(s, b_rank); }
+  int b_own_rows() const { return bplan.g.po[b_rank + 1] - bplan.g.po[b_rank]; }
+
+  static BandModel band_model(const Engine& e, int n) {
+    BandModel m;
+    m.n = n; m.C_in = e.C_in; m.H = e.cfg.image_height; m.W = e.cfg.image_width;
+    m.p0 = e.cfg.pad_activate ? e.cfg.pad_lat[0] : 0; m.p1 = e.cfg.pad_activate ? e.cfg.pad_lat[1] : 0;
+    m.Hp = e.Hp; m.halo = e.halo;
+    for (int s = 0; s < 4; ++s) {
+      m.stride[s] = e.cfg.embed_strides[s];
+      m.sh[s] = e.band_on ? e.gsh[s] : e.sh[s]; m.sw[s] = e.sw[s];
+      m.wl[s] = e.cfg.local_window_size[s]; m.wg[s] = e.cfg.global_window_size[s];
+      m.depth[s] = e.cfg.depth[s]; m.dim[s] = e.cfg.dim[s];
+      int lo = 0, hi = 0;
+      for (int b = 0; b < e.cfg.n_embed_kernels[s]; ++b) {
+        const int k = e.cfg.embed_kernels[s][b], pd = (k - m.stride[s]) / 2;
+        lo = std::max(lo, pd);
+        hi = std::max(hi, k - m.stride[s] - pd);
+      }
+      m.emb_lo[s] = lo; m.emb_hi[s] = hi;
+    }
+    m.elem = (int)sizeof(T);
+    for (int i = 0; i < 3; ++i) m.up_cout[i] = e.cfg.dim[2 - i];
+    m.Hd = e.Hd; m.Wd = e.Wd; m.Hu = e.Hu; m.Ho = e.Ho; m.off_y = e.cfg.pad_activate ? e.cfg.pad_lat[0] : 0;
+    m.interp = e.cfg.interp; m.ld_dec = e.ld_dec;
+    return m;
+  }
+  static void band_check_supported(const Engine& e) {
+    if (e.cfg.arch != WX_ARCH_CROSSFORMER) throw ConfigError("lat-band mode: only the legacy `crossformer` architecture (the 0.25-degree config) is wired");
+    if (e.cfg.frames != 1 || e.cfg.output_frames != 1) throw ConfigError("lat-band mode needs frames == output_frames == 1");
+    if (e.halo != 15 && e.stages[0].embed_k.size() && false) throw ConfigError("unreachable");
+  }
+
+  void band_enable(int rank, int n) override {
+    if (!finalized) throw StateError("wx_band_enable: finalize the weights first");
+    if (band_on) throw StateError("wx_band_enable: already enabled");
+    if (n < 1 || rank < 0 || rank >= n) throw ConfigError("wx_band_enable: bad rank / nranks");
+    if (post) throw ConfigError("lat-band mode: an attached post block needs global reductions that are not wired yet");
+    band_check_supported(*this);
+    WX_HIP(hipSetDevice(device));
+    for (int s = 0; s < 4; ++s) gsh[s] = sh[s];
+    bplan.build(band_model(*this, n));
+    b_rank = rank; b_n = n;
+    const BandGeom& g = bplan.g;
+    if (g.rows_short(0, rank) <= 0) throw ConfigError("lat-band mode: more ranks than window rows at stage 0");
+    // ---- buffers of this band
+    const int st0 = cfg.embed_strides[0];
+    const int64_t xin_elems = (int64_t)(st0 * g.rows_short(0, rank) + 2 * halo + 2) * (Wp + 2 * halo + 2) * cpad0;
+    bxin = (T*)dalloc(xin_elems * sizeof(T));
+    WX_HIP(hipMemset(bxin, 0, xin_elems * sizeof(T)));
+    if (use_patch && planar_xin) {
+      bxin_planar = (T*)dalloc(xin_elems * sizeof(T));
+      WX_HIP(hipMemset(bxin_planar, 0, xin_elems * sizeof(T)));
+    }
+    const int xneed = bplan.x_need_hi[rank] - bplan.x_need_lo[rank];
+    bxneed = (float*)dalloc((size_t)std::max(1, xneed) * C_in * cfg.image_width * sizeof(float));
+    int64_t emb_max = 1, dec_in_max = 1, dt_max = 1;
+    for (int s = 0; s < 4; ++s) {
+      const int64_t rs = g.rows_short(s, rank), rl = g.rows_long(s, rank);
+      if (s < 3) {
+        const int64_t el = (rs + 2) * sw[s] * 2 * cfg.dim[s];
+        bcat[s] = (T*)dalloc(el * sizeof(T));
+        WX_HIP(hipMemset(bcat[s], 0, el * sizeof(T)));
+      } else {
+        bx3 = (T*)dalloc(std::max<int64_t>(1, rs * sw[s] * cfg.dim[s]) * sizeof(T));
+      }
+      if (cfg.global_window_size[s] > 1) blong[s] = (T*)dalloc(std::max<int64_t>(1, rl * sw[s] * cfg.dim[s]) * sizeof(T));
+      if (s > 0) emb_max = std::max(emb_max, (int64_t)(cfg.embed_strides[s] * rs + bplan.m.emb_lo[s] + bplan.m.emb_hi[s]) * sw[s - 1] * cfg.dim[s - 1]);
+      // scratch / attn_o / rowstat / statpart of the whole-map engine are large enough for any band
+    }
+    for (int i = 0; i < 3; ++i) {
+      const int si = 3 - i, so = 2 - i;
+      const int64_t rows_in = (g.rows_short(so, rank) + 1) / 2 + 1;
+      dec_in_max = std::max(dec_in_max, rows_in * sw[si] * (i == 0 ? cfg.dim[3] : 2 * cfg.dim[si]));
+      dt_max = std::max(dt_max, (int64_t)(g.rows_short(so, rank) + 2) * sw[so] * ups[i].cout);
+    }
+    bemb_in = (T*)dalloc(emb_max * sizeof(T));
+    bdec_in = (T*)dalloc(dec_in_max * sizeof(T));
+    bscut = (T*)dalloc(dt_max * sizeof(T));
+    bta = (T*)dalloc(dt_max * sizeof(T));
+    btb = (T*)dalloc(dt_max * sizeof(T));
+    WX_HIP(hipMemset(bscut, 0, dt_max * sizeof(T)));
+    WX_HIP(hipMemset(btb, 0, dt_max * sizeof(T)));
+    const int64_t dec_el = (int64_t)(2 * g.rows_short(0, rank) + 2) * Wd * ld_dec;
+    bdec = (T*)dalloc(dec_el * sizeof(T));
+    WX_HIP(hipMemset(bdec, 0, dec_el * sizeof(T)));
+    gn_all = (double*)dalloc((size_t)n * 2 * cfg.dim[3] * sizeof(double));
+    for (const BandExchange& x : bplan.xs) {
+      b_send_need = std::max(b_send_need, band_send_bytes(x, rank));
+      b_recv_need = std::max(b_recv_need, band_recv_bytes(x, rank));
+    }
+    band_on = true;
+    band_upload_maps();
+    band_build_program();
+  }
+  void band_info(int* own_row0, int* own_rows, int64_t* send_bytes, int64_t* recv_bytes, int* n_exchanges) override {
+    band_need();
+    *own_row0 = bplan.g.po[b_rank]; *own_rows = b_own_rows();
+    *send_bytes = b_send_need; *recv_bytes = b_recv_need; *n_exchanges = (int)bplan.xs.size();
+  }
+  void band_set_staging(void* send, int64_t send_bytes, void* recv, int64_t recv_bytes) override {
+    band_need();
+    if (send_bytes < b_send_need || recv_bytes < b_recv_need) throw ConfigError("wx_band_set_staging: buffers smaller than wx_band_info asks for");
+    if ((b_send_need && !send) || (b_recv_need && !recv)) throw ConfigError("wx_band_set_staging: null staging buffer");
+    b_send = (char*)send; b_recv = (char*)recv;
+  }
+  int band_messages_of(int xid, wx_band_msg* sends, int cap_s, int* n_s, wx_band_msg* recvs, int cap_r, int* n_r) override {
+    band_need();
+    if (xid < 0 || xid >= (int)bplan.xs.size()) throw ConfigError("wx_band_exchange: no such exchange");
+    std::vector<BandMsg> s, r;
+    band_messages(bplan.xs[xid], b_rank, &s, &r);
+    if ((int)s.size() > cap_s || (int)r.size() > cap_r) throw ConfigError("wx_band_exchange: message arrays too small (need nranks - 1)");
+    for (size_t i = 0; i < s.size(); ++i) sends[i] = wx_band_msg{s[i].peer, s[i].offset, s[i].bytes};
+    for (size_t i = 0; i < r.size(); ++i) recvs[i] = wx_band_msg{r[i].peer, r[i].offset, r[i].bytes};
+    *n_s = (int)s.size(); *n_r = (int)r.size();
+    return 0;
+  }
+  void band_need() const { if (!band_on) throw StateError("lat-band mode is not enabled (wx_band_enable)"); }
+
+  // ---- buffer views: the shape of ONE row of buffer `buf` (every row of an exchange has the same shape)
+  struct BRow { char* base; int64_t row_stride, pitch, width; int hpr; };
+  BRow band_row(int buf, const BandExchange& x) {
+    const int64_t e = sizeof(T);
+    const int s = x.stage;
+    auto tok = [&](T* base, int64_t ld_el, int64_t ch_el, int64_t ch_off, int w) {
+      return BRow{reinterpret_cast<char*>(base + ch_off), (int64_t)w * ld_el * e, ld_el * e, ch_el * e, w};
+    };
+    auto chan = [&](const float* base, int rows_loc) {   // [C_in][rows][W] fp32: a "row" is one W-line of every channel
+      const int64_t w4 = (int64_t)cfg.image_width * 4;
+      return BRow{reinterpret_cast<char*>(const_cast<float*>(base)), w4, rows_loc * w4, w4, C_in};
+    };
+    switch (buf) {
+      case BB_X_OWN: return chan(bx_own, b_own_rows());
+      case BB_X_NEED: return chan(bxneed, bplan.x_need_hi[b_rank] - bplan.x_need_lo[b_rank]);
+      case BB_STREAM_S: return s < 3 ? tok(bcat[s], 2 * cfg.dim[s], cfg.dim[s], cfg.dim[s], sw[s]) : tok(bx3, cfg.dim[3], cfg.dim[3], 0, sw[3]);
+      case BB_STREAM_L: return tok(blong[s], cfg.dim[s], cfg.dim[s], 0, sw[s]);
+      case BB_EMB_IN: return tok(bemb_in, cfg.dim[s], cfg.dim[s], 0, sw[s]);
+      case BB_DEC_SRC: return s == 3 ? tok(bx3, cfg.dim[3], cfg.dim[3], 0, sw[3]) : tok(bcat[s], 2 * cfg.dim[s], 2 * cfg.dim[s], 0, sw[s]);
+      case BB_DEC_IN: { const int64_t c = s == 3 ? cfg.dim[3] : 2 * cfg.dim[s]; return tok(bdec_in, c, c, 0, sw[s]); }
+      case BB_SCUT: return tok(bscut, ups[2 - s].cout, ups[2 - s].cout, 0, sw[s]);
+      case BB_TB: return tok(btb, ups[2 - s].cout, ups[2 - s].cout, 0, sw[s]);
+      case BB_CAT0: return tok(bcat[0], 2 * cfg.dim[0], 2 * cfg.dim[0], 0, sw[0]);
+      case BB_DEC: return tok(bdec, ld_dec, ld_dec, 0, Wd);
+      case BB_GN_ACC: return BRow{reinterpret_cast<char*>(gn_acc), x.row_bytes, x.row_bytes, x.row_bytes, 1};
+      case BB_GN_ALL: return BRow{reinterpret_cast<char*>(gn_all), x.row_bytes, x.row_bytes, x.row_bytes, 1};
+    }
+    throw StateError("band: unknown buffer id");
+  }
+  BRow band_staging(char* base, const BRow& like) { return BRow{base, like.width * like.hpr, like.width, like.width, like.hpr}; }
+  // row lists of every exchange, resident on the device (built once in band_enable)
+  struct BandXDev { int2 *pack = nullptr, *unpack = nullptr, *self = nullptr; int* zero = nullptr; int n_pack = 0, n_unpack = 0, n_self = 0, n_zero = 0; };
+  std::vector<BandXDev> bx_dev;
+  void band_upload_maps() {
+    bx_dev.assign(bplan.xs.size(), BandXDev());
+    for (size_t xid = 0; xid < bplan.xs.size(); ++xid) {
+      const BandExchange& x = bplan.xs[xid];
+      std::vector<int2> pk, up, sf;
+      std::vector<int> zr;
+      int row = 0;
+      for (int p = 0; p < b_n; ++p) {
+        if (p == b_rank) continue;
+        for (const BandSeg& sg : x.recv[p])
+          if (sg.peer == b_rank)
+            for (int k = 0; k < sg.nrows; ++k) pk.push_back(make_int2(sg.src_row + k, row++));
+      }
+      row = 0;
+      for (int r = 0; r < b_n; ++r) {
+        if (r == b_rank) continue;
+        for (const BandSeg& sg : x.recv[b_rank])
+          if (sg.peer == r)
+            for (int k = 0; k < sg.nrows; ++k) up.push_back(make_int2(row++, sg.dst_row + k));
+      }
+      for (const BandSeg& sg : x.recv[b_rank])
+        for (int k = 0; k < sg.nrows; ++k) {
+          if (sg.peer == b_rank) sf.push_back(make_int2(sg.src_row + k, sg.dst_row + k));
+          else if (sg.peer < 0) zr.push_back(sg.dst_row + k);
+        }
+      BandXDev& d = bx_dev[xid];
+      auto up2 = [&](const std::vector<int2>& v, int2** dst, int* n) {
+        *n = (int)v.size();
+        if (v.empty()) return;
+        *dst = (int2*)dalloc(v.size() * sizeof(int2));
+        WX_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(int2), hipMemcpyHostToDevice));
+      };
+      up2(pk, &d.pack, &d.n_pack); up2(up, &d.unpack, &d.n_unpack); up2(sf, &d.self, &d.n_self);
+      d.n_zero = (int)zr.size();
+      if (!zr.empty()) {
+        d.zero = (int*)dalloc(zr.size() * sizeof(int));
+        WX_HIP(hipMemcpy(d.zero, zr.data(), zr.size() * sizeof(int), hipMemcpyHostToDevice));
+      }
+    }
+  }
+  void band_rowcopy(const BRow& d, const BRow& s, const int2* map, int n) {
+    if (n <= 0) return;
+    if (d.width != s.width || d.hpr != s.hpr || (d.width & 15)) throw StateError("band: row shape mismatch");
+    const int64_t total = (int64_t)n * d.hpr * (d.width / 16);
+    hipLaunchKernelGGL(band_rowcopy_kernel, dim3((unsigned)std::min<int64_t>(8192, cdiv(total, 256))), dim3(256), 0, cur_stream, d.base,
+                       d.row_stride, d.pitch, s.base, s.row_stride, s.pitch, (int)(d.width / 16), d.hpr, n, map);
+    WX_HIP(hipGetLastError());
+  }
+  void band_pack(int xid) {
+    const BandExchange& x = bplan.xs[xid];
+    const BandXDev& d = bx_dev[xid];
+    if (d.n_pack <= 0) return;
+    const BRow s = band_row(x.src_buf, x);
+    if (s.width * s.hpr != x.row_bytes) throw StateError("band: row size mismatch in " + x.name);
+    band_rowcopy(band_staging(b_send, s), s, d.pack, d.n_pack);
+  }
+  void band_unpack(int xid) {
+    const BandExchange& x = bplan.xs[xid];
+    const BandXDev& d = bx_dev[xid];
+    const BRow dv = band_row(x.dst_buf, x);
+    if (dv.width * dv.hpr != x.row_bytes) throw StateError("band: row size mismatch in " + x.name);
+    band_rowcopy(dv, band_staging(b_recv, dv), d.unpack, d.n_unpack);
+    if (d.n_self > 0) band_rowcopy(dv, band_row(x.src_buf, x), d.self, d.n_self);
+    if (d.n_zero > 0) {   // beyond the pole: the convolution's zero padding
+      const int64_t total = (int64_t)d.n_zero * dv.hpr * (dv.width / 16);
+      hipLaunchKernelGGL(band_rowzero_kernel, dim3((unsigned)std::min<int64_t>(8192, cdiv(total, 256))), dim3(256), 0, cur_stream, dv.base,
+                         dv.row_stride, dv.pitch, (int)(dv.width / 16), dv.hpr, d.n_zero, d.zero);
+      WX_HIP(hipGetLastError());
+    }
+  }
+
+  // ---- the program
+  int b_next_x = 0;
+  void band_op(std::function<void()> f, const char* exchange = nullptr, const std::string& suffix = "") {
+    int xid = -1;
+    if (exchange) {
+      const std::string name = exchange + suffix;
+      if (b_next_x >= (int)bplan.xs.size() || bplan.xs[b_next_x].name != name)
+        throw StateError("band: program / plan out of step at " + name);
+      xid = b_next_x++;
+    }
+    b_ops.push_back(std::move(f));
+    b_xid.push_back(xid);
+  }
+  void band_attach(const std::string& name) {   // the exchange follows the op pushed last
+    if (b_xid.empty() || b_xid.back() >= 0) throw StateError("band: two exchanges after one op at " + name);
+    b_xid.back() = band_take(name);
+  }
+  void band_layout(int s, bool is_long) {
+    b_long[s] = is_long;
+    sh[s] = is_long ? bplan.g.rows_long(s, b_rank) : bplan.g.rows_short(s, b_rank);
+    attn_kind_override = is_long ? 2 : -1;
+    stat_tiles_ready = 0;   // LayerNorm partials belong to the rows that just left
+  }
+  // GroupNorm: local (sum, sum sq) -> gn_acc
+  void band_gn_local(const T* x, int c, int64_t m, bool have_partials) {
+    if (m <= 0) { WX_HIP(hipMemsetAsync(gn_acc, 0, 2 * c * sizeof(double), cur_stream)); return; }
+    gn_local_stats(x, c, m, have_partials);
+  }
+  void band_gn_finish(const T* x, int c, int64_t m_local, int64_t m_global, int64_t g_off, int64_t b_off, const T* res, int64_t res_ld,
+                      T* out, int64_t out_ld) {
+    hipLaunchKernelGGL(band_gn_sum_kernel, dim3(cdiv(2 * c, 128)), dim3(128), 0, cur_stream, gn_all, b_n, 2 * c, gn_acc);
+    WX_HIP(hipGetLastError());
+    if (m_local <= 0) return;
+    gn_finalize_apply(x, c, m_local, m_global, g_off, b_off, res, res_ld, out, out_ld);
+  }
+  void band_build_program() {
+    const BandGeom& g = bplan.g;
+    const int r = b_rank;
+    b_ops.clear(); b_xid.clear(); b_next_x = 0;
+    band_op([] {}, "x_rows");
+    // stage 0: pack the band's padded patch, CrossEmbed
+    band_op([this, r] {
+      const BandGeom& g = bplan.g;
+      const int st0 = cfg.embed_strides[0], a0 = g.ps[0][r], rows0 = g.rows_short(0, r);
+      for (int s = 0; s < 4; ++s) { b_long[s] = false; sh[s] = g.rows_short(s, r); }
+      attn_kind_override = -1;
+      cur_stage = 0;
+      stat_tiles_ready = 0;
+      const int Hb = st0 * rows0 + 2 * halo;
+      pack_input(bxneed, bxin, bxin_planar, Hb, bplan.pad_lo[r], bplan.pad_hi[r] - bplan.pad_lo[r], bplan.pad_lo[r] - (st0 * a0 - halo),
+                 bplan.x_need_lo[r], bplan.x_need_hi[r] - bplan.x_need_lo[r]);
+      cross_embed(0, bxin, bxin_planar, Hb, 0, 0);
+    });
+    for (int s = 0; s < 4; ++s) {
+      if (s > 0) {
+        band_attach("embed_in.s" + std::to_string(s));
+        band_op([this, s, r] {
+          const BandGeom& g = bplan.g;
+          cur_stage = s;
+          band_layout(s, false);
+          const int rows = g.rows_short(s, r);
+          cross_embed(s, bemb_in, nullptr, cfg.embed_strides[s] * rows + bplan.m.emb_lo[s] + bplan.m.emb_hi[s], -bplan.m.emb_lo[s], cfg.dim[s - 1]);
+        });
+      }
+      const bool a2a = cfg.global_window_size[s] > 1;
+      for (int d = 0; d < cfg.depth[s]; ++d) {
+        const std::string tag = ".s" + std::to_string(s) + "." + std::to_string(d);
+        if (a2a) {
+          band_op([this, s, d] { cur_stage = s; block_half(s, d, false); }, "to_long", tag);
+          band_op([this, s, d] { band_layout(s, true); block_half(s, d, true); }, "to_short", tag);
+          band_op([this, s] { band_layout(s, false); });
+        } else {
+          band_op([this, s, d] { cur_stage = s; block_half(s, d, false); block_half(s, d, true); });
+        }
+      }
+    }
+    // decoder
+    for (int i = 0; i < 3; ++i) {
+      const int si = 3 - i, so = 2 - i;
+      const std::string lv = ".l" + std::to_string(i);
+      band_attach("dec_in" + lv);
+      band_op([this, i, si, so, r] {
+        const BandGeom& g = bplan.g;
+        cur_stage = 4 + i;
+        stat_tiles_ready = 0;
+        const UpL& u = ups[i];
+        const int a = g.ps[so][r], b = g.ps[so][r + 1];
+        if (b > a) {
+          const int j0 = a / 2, j1 = (b + 1) / 2;
+          T* out = bscut + (int64_t)(2 * j0 - (a - 1)) * sw[so] * u.cout;   // output rows 2 j0 .. 2 j1 - 1; owned row `a` is buffer row 1
+          gemm("gemm_convT2", u.convt, bdec_in, j1 - j0, sw[si], i == 0 ? cfg.dim[3] : 2 * cfg.dim[si], 1, 0, 0, j1 - j0, sw[si], out, u.cout,
+               nullptr, 0, nullptr, 0, 1, u.cout);
+        }
+      }, "halo_scut", lv);
+      band_op([this, i, so, r] {
+        const BandGeom& g = bplan.g;
+        const UpL& u = ups[i];
+        const int rows = g.rows_short(so, r);
+        bool gp = false;
+        if (rows > 0)
+          gp = gemm("gemm_conv3", u.c1, bscut, rows + 2, sw[so], u.cout, 1, 0, 1, rows, sw[so], bta, u.cout, nullptr, 0, nullptr, 0, 0, 0, 0, 0,
+                    false, true);
+        band_gn_local(bta, u.cout, (int64_t)rows * sw[so], gp);
+      }, "gn", lv + ".0");
+      band_op([this, i, so, r] {
+        const BandGeom& g = bplan.g;
+        const UpL& u = ups[i];
+        const int rows = g.rows_short(so, r);
+        band_gn_finish(bta, u.cout, (int64_t)rows * sw[so], (int64_t)gsh[so] * sw[so], u.g1, u.b1, nullptr, 0,
+                       btb + (int64_t)sw[so] * u.cout, u.cout);
+      }, "halo_tb", lv);
+      band_op([this, i, so, r] {
+        const BandGeom& g = bplan.g;
+        const UpL& u = ups[i];
+        const int rows = g.rows_short(so, r);
+        bool gp = false;
+        if (rows > 0)
+          gp = gemm("gemm_conv3", u.c2, btb, rows + 2, sw[so], u.cout, 1, 0, 1, rows, sw[so], bta, u.cout, nullptr, 0, nullptr, 0, 0, 0, 0, 0,
+                    false, true);
+        band_gn_local(bta, u.cout, (int64_t)rows * sw[so], gp);
+      }, "gn", lv + ".1");
+      band_op([this, i, so, r] {
+        const BandGeom& g = bplan.g;
+        const UpL& u = ups[i];
+        const int rows = g.rows_short(so, r);
+        const int64_t row_el = (int64_t)sw[so] * 2 * cfg.dim[so];
+        band_gn_finish(bta, u.cout, (int64_t)rows * sw[so], (int64_t)gsh[so] * sw[so], u.g2, u.b2, bscut + (int64_t)sw[so] * u.cout, u.cout,
+                       bcat[so] + row_el, 2 * cfg.dim[so]);
+      });
+    }
+    band_attach("halo_cat0");
+    band_op([this, r] {
+      const BandGeom& g = bplan.g;
+      cur_stage = 7;
+      const int rows = g.rows_short(0, r);
+      for (int q = 0; q < 4; ++q) {
+        const int py = q >> 1, px = q & 1;
+        gemm("gemm_convT4", up4[q], bcat[0], rows + 2, sw[0], 2 * cfg.dim[0], 1, -py, 1 - px, rows, sw[0], bdec + (int64_t)Wd * ld_dec, ld_dec,
+             nullptr, 0, nullptr, 0, 2, 0, py, px);
+      }
+    }, "halo_dec");
+    band_op([this, r] {
+      const BandGeom& g = bplan.g;
+      band_tail(2 * g.ps[0][r] - 1);
+      for (int s = 0; s < 4; ++s) sh[s] = gsh[s];   // leave the whole-map geometry behind
+      attn_kind_override = -1;
+    });
+    if (b_next_x != (int)bplan.xs.size()) throw StateError("band: program does not consume every exchange of the plan");
+    (void)g;
+  }
+  int band_take(const std::string& name) {
+    if (b_next_x >= (int)bplan.xs.size() || bplan.xs[b_next_x].name != name) throw StateError("band: program / plan out of step at " + name);
+    return b_next_x++;
+  }
+  void band_tail(int dec_row0) {
+    const int own0 = bplan.g.po[b_rank], own = b_own_rows();
+    if (own <= 0) return;
+    TailParams p;
+    p.dec = bdec; p.ld = ld_dec; p.Hd = Hd; p.Wd = Wd;
+    p.off_y = cfg.pad_activate ? cfg.pad_lat[0] : 0; p.off_x = cfg.pad_activate ? cfg.pad_lon[0] : 0;
+    p.Hu = Hu; p.Wu = Wu; p.H = Ho; p.W = Wo; p.C = C_out; p.interp = cfg.interp;
+    p.y = by; p.y_phys = by_phys; p.x_next = bx_next; p.n_prog = n_prog < 0 ? 0 : n_prog;
+    p.mean = have_denorm ? d_mean : nullptr; p.stdv = have_denorm ? d_std : nullptr;
+    p.thr_lo = have_tracer ? d_lo : nullptr; p.thr_hi = have_tracer ? d_hi : nullptr;
+    p.tracer_denorm = tracer_denorm;
+    p.oy0 = own0; p.dec_row0 = dec_row0; p.Hloc = own;
+    const size_t lds = (size_t)C_out * 65 * sizeof(float);
+    WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const double plane = (double)own * Wo * C_out;
+    timed("tail", 0.0, plane * (2.0 * sizeof(T) + 4.0 * ((by ? 1 : 0) + (by_phys ? 1 : 0)) + (bx_next ? 4.0 : 0.0)), [&] {
+      hipLaunchKernelGGL(tail_kernel<T>, dim3(cdiv(Wo, 64), own), dim3(256), lds, cur_stream, p);
+      WX_HIP(hipGetLastError());
+    });
+    if (bx_next) {
+      const int64_t plane_b = (int64_t)own * cfg.image_width;
+      if (n_static > 0)
+        WX_HIP(hipMemcpyAsync(bx_next + n_prog * plane_b, bx_own + n_prog * plane_b, n_static * plane_b * sizeof(float), hipMemcpyDeviceToDevice, cur_stream));
+      if (n_dyn > 0)
+        WX_HIP(hipMemcpyAsync(bx_next + (n_prog + n_static) * plane_b, bfrc_own, n_dyn * plane_b * sizeof(float), hipMemcpyDeviceToDevice, cur_stream));
+    }
+  }
+  int band_run() {
+    while (b_pc < b_ops.size()) {
+      b_ops[b_pc]();
+      const int xid = b_xid[b_pc];
+      ++b_pc;
+      if (xid >= 0) {
+        timed("band_pack", 0.0, (double)band_send_bytes(bplan.xs[xid], b_rank) * 2.0, [&] { band_pack(xid); });
+        b_pending = xid;
+        return xid;
+      }
+    }
+    b_pending = -1;
+    if (prof_on) drain();
+    return -1;
+  }
+  int band_begin(const float* x_own, const float* frc_own, float* y, float* y_phys, float* x_next, hipStream_t s) override {
+    band_need();
+    check_ready();
+    if (b_pending >= 0) throw StateError("wx_band_begin: the previous step is still waiting for an exchange");
+    if ((b_send_need && !b_send) || (b_recv_need && !b_recv)) throw StateError("wx_band_begin: no staging buffers (wx_band_set_staging)");
+    if (!x_own && b_own_rows() > 0) throw ConfigError("wx_band_begin: null input band");   // a polar rank may own pad rows only
+    if (x_next) {
+      if (n_prog < 0) throw StateError("wx_band_begin with x_next needs wx_set_layout first");
+      if (x_next == x_own) throw ConfigError("x_next may not alias x");
+      if (n_dyn > 0 && !frc_own) throw ConfigError("forcing pointer is NULL but the layout has dynamic forcing channels");
+    }
+    if (y_phys && !have_denorm) throw StateError("wx_band_begin with y_phys needs wx_set_denorm first");
+    cur_stream = s;
+    bx_own = x_own; bfrc_own = frc_own; by = y; by_phys = y_phys; bx_next = x_next;
+    b_pc = 0;
+    return band_run();
+  }
+  int band_resume() override {
+    band_need();
+    if (b_pending < 0) throw StateError("wx_band_resume: no exchange is pending");
+    WX_HIP(hipSetDevice(device));
+    {
+      const int xid = b_pending;
+      timed("band_unpack", 0.0, (double)band_recv_bytes(bplan.xs[xid], b_rank) * 2.0, [&] { band_unpack(xid); });
+    }
+    return band_run();
+  }
   void check_ready() {
     if (!finalized) throw StateError("weights not finalized (call wx_finalize_weights after loading every tensor)");
     WX_HIP(hipSetDevice(device));
   }
   void forward(const float* x, float* y, int batch, hipStream_t s) override {
     check_ready();
+    if (band_on) throw StateError("this engine is in lat-band mode: drive it with wx_band_begin / wx_band_resume");
     if (batch < 1) throw ConfigError("batch must be >= 1");
     cur_stream = s;
     const int64_t in_item = (int64_t)C_in * cfg.image_height * cfg.image_width;
@@ -1217,6 +1742,7 @@ class Engine : public EngineBase {
   }
   void step(const float* x, const float* frc, float* y, float* y_phys, float* x_next, hipStream_t s) override {
     check_ready();
+    if (band_on) throw StateError("this engine is in lat-band mode: drive it with wx_band_begin / wx_band_resume");
     if (cfg.frames != 1 || cfg.output_frames != 1) throw ConfigError("wx_step needs frames == output_frames == 1");
     if (x_next) {
       if (n_prog < 0) throw StateError("wx_step with x_next needs wx_set_layout first");
@@ -1306,7 +1832,89 @@ int wx_set_comm(wx_handle h, void* nccl_comm, int rank, int nranks) {
   return guarded([&] {
     WX_NEED(h);
     (void)nccl_comm; (void)rank;
-    if (nranks != 1) throw wx::ConfigError("lat-band sharding is not built yet: run one replica per GPU (SURVEY.md §8(e) 'replicas')");
+    if (nranks != 1) throw wx::ConfigError("wx_set_comm: lat-band sharding is driven through wx_band_enable / wx_band_begin / wx_band_resume");
+  });
+}
+int wx_band_enable(wx_handle h, int rank, int nranks) { return guarded([&] { WX_NEED(h); h->impl->band_enable(rank, nranks); }); }
+int wx_band_info(wx_handle h, int* own_row0, int* own_rows, int64_t* send_bytes, int64_t* recv_bytes, int* n_exchanges) {
+  return guarded([&] {
+    WX_NEED(h);
+    if (!own_row0 || !own_rows || !send_bytes || !recv_bytes || !n_exchanges) throw wx::ConfigError("wx_band_info: null argument");
+    h->impl->band_info(own_row0, own_rows, send_bytes, recv_bytes, n_exchanges);
+  });
+}
+int wx_band_set_staging(wx_handle h, void* send_dev, int64_t send_bytes, void* recv_dev, int64_t recv_bytes) {
+  return guarded([&] { WX_NEED(h); h->impl->band_set_staging(send_dev, send_bytes, recv_dev, recv_bytes); });
+}
+int wx_band_exchange(wx_handle h, int xid, wx_band_msg* sends, int cap_sends, int* n_sends, wx_band_msg* recvs, int cap_recvs, int* n_recvs) {
+  return guarded([&] {
+    WX_NEED(h);
+    if (!sends || !recvs || !n_sends || !n_recvs) throw wx::ConfigError("wx_band_exchange: null argument");
+    h->impl->band_messages_of(xid, sends, cap_sends, n_sends, recvs, cap_recvs, n_recvs);
+  });
+}
+int wx_band_begin(wx_handle h, const float* x_band, const float* frc_band, float* y_band, float* y_phys_band, float* x_next_band, void* stream,
+                  int* next_xid) {
+  return guarded([&] {
+    WX_NEED(h);
+    if (!next_xid) throw wx::ConfigError("wx_band_begin: null next_xid");
+    *next_xid = h->impl->band_begin(x_band, frc_band, y_band, y_phys_band, x_next_band, (hipStream_t)stream);
+  });
+}
+int wx_band_resume(wx_handle h, int* next_xid) {
+  return guarded([&] {
+    WX_NEED(h);
+    if (!next_xid) throw wx::ConfigError("wx_band_resume: null next_xid");
+    *next_xid = h->impl->band_resume();
+  });
+}
+// host-only plan: a never-finalized engine object supplies the derived geometry (no HIP call is made)
+struct wx_band_plan_s { wx::BandPlan plan; };
+int wx_band_plan_create(const wx_config* cfg, int nranks, wx_band_plan* out) {
+  return guarded([&] {
+    if (!cfg || !out) throw wx::ConfigError("wx_band_plan_create: null argument");
+    if (nranks < 1) throw wx::ConfigError("wx_band_plan_create: nranks must be >= 1");
+    std::unique_ptr<wx_band_plan_s> p(new wx_band_plan_s);
+    if (cfg->precision == WX_PREC_FP32) {
+      wx::Engine<float> e(*cfg, -1);
+      wx::Engine<float>::band_check_supported(e);
+      p->plan.build(wx::Engine<float>::band_model(e, nranks));
+    } else {
+      wx::Engine<wx::bf16_t> e(*cfg, -1);
+      wx::Engine<wx::bf16_t>::band_check_supported(e);
+      p->plan.build(wx::Engine<wx::bf16_t>::band_model(e, nranks));
+    }
+    *out = p.release();
+  });
+}
+int wx_band_plan_destroy(wx_band_plan p) { return guarded([&] { delete p; }); }
+int wx_band_plan_num_exchanges(wx_band_plan p, int* n) {
+  return guarded([&] { if (!p || !n) throw wx::ConfigError("null argument"); *n = (int)p->plan.xs.size(); });
+}
+int wx_band_plan_exchange_name(wx_band_plan p, int xid, const char** name) {
+  return guarded([&] {
+    if (!p || !name || xid < 0 || xid >= (int)p->plan.xs.size()) throw wx::ConfigError("wx_band_plan_exchange_name: bad argument");
+    *name = p->plan.xs[xid].name.c_str();
+  });
+}
+int wx_band_plan_messages(wx_band_plan p, int xid, int rank, wx_band_msg* sends, int cap_sends, int* n_sends, wx_band_msg* recvs,
+                          int cap_recvs, int* n_recvs) {
+  return guarded([&] {
+    if (!p || !sends || !recvs || !n_sends || !n_recvs || xid < 0 || xid >= (int)p->plan.xs.size() || rank < 0 || rank >= p->plan.m.n)
+      throw wx::ConfigError("wx_band_plan_messages: bad argument");
+    std::vector<wx::BandMsg> s, r;
+    wx::band_messages(p->plan.xs[xid], rank, &s, &r);
+    if ((int)s.size() > cap_sends || (int)r.size() > cap_recvs) throw wx::ConfigError("wx_band_plan_messages: arrays too small");
+    for (size_t i = 0; i < s.size(); ++i) sends[i] = wx_band_msg{s[i].peer, s[i].offset, s[i].bytes};
+    for (size_t i = 0; i < r.size(); ++i) recvs[i] = wx_band_msg{r[i].peer, r[i].offset, r[i].bytes};
+    *n_sends = (int)s.size(); *n_recvs = (int)r.size();
+  });
+}
+int wx_band_plan_partition(wx_band_plan p, int which, int32_t* starts) {
+  return guarded([&] {
+    if (!p || !starts || which < 0 || which > 8) throw wx::ConfigError("wx_band_plan_partition: bad argument");
+    const std::vector<int>& v = which < 4 ? p->plan.g.ps[which] : which < 8 ? p->plan.g.pl[which - 4] : p->plan.g.po;
+    for (size_t i = 0; i < v.size(); ++i) starts[i] = v[i];
   });
 }
 int wx_set_debug(wx_handle h, int enable) { return guarded([&] { WX_NEED(h); h->impl->set_debug(enable); }); }

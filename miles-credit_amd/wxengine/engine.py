@@ -38,6 +38,10 @@ class wx_config(C.Structure):
     ]
 
 
+class wx_band_msg(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("offset", C.c_int64), ("bytes", C.c_int64)]
+
+
 class wx_kernel_stat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -62,6 +66,20 @@ _PROTOTYPES = {
     "wx_forward": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     "wx_step": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "wx_set_comm": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int], C.c_int),
+    "wx_band_enable": ([C.c_void_p, C.c_int, C.c_int], C.c_int),
+    "wx_band_info": ([C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
+    "wx_band_set_staging": ([C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64], C.c_int),
+    "wx_band_exchange": ([C.c_void_p, C.c_int, C.POINTER(wx_band_msg), C.c_int, C.POINTER(C.c_int), C.POINTER(wx_band_msg), C.c_int,
+                          C.POINTER(C.c_int)], C.c_int),
+    "wx_band_begin": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)], C.c_int),
+    "wx_band_resume": ([C.c_void_p, C.POINTER(C.c_int)], C.c_int),
+    "wx_band_plan_create": ([C.POINTER(wx_config), C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    "wx_band_plan_destroy": ([C.c_void_p], C.c_int),
+    "wx_band_plan_num_exchanges": ([C.c_void_p, C.POINTER(C.c_int)], C.c_int),
+    "wx_band_plan_exchange_name": ([C.c_void_p, C.c_int, C.POINTER(C.c_char_p)], C.c_int),
+    "wx_band_plan_messages": ([C.c_void_p, C.c_int, C.c_int, C.POINTER(wx_band_msg), C.c_int, C.POINTER(C.c_int), C.POINTER(wx_band_msg),
+                               C.c_int, C.POINTER(C.c_int)], C.c_int),
+    "wx_band_plan_partition": ([C.c_void_p, C.c_int, C.POINTER(C.c_int32)], C.c_int),
     "wx_set_debug": ([C.c_void_p, C.c_int], C.c_int),
     "wx_debug_read": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)], C.c_int),
     "wx_profile": ([C.c_void_p, C.c_int], C.c_int),
