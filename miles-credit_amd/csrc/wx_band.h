@@ -234,6 +234,8 @@ struct BandPlan {
     m = model;
     g.init(m.n, m.sh, m.wl, m.wg);
     const int n = m.n;
+    for (int r = 0; r < n; ++r)
+      if (g.rows_short(0, r) <= 0) throw std::runtime_error("band: more ranks than window rows at stage 0");
     // ---- output / input row ownership follows the decoder rows of stage 0: out row oy belongs to whoever owns dec row r0
     g.out_h = m.Ho;
     g.po.assign(n + 1, 0);

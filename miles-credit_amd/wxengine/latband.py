@@ -175,6 +175,35 @@ class VirtualBands:
                 full(xn, cfg.base_input_channels) if want_next else None)
 
 
+def p2p_exchange(dist, group, send_buf, recv_buf, sends, recvs, host_staged: bool) -> int:
+    """Move one exchange's messages: slices [offset, offset+bytes) of `send_buf` to their peers, the peers' slices into
+    `recv_buf` (halo_exchange.py:56-65 uses the same batch_isend_irecv).  With host_staged (gloo) device slices travel
+    through host memory.  Returns the bytes sent."""
+    import torch
+    if not sends and not recvs:
+        return 0
+    ops, host_recv, sent = [], [], 0
+    on_gpu = send_buf.is_cuda
+    if host_staged and on_gpu:
+        torch.cuda.current_stream().synchronize()
+    for peer, off, nbytes in sends:
+        buf = send_buf[off:off + nbytes]
+        ops.append(dist.P2POp(dist.isend, buf.cpu() if (host_staged and on_gpu) else buf, peer, group))
+        sent += nbytes
+    for peer, off, nbytes in recvs:
+        buf = recv_buf[off:off + nbytes]
+        if host_staged and on_gpu:
+            h = torch.empty(nbytes, dtype=torch.uint8)
+            host_recv.append((buf, h))
+            buf = h
+        ops.append(dist.P2POp(dist.irecv, buf, peer, group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    for buf, h in host_recv:
+        buf.copy_(h)
+    return sent
+
+
 class DistBand:
     """One rank of a sharded forecast in a torch.distributed world (one process per GPU).  backend "nccl" (= RCCL)
     moves the staging slices GPU to GPU over xGMI; with "gloo" they are staged through host memory."""
@@ -193,29 +222,8 @@ class DistBand:
         return self.band.row0, self.band.rows
 
     def _exchange(self, xid: int):
-        import torch
-        dist = self.dist
         sends, recvs = self.band.messages(xid)
-        if not sends and not recvs:
-            return
-        ops, host_recv = [], []
-        if self.host_staged:
-            torch.cuda.current_stream().synchronize()
-        for peer, off, nbytes in sends:
-            buf = self.band.send[off:off + nbytes]
-            ops.append(dist.P2POp(dist.isend, buf.cpu() if self.host_staged else buf, peer, self.group))
-            self.exchanged_bytes += nbytes
-        for peer, off, nbytes in recvs:
-            buf = self.band.recv[off:off + nbytes]
-            if self.host_staged:
-                h = torch.empty(nbytes, dtype=torch.uint8)
-                host_recv.append((buf, h))
-                buf = h
-            ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        for buf, h in host_recv:
-            buf.copy_(h)
+        self.exchanged_bytes += p2p_exchange(self.dist, self.group, self.band.send, self.band.recv, sends, recvs, self.host_staged)
 
     def step(self, x_band, frc_band=None, y=None, y_phys=None, x_next=None):
         """Bands in, bands out ([C, rows, W] float32 on this rank's GPU).  Same semantics as WXEngine.step."""
