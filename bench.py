@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--latband", action="store_true",
+                    help="opt-in: ONE forecast sharded over the N ranks by latitude (SURVEY 8(e) mode 2, strong scaling) instead "
+                         "of N independent forecasts; exchanges go through torch.distributed P2P (RCCL)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -55,12 +58,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    # WX_BENCH_BACKEND=gloo: functional check of the multi-process paths on a box with fewer GPUs than ranks (ranks then
+    # share devices and timings mean nothing); the real runs use RCCL ("nccl"), one rank per GPU
+    backend = os.environ.get("WX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
 
     from wxengine.config import named_config
@@ -83,6 +94,8 @@ def main():
     eng.set_tracer_fixer(q_inds, [1e-8] * len(q_inds), None, denorm=True)
 
     dev = torch.device("cuda", local_rank)
+    if args.latband:
+        return bench_latband(args, cfg, eng, dist, rank, world, dev, n_dyn)
     # each rank = its own init time (seed) -> independent forecasts, as rollout_to_netcdf.py:259
     x_a = torch.from_numpy(synth_input(cfg, seed=1000 + rank)).to(dev)
     x_b = torch.empty_like(x_a)
@@ -109,7 +122,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     finite = bool(torch.isfinite(y_phys).all().item())
@@ -176,6 +189,67 @@ def main():
                        "parallelism": f"replicas over init times x{world} (no data-path collective)",
                        "params": cfg.num_params(), "finite_outputs": finite},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+def bench_latband(args, cfg, eng, dist, rank, world, dev, n_dyn):
+    """One forecast over `world` ranks: every rank keeps its latitude band of x / forcing / y resident; no gather in the loop."""
+    from wxengine.latband import DistBand
+    from wxengine.synth import synth_forcing, synth_input
+    db = DistBand(eng)
+    r0, rows = db.rows
+    band = lambda t: t[0, :, 0, r0:r0 + rows].contiguous().to(dev)  # noqa: E731
+    x_a = band(torch.from_numpy(synth_input(cfg, seed=1000)))
+    x_b = torch.empty_like(x_a)
+    n_frc = 8
+    frcs = [band(torch.from_numpy(synth_forcing(cfg, n_dyn, t, seed=1000))) for t in range(n_frc)]
+    y = torch.empty((cfg.base_output_channels, rows, cfg.image_width), dtype=torch.float32, device=dev)
+    y_phys = torch.empty_like(y)
+
+    def run(nsteps, x_cur, x_nxt, t0):
+        for t in range(nsteps):
+            db.step(x_cur, frcs[(t0 + t) % n_frc], y=y, y_phys=y_phys, x_next=x_nxt)
+            x_cur, x_nxt = x_nxt, x_cur
+        return x_cur, x_nxt
+
+    x_cur, x_nxt = run(args.warmup, x_a, x_b, 0)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    db.exchanged_bytes = 0
+    t0 = time.perf_counter()
+    x_cur, x_nxt = run(args.steps, x_cur, x_nxt, args.warmup)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stats = torch.tensor([elapsed, float(db.exchanged_bytes) / args.steps, float(torch.isfinite(y_phys).all().item())],
+                         dtype=torch.float64, device=dev if (not dist or dist.get_backend() == "nccl") else "cpu")
+    if dist:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        mn = stats.clone()
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        elapsed, sent, finite = float(mx[0]), float(mx[1]), bool(mn[2] > 0)
+    else:
+        elapsed, sent, finite = float(stats[0]), float(stats[1]), bool(stats[2] > 0)
+    if rank == 0:
+        out = {
+            "metric": "forecast-steps/sec (rollout) WXFormer-6h 0.25deg 721x1440",
+            "value": round(args.steps / elapsed, 4), "unit": "forecast-steps/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic (N(0,1) ERA5-shaped inputs/forcing, name-keyed synthetic weights; no dataset/checkpoint)",
+            "config": {"workload": WORKLOADS[args.config], "batch": 1,
+                       "parallelism": f"lat-band sharding of ONE forecast x{world} (halo / long-attention / GroupNorm exchanges over "
+                                      f"torch.distributed P2P)",
+                       "exchanges_per_step": db.band.num_exchanges, "max_sent_MB_per_rank_per_step": round(sent / 1e6, 2),
+                       "params": cfg.num_params(), "finite_outputs": finite},
+            "roofline": None, "cpu_baseline": None,
         }
         print(json.dumps(out), flush=True)
     if dist:

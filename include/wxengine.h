@@ -201,6 +201,15 @@ int wx_band_exchange(wx_handle h, int xid, wx_band_msg* sends, int cap_sends, in
 int wx_band_begin(wx_handle h, const float* x_band, const float* frc_band, float* y_band, float* y_phys_band, float* x_next_band,
                   void* stream, int* next_xid);
 int wx_band_resume(wx_handle h, int* next_xid);   /* *next_xid = -1 when the step is complete */
+/* RCCL transport inside the engine (one process per GPU; xGMI peer-to-peer): rank 0 draws an id, every rank receives it
+ * through any side channel (the Python shim broadcasts it with torch.distributed), wx_band_rccl_init creates the
+ * communicator (ncclCommInitRank), and wx_band_step_rccl runs a whole step with a grouped ncclSend/ncclRecv per exchange
+ * on the compute stream -- no host code between segments.  librccl is bound with dlopen on first use (no link dependency);
+ * staging buffers are allocated by the engine when wx_band_set_staging was not called. */
+int wx_band_rccl_unique_id(uint8_t id[128]);
+int wx_band_rccl_init(wx_handle h, const uint8_t id[128]);
+int wx_band_step_rccl(wx_handle h, const float* x_band, const float* frc_band, float* y_band, float* y_phys_band, float* x_next_band,
+                      void* stream);
 /* Host-only view of the same plan (no GPU needed: the CPU tests check it for every rank of a world):
  * rows owned per stage and the (peer, offset, bytes) messages of every exchange. */
 typedef struct wx_band_plan_s* wx_band_plan;

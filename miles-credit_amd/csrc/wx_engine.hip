@@ -21,6 +21,8 @@
 #include "wx_elem.h"
 #include "wx_embed.h"
 #include "wx_band.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is bound with dlopen when a communicator is requested
 #include "wx_gemm.h"
 #include "wx_post.h"
 #include "wx_pre.h"
@@ -55,6 +57,51 @@ struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmb
 struct StageL { std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks; };
 struct UpL { ConvW convt, convps, sharp, upc, c1, c2; int64_t g1 = -1, b1 = -1, g2 = -1, b2 = -1; int cin = 0, cout = 0; };
 
+
+// RCCL bound at run time (no link dependency: single-GPU users never load it).  In a torch process the already-loaded
+// librccl is found first, so the engine and torch.distributed share one RCCL.
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  static RcclApi& get() {
+    static RcclApi api;
+    if (api.lib) return api;
+    for (const char* name : {"librccl.so", "librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+      if (api.lib) break;
+    }
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+      if (api.lib) break;
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!api.lib) throw StateError(std::string("RCCL not found (librccl.so): ") + dlerror());
+    auto sym = [&](const char* n) {
+      void* p = dlsym(api.lib, n);
+      if (!p) throw StateError(std::string("RCCL symbol missing: ") + n);
+      return p;
+    };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    return api;
+  }
+  void check(ncclResult_t r, const char* what) const {
+    if (r != ncclSuccess) throw StateError(std::string("RCCL ") + what + ": " + GetErrorString(r));
+  }
+};
+
 struct KernelStatAcc { int64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
 
 class EngineBase {
@@ -81,6 +128,8 @@ class EngineBase {
   virtual int band_messages_of(int xid, wx_band_msg* sends, int cap_s, int* n_s, wx_band_msg* recvs, int cap_r, int* n_r) = 0;
   virtual int band_begin(const float* x_own, const float* frc_own, float* y, float* y_phys, float* x_next, hipStream_t s) = 0;
   virtual int band_resume() = 0;
+  virtual void band_rccl_init(const ncclUniqueId& id) = 0;
+  virtual void band_step_rccl(const float* x_own, const float* frc_own, float* y, float* y_phys, float* x_next, hipStream_t s) = 0;
   int device = 0;
 };
 
@@ -95,6 +144,7 @@ class Engine : public EngineBase {
   ~Engine() override {
     if (device < 0) return;   // host-only instance (wx_band_plan_create): nothing was allocated
     (void)hipSetDevice(device);
+    if (b_comm) (void)RcclApi::get().CommDestroy(b_comm);
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
@@ -1713,6 +1763,35 @@ class Engine : public EngineBase {
     b_pc = 0;
     return band_run();
   }
+  // ---- RCCL transport inside the engine: no host code between the segments of a step besides the launches themselves
+  ncclComm_t b_comm = nullptr;
+  std::vector<std::pair<std::vector<BandMsg>, std::vector<BandMsg>>> b_msgs;
+  void band_rccl_init(const ncclUniqueId& id) override {
+    band_need();
+    if (b_comm) throw StateError("wx_band_rccl_init: communicator already created");
+    WX_HIP(hipSetDevice(device));
+    RcclApi& api = RcclApi::get();
+    api.check(api.CommInitRank(&b_comm, b_n, id, b_rank), "ncclCommInitRank");
+    if (!b_send && b_send_need) b_send = (char*)dalloc((size_t)b_send_need);
+    if (!b_recv && b_recv_need) b_recv = (char*)dalloc((size_t)b_recv_need);
+    b_msgs.resize(bplan.xs.size());
+    for (size_t x = 0; x < bplan.xs.size(); ++x) band_messages(bplan.xs[x], b_rank, &b_msgs[x].first, &b_msgs[x].second);
+  }
+  void band_step_rccl(const float* x_own, const float* frc_own, float* y, float* y_phys, float* x_next, hipStream_t s) override {
+    if (!b_comm) throw StateError("wx_band_step_rccl: no communicator (wx_band_rccl_init)");
+    RcclApi& api = RcclApi::get();
+    int xid = band_begin(x_own, frc_own, y, y_phys, x_next, s);
+    while (xid >= 0) {
+      const auto& m = b_msgs[xid];
+      if (!m.first.empty() || !m.second.empty()) {   // every pair at once: the grouped send/recv idiom (all-to-all safe)
+        api.check(api.GroupStart(), "ncclGroupStart");
+        for (const BandMsg& q : m.first) api.check(api.Send(b_send + q.offset, (size_t)q.bytes, ncclInt8, q.peer, b_comm, cur_stream), "ncclSend");
+        for (const BandMsg& q : m.second) api.check(api.Recv(b_recv + q.offset, (size_t)q.bytes, ncclInt8, q.peer, b_comm, cur_stream), "ncclRecv");
+        api.check(api.GroupEnd(), "ncclGroupEnd");
+      }
+      xid = band_resume();
+    }
+  }
   int band_resume() override {
     band_need();
     if (b_pending < 0) throw StateError("wx_band_resume: no exchange is pending");
@@ -1867,6 +1946,29 @@ int wx_band_resume(wx_handle h, int* next_xid) {
     if (!next_xid) throw wx::ConfigError("wx_band_resume: null next_xid");
     *next_xid = h->impl->band_resume();
   });
+}
+int wx_band_rccl_unique_id(uint8_t id[128]) {
+  return guarded([&] {
+    if (!id) throw wx::ConfigError("wx_band_rccl_unique_id: null argument");
+    wx::RcclApi& api = wx::RcclApi::get();
+    ncclUniqueId u;
+    api.check(api.GetUniqueId(&u), "ncclGetUniqueId");
+    static_assert(sizeof(u) == 128, "ncclUniqueId size");
+    std::memcpy(id, &u, 128);
+  });
+}
+int wx_band_rccl_init(wx_handle h, const uint8_t id[128]) {
+  return guarded([&] {
+    WX_NEED(h);
+    if (!id) throw wx::ConfigError("wx_band_rccl_init: null argument");
+    ncclUniqueId u;
+    std::memcpy(&u, id, 128);
+    h->impl->band_rccl_init(u);
+  });
+}
+int wx_band_step_rccl(wx_handle h, const float* x_band, const float* frc_band, float* y_band, float* y_phys_band, float* x_next_band,
+                      void* stream) {
+  return guarded([&] { WX_NEED(h); h->impl->band_step_rccl(x_band, frc_band, y_band, y_phys_band, x_next_band, (hipStream_t)stream); });
 }
 // host-only plan: a never-finalized engine object supplies the derived geometry (no HIP call is made)
 struct wx_band_plan_s { wx::BandPlan plan; };

@@ -73,6 +73,9 @@ _PROTOTYPES = {
                           C.POINTER(C.c_int)], C.c_int),
     "wx_band_begin": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)], C.c_int),
     "wx_band_resume": ([C.c_void_p, C.POINTER(C.c_int)], C.c_int),
+    "wx_band_rccl_unique_id": ([C.POINTER(C.c_uint8)], C.c_int),
+    "wx_band_rccl_init": ([C.c_void_p, C.POINTER(C.c_uint8)], C.c_int),
+    "wx_band_step_rccl": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "wx_band_plan_create": ([C.POINTER(wx_config), C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     "wx_band_plan_destroy": ([C.c_void_p], C.c_int),
     "wx_band_plan_num_exchanges": ([C.c_void_p, C.POINTER(C.c_int)], C.c_int),

@@ -208,13 +208,35 @@ class DistBand:
     """One rank of a sharded forecast in a torch.distributed world (one process per GPU).  backend "nccl" (= RCCL)
     moves the staging slices GPU to GPU over xGMI; with "gloo" they are staged through host memory."""
 
-    def __init__(self, engine: WXEngine, group=None):
+    def __init__(self, engine: WXEngine, group=None, transport: Optional[str] = None):
+        """transport: "rccl" = grouped ncclSend/ncclRecv issued by the engine itself on the compute stream (default with the
+        nccl backend; no Python between the segments of a step), "torch" = torch.distributed P2P ops on the staging slices
+        (any backend; the default with gloo).  Env WX_BAND_TRANSPORT overrides the default."""
+        import os
         import torch.distributed as dist
-        if not dist.is_initialized():
-            raise WXEngineError("DistBand needs an initialised torch.distributed process group")
         self.dist, self.group = dist, group
-        self.band = BandRank(engine, dist.get_rank(group), dist.get_world_size(group))
-        self.host_staged = dist.get_backend(group) == "gloo"
+        live = dist.is_available() and dist.is_initialized()
+        if live:
+            self.band = BandRank(engine, dist.get_rank(group), dist.get_world_size(group))
+            self.host_staged = dist.get_backend(group) == "gloo"
+        else:                      # a world of one: same program, nothing to exchange
+            self.band = BandRank(engine, 0, 1)
+            self.host_staged = False
+        if transport is None:
+            transport = os.environ.get("WX_BAND_TRANSPORT", "rccl" if (live and dist.get_backend(group) == "nccl") else "torch")
+        if transport not in ("rccl", "torch"):
+            raise WXEngineError("transport must be 'rccl' or 'torch'")
+        self.transport = transport
+        if transport == "rccl":
+            lib = engine.lib
+            ident = (C.c_uint8 * 128)()
+            if self.band.rank == 0:
+                _check(lib.wx_band_rccl_unique_id(ident))
+            if live:
+                box = [bytes(ident)]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            _check(lib.wx_band_rccl_init(engine._h, ident))
         self.exchanged_bytes = 0
 
     @property
@@ -231,6 +253,14 @@ class DistBand:
         cfg = self.band.eng.cfg
         if y is None:
             y = torch.empty(self.band.band_shape(cfg.base_output_channels), dtype=torch.float32, device=x_band.device)
+        if self.transport == "rccl":
+            eng = self.band.eng
+            for t, name in ((x_band, "x_band"), (frc_band, "frc_band"), (y, "y"), (y_phys, "y_phys"), (x_next, "x_next")):
+                if t is not None:
+                    eng._chk_in(t, name)
+            p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+            _check(eng.lib.wx_band_step_rccl(eng._h, p(x_band), p(frc_band), p(y), p(y_phys), p(x_next), eng._stream()))
+            return y, y_phys, x_next
         xid = self.band.begin(x_band, frc_band, y, y_phys, x_next)
         while xid >= 0:
             self._exchange(xid)

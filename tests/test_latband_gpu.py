@@ -136,6 +136,27 @@ def test_band_mode_guards():
         BandRank(w, 0, 2)
 
 
+def test_rccl_transport_world_of_one():
+    """The in-engine RCCL driver (dlopen'd librccl, ncclCommInitRank, whole step in one C call) on the one GPU we have: a
+    communicator of one rank, so the grouped send/recv lists are empty -- what this pins is the binding, the communicator
+    life cycle and the segment loop; the message lists themselves are the ones the gloo tests move."""
+    cfg = named_config("T1")
+    sd = synth_state_dict(cfg)
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    frc = torch.from_numpy(synth_forcing(cfg, _layout(cfg)[2], 1)).cuda()
+    y0, p0, x0 = _reference(cfg, sd, "fp32").step(x, frc)
+    eng = _reference(cfg, sd, "fp32")
+    db = DistBand(eng, transport="rccl")
+    assert db.transport == "rccl" and db.rows == (0, cfg.image_height)
+    xb, fb = x[0, :, 0].contiguous(), frc[0, :, 0].contiguous()
+    yp, xn = torch.empty_like(y0[0, :, 0]), torch.empty_like(xb)
+    for _ in range(2):
+        y, yp, xn = db.step(xb, fb, y_phys=yp, x_next=xn)
+    _close(y, y0[0, :, 0], "fp32")
+    _close(yp, p0[0], "fp32")
+    _close(xn, x0[0, :, 0], "fp32")
+
+
 # ---- two real processes over torch.distributed on the one GPU ---------------------------------------------------------
 def _free_port():
     s = socket.socket()
