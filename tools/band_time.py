@@ -49,6 +49,10 @@ for n in [int(a) for a in sys.argv[3:]]:
         st = r.eng.profile_read()
         per_rank.append(sum(k["ms"] for k in st) / K)
         xch.append(sum(k["ms"] for k in st if k["name"].startswith("band_")) / K)
+    if os.environ.get("BAND_CLASSES"):
+        slow_r = max(range(n), key=lambda i: per_rank[i])
+        rows = sorted(vb.ranks[slow_r].eng.profile_read(), key=lambda k: -k["ms"])
+        print(f"     slowest rank {slow_r} by class: " + ", ".join(f"{k['name']} {k['ms'] / K:.3f} ({k['launches'] // K})" for k in rows[:14]))
     err = (y - y0).abs().max().item() / y0.abs().max().item()
     slow = max(per_rank)
     print(f"  n={n}: rows {vb.starts}")
