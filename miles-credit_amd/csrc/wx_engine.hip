@@ -1357,7 +1357,6 @@ class Engine : public EngineBase {
   static void band_check_supported(const Engine& e) {
     if (e.cfg.arch != WX_ARCH_CROSSFORMER) throw ConfigError("lat-band mode: only the legacy `crossformer` architecture (the 0.25-degree config) is wired");
     if (e.cfg.frames != 1 || e.cfg.output_frames != 1) throw ConfigError("lat-band mode needs frames == output_frames == 1");
-    if (e.halo != 15 && e.stages[0].embed_k.size() && false) throw ConfigError("unreachable");
   }
 
   void band_enable(int rank, int n) override {
