@@ -162,6 +162,7 @@ enum BandBuf {
   BB_DEC,         // decoder output map, 1 halo row
   BB_GN_ACC,      // GroupNorm (sum, sum sq) of this rank: one "row"
   BB_GN_ALL,      // ... of every rank: n rows
+  BB_PS4,         // wxformer head: pixel-shuffled map before the final 3x3 conv, 1 halo row
 };
 
 struct BandModel {
@@ -175,6 +176,7 @@ struct BandModel {
   int elem = 2;                          // sizeof(T)
   int up_cout[3] = {0, 0, 0};            // decoder level output channels
   int Hd = 0, Wd = 0, Hu = 0, Ho = 0, off_y = 0, interp = 0, ld_dec = 0;
+  int wxformer = 0, cpad4 = 0;           // PixelShuffle decoder (wxformer/crossformer.py:137-162, :817-830)
 };
 
 struct BandPlan {
@@ -197,6 +199,13 @@ struct BandPlan {
     } else {
       *r0 = *r1 = oy;
     }
+  }
+  // wxformer decoder level with output rows [a, b) of a map of m.sh[so] rows: input rows [j0, j1) whose pixel-shuffled
+  // rows cover [max(a-1, 0), min(b+1, sh)) -- what the "sharp" 3x3 conv of the owned rows reads
+  void dec_ps_rows(int so, int a, int b, int* j0, int* j1) const {
+    const int pa = std::max(a - 1, 0), pb = std::min(b + 1, m.sh[so]);
+    *j0 = pa / 2;
+    *j1 = (pb + 1) / 2;
   }
   int src_row_of_padded(int gp) const {  // boundary_padding.py:50-72: the pole pads mirror rows 0..p-1 / H-p..H-1
     if (gp < m.p0) return m.p0 - 1 - gp;
@@ -307,7 +316,14 @@ struct BandPlan {
                  [&, so](int r) {
                    std::vector<int> v;
                    const int a = g.ps[so][r], b = g.ps[so][r + 1];
-                   if (a < b) for (int j = a / 2; j < (b + 1) / 2; ++j) v.push_back(j);
+                   if (a >= b) return v;
+                   if (!m.wxformer) {   // ConvTranspose k2 s2: output rows 2j, 2j+1 from input row j
+                     for (int j = a / 2; j < (b + 1) / 2; ++j) v.push_back(j);
+                   } else {             // 3x3 conv -> PixelShuffle -> 3x3 "sharp" conv: the shuffled rows a-1 .. b (inside
+                     int j0, j1;        // the map) are recomputed locally, each from input rows j-1 .. j+1
+                     dec_ps_rows(so, a, b, &j0, &j1);
+                     for (int j = j0 - 1; j < j1 + 1; ++j) v.push_back(j);
+                   }
                    return v;
                  },
                  [](int) { return 0; }, band_owner_rows(g.ps[si], si < 3 ? 1 : 0));
@@ -327,6 +343,7 @@ struct BandPlan {
     {
       std::vector<int> dstarts(n + 1);
       for (int r = 0; r <= n; ++r) dstarts[r] = 2 * g.ps[0][r];
+      if (m.wxformer) add_halo("halo_ps4", BB_PS4, 0, (int64_t)m.Wd * m.cpad4 * m.elem, m.Hd, dstarts);
       add_halo("halo_dec", BB_DEC, 0, (int64_t)m.Wd * m.ld_dec * m.elem, m.Hd, dstarts);
     }
   }

@@ -1312,6 +1312,7 @@ class Engine : public EngineBase {
   BandPlan bplan;
   int gsh[4] = {0, 0, 0, 0};           // global stage rows; sh[] holds the LOCAL rows of the current layout while a band step runs
   T *bcat[3] = {nullptr, nullptr, nullptr}, *bx3 = nullptr, *blong[4] = {nullptr, nullptr, nullptr, nullptr};
+  T *bps[3] = {nullptr, nullptr, nullptr}, *bps4 = nullptr;   // wxformer: pixel-shuffled maps (2 / 1 halo rows, rows beyond the map stay zero)
   T *bxin = nullptr, *bxin_planar = nullptr, *bemb_in = nullptr, *bdec_in = nullptr, *bscut = nullptr, *bta = nullptr, *btb = nullptr,
     *bdec = nullptr;
   float* bxneed = nullptr;
@@ -1352,10 +1353,12 @@ class Engine : public EngineBase {
     for (int i = 0; i < 3; ++i) m.up_cout[i] = e.cfg.dim[2 - i];
     m.Hd = e.Hd; m.Wd = e.Wd; m.Hu = e.Hu; m.Ho = e.Ho; m.off_y = e.cfg.pad_activate ? e.cfg.pad_lat[0] : 0;
     m.interp = e.cfg.interp; m.ld_dec = e.ld_dec;
+    m.wxformer = e.cfg.arch == WX_ARCH_WXFORMER; m.cpad4 = ((e.C_out + 31) / 32) * 32;
     return m;
   }
   static void band_check_supported(const Engine& e) {
-    if (e.cfg.arch != WX_ARCH_CROSSFORMER) throw ConfigError("lat-band mode: only the legacy `crossformer` architecture (the 0.25-degree config) is wired");
+    if (e.cfg.arch != WX_ARCH_CROSSFORMER && e.cfg.arch != WX_ARCH_WXFORMER)
+      throw ConfigError("lat-band mode: the upsample_v_conv decoder variant is not wired (crossformer and wxformer are)");
     if (e.cfg.frames != 1 || e.cfg.output_frames != 1) throw ConfigError("lat-band mode needs frames == output_frames == 1");
   }
 
@@ -1398,7 +1401,12 @@ class Engine : public EngineBase {
     }
     for (int i = 0; i < 3; ++i) {
       const int si = 3 - i, so = 2 - i;
-      const int64_t rows_in = (g.rows_short(so, rank) + 1) / 2 + 1;
+      const int64_t rows_in = (g.rows_short(so, rank) + 1) / 2 + 1 + (cfg.arch == WX_ARCH_WXFORMER ? 4 : 0);
+      if (cfg.arch == WX_ARCH_WXFORMER) {
+        const int64_t el = (int64_t)(g.rows_short(so, rank) + 4) * sw[so] * ups[i].cout;
+        bps[i] = (T*)dalloc(el * sizeof(T));
+        WX_HIP(hipMemset(bps[i], 0, el * sizeof(T)));
+      }
       dec_in_max = std::max(dec_in_max, rows_in * sw[si] * (i == 0 ? cfg.dim[3] : 2 * cfg.dim[si]));
       dt_max = std::max(dt_max, (int64_t)(g.rows_short(so, rank) + 2) * sw[so] * ups[i].cout);
     }
@@ -1409,6 +1417,11 @@ class Engine : public EngineBase {
     btb = (T*)dalloc(dt_max * sizeof(T));
     WX_HIP(hipMemset(bscut, 0, dt_max * sizeof(T)));
     WX_HIP(hipMemset(btb, 0, dt_max * sizeof(T)));
+    if (cfg.arch == WX_ARCH_WXFORMER) {
+      const int64_t el = (int64_t)(2 * g.rows_short(0, rank) + 2) * Wd * cpad4;
+      bps4 = (T*)dalloc(el * sizeof(T));
+      WX_HIP(hipMemset(bps4, 0, el * sizeof(T)));
+    }
     const int64_t dec_el = (int64_t)(2 * g.rows_short(0, rank) + 2) * Wd * ld_dec;
     bdec = (T*)dalloc(dec_el * sizeof(T));
     WX_HIP(hipMemset(bdec, 0, dec_el * sizeof(T)));
@@ -1471,6 +1484,7 @@ class Engine : public EngineBase {
       case BB_DEC: return tok(bdec, ld_dec, ld_dec, 0, Wd);
       case BB_GN_ACC: return BRow{reinterpret_cast<char*>(gn_acc), x.row_bytes, x.row_bytes, x.row_bytes, 1};
       case BB_GN_ALL: return BRow{reinterpret_cast<char*>(gn_all), x.row_bytes, x.row_bytes, x.row_bytes, 1};
+      case BB_PS4: return tok(bps4, cpad4, cpad4, 0, Wd);
     }
     throw StateError("band: unknown buffer id");
   }
@@ -1636,10 +1650,22 @@ class Engine : public EngineBase {
         stat_tiles_ready = 0;
         const UpL& u = ups[i];
         const int a = g.ps[so][r], b = g.ps[so][r + 1];
-        if (b > a) {
+        const int64_t in_ld = i == 0 ? cfg.dim[3] : 2 * cfg.dim[si];
+        if (b > a && cfg.arch == WX_ARCH_WXFORMER) {
+          // x = PixelShuffle(conv3x3(x)); x = x + sharp(x)  (wxformer/crossformer.py:157-158) on rows a-1 .. b of the
+          // shuffled map, recomputed here instead of exchanged; bdec_in holds input rows j0-1 .. j1 (zero beyond the map)
+          int j0, j1;
+          bplan.dec_ps_rows(so, a, b, &j0, &j1);
+          const int64_t row = (int64_t)sw[so] * u.cout;
+          T* ps = bps[i];                                    // buffer row 0 = map row a - 2
+          gemm("gemm_convPS", u.convps, bdec_in, j1 - j0 + 2, sw[si], in_ld, 1, 0, 1, j1 - j0, sw[si], ps + (2 * j0 - (a - 2)) * row, u.cout,
+               nullptr, 0, nullptr, 0, 1, u.cout);
+          gemm("gemm_conv3", u.sharp, ps + row, b - a + 2, sw[so], u.cout, 1, 0, 1, b - a, sw[so], bscut + row, u.cout, nullptr, 0, ps + 2 * row,
+               u.cout);
+        } else if (b > a) {
           const int j0 = a / 2, j1 = (b + 1) / 2;
           T* out = bscut + (int64_t)(2 * j0 - (a - 1)) * sw[so] * u.cout;   // output rows 2 j0 .. 2 j1 - 1; owned row `a` is buffer row 1
-          gemm("gemm_convT2", u.convt, bdec_in, j1 - j0, sw[si], i == 0 ? cfg.dim[3] : 2 * cfg.dim[si], 1, 0, 0, j1 - j0, sw[si], out, u.cout,
+          gemm("gemm_convT2", u.convt, bdec_in, j1 - j0, sw[si], in_ld, 1, 0, 0, j1 - j0, sw[si], out, u.cout,
                nullptr, 0, nullptr, 0, 1, u.cout);
         }
       }, "halo_scut", lv);
@@ -1680,10 +1706,22 @@ class Engine : public EngineBase {
       });
     }
     band_attach("halo_cat0");
+    if (cfg.arch == WX_ARCH_WXFORMER) {
+      band_op([this, r] {
+        cur_stage = 7;
+        const int rows = bplan.g.rows_short(0, r);
+        gemm("gemm_convPS", ps4, bcat[0], rows + 2, sw[0], 2 * cfg.dim[0], 1, 0, 1, rows, sw[0], bps4 + (int64_t)Wd * cpad4, cpad4, nullptr, 0,
+             nullptr, 0, 1, cpad4);
+      }, "halo_ps4");
+    }
     band_op([this, r] {
       const BandGeom& g = bplan.g;
       cur_stage = 7;
       const int rows = g.rows_short(0, r);
+      if (cfg.arch == WX_ARCH_WXFORMER) {
+        gemm("gemm_conv3", fin4, bps4, 2 * rows + 2, Wd, cpad4, 1, 0, 1, 2 * rows, Wd, bdec + (int64_t)Wd * ld_dec, ld_dec, nullptr, 0, nullptr, 0);
+        return;
+      }
       for (int q = 0; q < 4; ++q) {
         const int py = q >> 1, px = q & 1;
         gemm("gemm_convT4", up4[q], bcat[0], rows + 2, sw[0], 2 * cfg.dim[0], 1, -py, 1 - px, rows, sw[0], bdec + (int64_t)Wd * ld_dec, ld_dec,

@@ -64,7 +64,8 @@ def _close(a, b, prec, l2_tol=1e-2, max_tol=5e-2):
 
 
 @pytest.mark.parametrize("name,prec,n", [("T0", "fp32", 2), ("T0", "fp32", 3), ("T1", "fp32", 3), ("T1", "fp32", 8), ("T1", "bf16", 2),
-                                         ("C1", "fp32", 5), ("C1", "bf16", 4)])
+                                         ("C1", "fp32", 5), ("C1", "bf16", 4), ("T0W", "fp32", 2), ("T0W", "fp32", 3), ("C1W", "fp32", 4),
+                                         ("C1W", "bf16", 5)])
 def test_sharded_step_equals_unsharded(name, prec, n):
     """Ragged bands (T1/3, C1/5), ranks that own no rows at the deepest stages (T0, T1/8) or no grid rows at all because their
     band is pole padding (T1/8), y / y_phys / x_next of wx_step."""
@@ -129,10 +130,10 @@ def test_band_mode_guards():
     assert xid == 0 and band.messages(0)[0]  # rank 0 of 2 owes rank 1 the rows under its halo
     with pytest.raises(WXEngineError, match="still waiting"):
         band.begin(xb)
-    w = WXEngine(named_config("T0W"), "fp32", 0)
-    w.load_state_dict(synth_state_dict(named_config("T0W")))
+    w = WXEngine(named_config("T0U"), "fp32", 0)
+    w.load_state_dict(synth_state_dict(named_config("T0U")))
     w.finalize()
-    with pytest.raises(WXEngineError, match="crossformer"):
+    with pytest.raises(WXEngineError, match="upsample_v_conv"):
         BandRank(w, 0, 2)
 
 

@@ -83,8 +83,9 @@ def test_single_rank_plan_moves_nothing():
 def test_unsupported_worlds_raise():
     with pytest.raises(WXEngineError, match="more ranks than window rows"):
         BandPlan(named_config("T0"), 9, "bf16")            # 8 window rows at stage 0
-    with pytest.raises(WXEngineError, match="crossformer"):
-        BandPlan(named_config("T0W"), 2, "bf16")           # wxformer decoder is not wired for sharding yet
+    with pytest.raises(WXEngineError, match="upsample_v_conv"):
+        BandPlan(named_config("T0U"), 2, "bf16")           # the bilinear-upsample decoder variant is not wired for sharding
+    assert BandPlan(named_config("T0W"), 2, "bf16").num_exchanges == BandPlan(named_config("T0"), 2, "bf16").num_exchanges + 1
     with pytest.raises(WXEngineError):
         BandPlan(named_config("T0"), 0, "bf16")
 
