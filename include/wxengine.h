@@ -168,6 +168,11 @@ int wx_post_add_energy_fixer_signed(wx_post_handle p, int T_start, int q_start, 
                                     const int32_t* toa_inds, const float* toa_signs, int n_srf, const int32_t* srf_inds,
                                     const float* srf_signs, const float* gph_surf, float n_seconds, int denorm);
 int wx_post_apply(wx_post_handle p, const float* x_dev, float* y_dev, void* stream);
+/* Lat-band mode: the block covers rows [row0, row0 + rows) of the grid it was created for (x / y are bands then); call it
+ * right after wx_post_create.  lat2d / lon2d / gph_surf passed afterwards are still whole-grid arrays (cell areas need the
+ * neighbouring latitudes).  Such a block only runs attached to a lat-band engine (wx_attach_postblock BEFORE
+ * wx_band_enable), which completes the global integrals of gen1.py:280-1030 with one exchange per fixer. */
+int wx_post_set_band(wx_post_handle p, int row0, int rows);
 /* Run `p` inside wx_forward / wx_step (after the tail, before y_phys and x_next); NULL detaches.  The engine does not
  * take ownership. */
 int wx_attach_postblock(wx_handle h, wx_post_handle p);

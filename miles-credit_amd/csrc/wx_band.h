@@ -163,6 +163,8 @@ enum BandBuf {
   BB_GN_ACC,      // GroupNorm (sum, sum sq) of this rank: one "row"
   BB_GN_ALL,      // ... of every rank: n rows
   BB_PS4,         // wxformer head: pixel-shuffled map before the final 3x3 conv, 1 halo row
+  BB_FIX_ACC,     // post-block fixer: this rank's 4 global-integral partial sums (one row of 32 bytes)
+  BB_FIX_ALL,     // ... of every rank
 };
 
 struct BandModel {
@@ -177,6 +179,7 @@ struct BandModel {
   int up_cout[3] = {0, 0, 0};            // decoder level output channels
   int Hd = 0, Wd = 0, Hu = 0, Ho = 0, off_y = 0, interp = 0, ld_dec = 0;
   int wxformer = 0, cpad4 = 0;           // PixelShuffle decoder (wxformer/crossformer.py:137-162, :817-830)
+  int n_fix = 0;                         // conservation fixers of the attached post block (one sum exchange each)
 };
 
 struct BandPlan {
@@ -345,6 +348,15 @@ struct BandPlan {
       for (int r = 0; r <= n; ++r) dstarts[r] = 2 * g.ps[0][r];
       if (m.wxformer) add_halo("halo_ps4", BB_PS4, 0, (int64_t)m.Wd * m.cpad4 * m.elem, m.Hd, dstarts);
       add_halo("halo_dec", BB_DEC, 0, (int64_t)m.Wd * m.ld_dec * m.elem, m.Hd, dstarts);
+    }
+    for (int k = 0; k < m.n_fix; ++k) {   // global mass / water / energy integrals (gen1.py:280-1030): every rank's 4 sums to everyone
+      BandExchange x;
+      x.name = "fix." + std::to_string(k);
+      x.src_buf = BB_FIX_ACC; x.dst_buf = BB_FIX_ALL; x.stage = 0; x.row_bytes = 32;
+      x.recv.resize(n);
+      for (int r = 0; r < n; ++r)
+        for (int q = 0; q < n; ++q) x.recv[r].push_back(BandSeg{q, 0, q, 1});
+      xs.push_back(std::move(x));
     }
   }
 };

@@ -932,7 +932,8 @@ class Engine : public EngineBase {
   PostBlock* post = nullptr;    // not owned
   float* y_internal = nullptr;  // scratch for the normalised output when the caller does not ask for it
   void attach_post(PostBlock* p) override {
-    if (p && (p->h != Ho || p->w != Wo || p->cout != C_out || p->cin * p->fr != C_in || p->fr != cfg.frames))
+    if (band_on) throw StateError("wx_attach_postblock: attach the post block before wx_band_enable");
+    if (p && (p->h_full != Ho || p->w != Wo || p->cout != C_out || p->cin * p->fr != C_in || p->fr != cfg.frames))
       throw ConfigError("wx_attach_postblock: post block geometry does not match the model");
     post = p;
   }
@@ -1316,7 +1317,8 @@ class Engine : public EngineBase {
   T *bxin = nullptr, *bxin_planar = nullptr, *bemb_in = nullptr, *bdec_in = nullptr, *bscut = nullptr, *bta = nullptr, *btb = nullptr,
     *bdec = nullptr;
   float* bxneed = nullptr;
-  double* gn_all = nullptr;
+  double *gn_all = nullptr, *fix_all = nullptr;
+  float* by_internal = nullptr;   // y band when a post block runs and the caller did not ask for y
   bool b_long[4] = {false, false, false, false};
   char *b_send = nullptr, *b_recv = nullptr;
   int64_t b_send_need = 0, b_recv_need = 0;
@@ -1354,6 +1356,7 @@ class Engine : public EngineBase {
     m.Hd = e.Hd; m.Wd = e.Wd; m.Hu = e.Hu; m.Ho = e.Ho; m.off_y = e.cfg.pad_activate ? e.cfg.pad_lat[0] : 0;
     m.interp = e.cfg.interp; m.ld_dec = e.ld_dec;
     m.wxformer = e.cfg.arch == WX_ARCH_WXFORMER; m.cpad4 = ((e.C_out + 31) / 32) * 32;
+    m.n_fix = e.post ? e.post->n_fixers() : 0;
     return m;
   }
   static void band_check_supported(const Engine& e) {
@@ -1366,7 +1369,6 @@ class Engine : public EngineBase {
     if (!finalized) throw StateError("wx_band_enable: finalize the weights first");
     if (band_on) throw StateError("wx_band_enable: already enabled");
     if (n < 1 || rank < 0 || rank >= n) throw ConfigError("wx_band_enable: bad rank / nranks");
-    if (post) throw ConfigError("lat-band mode: an attached post block needs global reductions that are not wired yet");
     band_check_supported(*this);
     WX_HIP(hipSetDevice(device));
     for (int s = 0; s < 4; ++s) gsh[s] = sh[s];
@@ -1374,6 +1376,10 @@ class Engine : public EngineBase {
     b_rank = rank; b_n = n;
     const BandGeom& g = bplan.g;
     if (g.rows_short(0, rank) <= 0) throw ConfigError("lat-band mode: more ranks than window rows at stage 0");
+    if (post && (post->row0 != g.po[rank] || post->h != g.po[rank + 1] - g.po[rank]))
+      throw ConfigError("lat-band mode: the attached post block must cover this rank's rows (wx_post_set_band with the rows of "
+                        "wx_band_plan_partition(p, 8, ...))");
+    if (post && post->h == post->h_full && n > 1) throw ConfigError("lat-band mode: the attached post block covers the whole grid");
     // ---- buffers of this band
     const int st0 = cfg.embed_strides[0];
     const int64_t xin_elems = (int64_t)(st0 * g.rows_short(0, rank) + 2 * halo + 2) * (Wp + 2 * halo + 2) * cpad0;
@@ -1426,6 +1432,8 @@ class Engine : public EngineBase {
     bdec = (T*)dalloc(dec_el * sizeof(T));
     WX_HIP(hipMemset(bdec, 0, dec_el * sizeof(T)));
     gn_all = (double*)dalloc((size_t)n * 2 * cfg.dim[3] * sizeof(double));
+    fix_all = (double*)dalloc((size_t)n * 4 * sizeof(double));
+    if (post) by_internal = (float*)dalloc(std::max<size_t>(1, (size_t)C_out * (g.po[rank + 1] - g.po[rank]) * Wo) * sizeof(float));
     for (const BandExchange& x : bplan.xs) {
       b_send_need = std::max(b_send_need, band_send_bytes(x, rank));
       b_recv_need = std::max(b_recv_need, band_recv_bytes(x, rank));
@@ -1485,6 +1493,8 @@ class Engine : public EngineBase {
       case BB_GN_ACC: return BRow{reinterpret_cast<char*>(gn_acc), x.row_bytes, x.row_bytes, x.row_bytes, 1};
       case BB_GN_ALL: return BRow{reinterpret_cast<char*>(gn_all), x.row_bytes, x.row_bytes, x.row_bytes, 1};
       case BB_PS4: return tok(bps4, cpad4, cpad4, 0, Wd);
+      case BB_FIX_ACC: return BRow{reinterpret_cast<char*>(post->sums), 32, 32, 32, 1};
+      case BB_FIX_ALL: return BRow{reinterpret_cast<char*>(fix_all), 32, 32, 32, 1};
     }
     throw StateError("band: unknown buffer id");
   }
@@ -1728,9 +1738,24 @@ class Engine : public EngineBase {
              nullptr, 0, nullptr, 0, 2, 0, py, px);
       }
     }, "halo_dec");
-    band_op([this, r] {
-      const BandGeom& g = bplan.g;
-      band_tail(2 * g.ps[0][r] - 1);
+    band_op([this, r] { band_tail(2 * bplan.g.ps[0][r] - 1, post != nullptr); });
+    if (post) {   // a12 under sharding: local integrals, every rank's sums to everyone, added in rank order, local correction
+      int k = 0;
+      for (size_t o = 0; o < post->ops.size(); ++o) {
+        if (post->ops[o].kind == 0) {
+          band_op([this, o] { post->tracer_op(post->ops[o], by ? by : by_internal, cur_stream); });
+          continue;
+        }
+        band_op([this, o] { post->reduce_op(post->ops[o], bx_own, by ? by : by_internal, cur_stream); }, "fix", "." + std::to_string(k++));
+        band_op([this, o] {
+          hipLaunchKernelGGL(band_gn_sum_kernel, dim3(1), dim3(64), 0, cur_stream, fix_all, b_n, 4, post->sums);
+          WX_HIP(hipGetLastError());
+          post->finish_op(post->ops[o], bx_own, by ? by : by_internal, cur_stream);
+        });
+      }
+      band_op([this] { band_finish_post(); });
+    }
+    band_op([this] {
       for (int s = 0; s < 4; ++s) sh[s] = gsh[s];   // leave the whole-map geometry behind
       attn_kind_override = -1;
     });
@@ -1741,14 +1766,33 @@ class Engine : public EngineBase {
     if (b_next_x >= (int)bplan.xs.size() || bplan.xs[b_next_x].name != name) throw StateError("band: program / plan out of step at " + name);
     return b_next_x++;
   }
-  void band_tail(int dec_row0) {
+  void band_x_next_copies() {
+    const int own = b_own_rows();
+    if (!bx_next || own <= 0) return;
+    const int64_t plane_b = (int64_t)own * cfg.image_width;
+    if (n_static > 0)
+      WX_HIP(hipMemcpyAsync(bx_next + n_prog * plane_b, bx_own + n_prog * plane_b, n_static * plane_b * sizeof(float), hipMemcpyDeviceToDevice, cur_stream));
+    if (n_dyn > 0)
+      WX_HIP(hipMemcpyAsync(bx_next + (n_prog + n_static) * plane_b, bfrc_own, n_dyn * plane_b * sizeof(float), hipMemcpyDeviceToDevice, cur_stream));
+  }
+  void band_finish_post() {   // after the post block: y_phys and the prognostic channels of x_next from the corrected y
+    const int own = b_own_rows();
+    if (own > 0 && (by_phys || bx_next)) {
+      hipLaunchKernelGGL(finish_kernel, dim3(2048), dim3(256), 0, cur_stream, by ? by : by_internal, (int64_t)own * Wo, C_out,
+                         have_denorm ? d_mean : nullptr, have_denorm ? d_std : nullptr, by_phys, bx_next, n_prog < 0 ? 0 : n_prog);
+      WX_HIP(hipGetLastError());
+    }
+    band_x_next_copies();
+  }
+  void band_tail(int dec_row0, bool post_mode) {
     const int own0 = bplan.g.po[b_rank], own = b_own_rows();
     if (own <= 0) return;
     TailParams p;
     p.dec = bdec; p.ld = ld_dec; p.Hd = Hd; p.Wd = Wd;
     p.off_y = cfg.pad_activate ? cfg.pad_lat[0] : 0; p.off_x = cfg.pad_activate ? cfg.pad_lon[0] : 0;
     p.Hu = Hu; p.Wu = Wu; p.H = Ho; p.W = Wo; p.C = C_out; p.interp = cfg.interp;
-    p.y = by; p.y_phys = by_phys; p.x_next = bx_next; p.n_prog = n_prog < 0 ? 0 : n_prog;
+    p.y = post_mode ? (by ? by : by_internal) : by; p.y_phys = post_mode ? nullptr : by_phys; p.x_next = post_mode ? nullptr : bx_next;
+    p.n_prog = n_prog < 0 ? 0 : n_prog;
     p.mean = have_denorm ? d_mean : nullptr; p.stdv = have_denorm ? d_std : nullptr;
     p.thr_lo = have_tracer ? d_lo : nullptr; p.thr_hi = have_tracer ? d_hi : nullptr;
     p.tracer_denorm = tracer_denorm;
@@ -1756,17 +1800,11 @@ class Engine : public EngineBase {
     const size_t lds = (size_t)C_out * 65 * sizeof(float);
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const double plane = (double)own * Wo * C_out;
-    timed("tail", 0.0, plane * (2.0 * sizeof(T) + 4.0 * ((by ? 1 : 0) + (by_phys ? 1 : 0)) + (bx_next ? 4.0 : 0.0)), [&] {
+    timed("tail", 0.0, plane * (2.0 * sizeof(T) + 4.0 * ((p.y ? 1 : 0) + (p.y_phys ? 1 : 0)) + (p.x_next ? 4.0 : 0.0)), [&] {
       hipLaunchKernelGGL(tail_kernel<T>, dim3(cdiv(Wo, 64), own), dim3(256), lds, cur_stream, p);
       WX_HIP(hipGetLastError());
     });
-    if (bx_next) {
-      const int64_t plane_b = (int64_t)own * cfg.image_width;
-      if (n_static > 0)
-        WX_HIP(hipMemcpyAsync(bx_next + n_prog * plane_b, bx_own + n_prog * plane_b, n_static * plane_b * sizeof(float), hipMemcpyDeviceToDevice, cur_stream));
-      if (n_dyn > 0)
-        WX_HIP(hipMemcpyAsync(bx_next + (n_prog + n_static) * plane_b, bfrc_own, n_dyn * plane_b * sizeof(float), hipMemcpyDeviceToDevice, cur_stream));
-    }
+    if (!post_mode) band_x_next_copies();
   }
   int band_run() {
     while (b_pc < b_ops.size()) {
@@ -2108,6 +2146,9 @@ int wx_post_create(int H, int W, int c_in, int frames, int c_out, int device, wx
   });
 }
 int wx_post_destroy(wx_post_handle p) { return guarded([&] { delete p; }); }
+int wx_post_set_band(wx_post_handle p, int row0, int rows) {
+  return guarded([&] { if (!p || !p->impl) throw wx::ConfigError("null post handle"); p->impl->set_band(row0, rows); });
+}
 int wx_post_set_grid_sigma(wx_post_handle p, const float* lat2d, const float* lon2d, const float* coef_a, const float* coef_b,
                            int n_levels, int midpoint, int sp_ind) {
   return guarded([&] {

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void fix_reduce_kernel(const FixParams p) {
   if (threadIdx.x < 4) p.partial[(int64_t)blockIdx.x * 4 + threadIdx.x] = sh[threadIdx.x][0];
 }
 
-__global__ __launch_bounds__(256) void fix_finalize_kernel(const FixParams p) {
+// block partials -> p.sums[4] (fixed order: deterministic)
+__global__ __launch_bounds__(256) void fix_sum_kernel(const FixParams p) {
   __shared__ double sh[4][256];
   double s[4] = {0.0, 0.0, 0.0, 0.0};
   for (int b = threadIdx.x; b < p.n_blocks; b += 256)
@@ -154,15 +155,17 @@ __global__ __launch_bounds__(256) void fix_finalize_kernel(const FixParams p) {
       for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const double a = sh[0][0], b = sh[1][0], c = sh[2][0], d = sh[3][0];
-    for (int k = 0; k < 4; ++k) p.sums[k] = sh[k][0];
-    double r;
-    if (p.kind == 1) r = (a - b) / c;                                   // (M_dry(t0) - M_hold(t1)) / M_fix(t1)
-    else if (p.kind == 2) r = (c + (-a - b - c)) / c;                    // (P + residual) / P
-    else r = ((double)p.n_seconds * (a - b) + c) / d;                   // (dt (R_T - F_S) + TE(t0)) / TE(t1)
-    p.ratio[0] = (float)r;
-  }
+  if (threadIdx.x < 4) p.sums[threadIdx.x] = sh[threadIdx.x][0];
+}
+// p.sums[4] (of the whole globe: under lat-band sharding the engine has added every rank's sums by now) -> correction ratio
+__global__ void fix_ratio_kernel(const FixParams p) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double a = p.sums[0], b = p.sums[1], c = p.sums[2], d = p.sums[3];
+  double r;
+  if (p.kind == 1) r = (a - b) / c;                                   // (M_dry(t0) - M_hold(t1)) / M_fix(t1)
+  else if (p.kind == 2) r = (c + (-a - b - c)) / c;                    // (P + residual) / P
+  else r = ((double)p.n_seconds * (a - b) + c) / d;                   // (dt (R_T - F_S) + TE(t0)) / TE(t1)
+  p.ratio[0] = (float)r;
 }
 
 __global__ __launch_bounds__(256) void fix_apply_kernel(const FixParams p) {
@@ -224,7 +227,7 @@ struct PostOp {
 class PostBlock {
  public:
   PostBlock(int H, int W, int c_in, int frames, int c_out, int dev)
-      : h(H), w(W), cin(c_in), fr(frames), cout(c_out), device(dev) {
+      : h(H), w(W), cin(c_in), fr(frames), cout(c_out), device(dev), h_full(H) {
     if (H < 3 || W < 3 || c_in < 1 || c_out < 1 || frames < 1) throw std::runtime_error("wx_post_create: bad geometry");
     WX_HIP(hipSetDevice(device));
     n_blocks = cdiv((int64_t)H * W, 256);
@@ -237,6 +240,7 @@ class PostBlock {
     for (void* p : allocs) (void)hipFree(p);
   }
   int h, w, cin, fr, cout, device, n_blocks = 0;
+  int h_full, row0 = 0;   // lat-band mode: the block covers rows [row0, row0 + h) of a grid of h_full rows
   std::vector<void*> allocs;
   float *area = nullptr, *plev = nullptr, *coef_a = nullptr, *coef_b = nullptr;
   int n_p = 0, midpoint = 0, sigma = 0, sp_ind = -1;
@@ -256,6 +260,15 @@ class PostBlock {
     float* d = (float*)alloc(n * sizeof(float));
     WX_HIP(hipMemcpy(d, src, n * sizeof(float), hipMemcpyHostToDevice));
     return d;
+  }
+  // Lat-band mode (wx_band.h): this block then sees only rows [r0, r0 + rows) of x and y; the grid arrays passed later are
+  // still those of the WHOLE grid (cell areas need the neighbouring latitudes), and the fixers' global sums are completed
+  // by the engine between reduce_op and finish_op.
+  void set_band(int r0, int rows) {
+    if (area || !ops.empty()) throw std::runtime_error("wx_post_set_band: call it before the grid and the fixers are set");
+    if (r0 < 0 || rows < 0 || r0 + rows > h_full) throw std::runtime_error("wx_post_set_band: rows outside the grid");
+    row0 = r0; h = rows;
+    n_blocks = (int)cdiv((int64_t)h * w, 256);
   }
   // |R^2 d(sin lat) d(lon)|, second-order one-sided differences at the edges, lon difference wrapped into (-pi, pi]
   // (credit/physics_core.py:113-125: torch.gradient(edge_order=2)); fp32 like the reference
@@ -282,15 +295,16 @@ class PostBlock {
     sp_ind = sp;
   }
   void set_area(const float* lat2d, const float* lon2d) {
-    std::vector<float> a((size_t)h * w);
+    const int H = h_full;
+    std::vector<float> a((size_t)H * w);
     const float d2r = 3.14159265358979323846f / 180.f;
     auto sl = [&](int i, int j) { return std::sin(lat2d[(size_t)i * w + j] * d2r); };
     auto lo = [&](int i, int j) { return lon2d[(size_t)i * w + j] * d2r; };
-    for (int i = 0; i < h; ++i)
+    for (int i = 0; i < H; ++i)
       for (int j = 0; j < w; ++j) {
         float dphi, dlam;
         if (i == 0) dphi = (-3.f * sl(0, j) + 4.f * sl(1, j) - sl(2, j)) / 2.f;
-        else if (i == h - 1) dphi = (3.f * sl(h - 1, j) - 4.f * sl(h - 2, j) + sl(h - 3, j)) / 2.f;
+        else if (i == H - 1) dphi = (3.f * sl(H - 1, j) - 4.f * sl(H - 2, j) + sl(H - 3, j)) / 2.f;
         else dphi = (sl(i + 1, j) - sl(i - 1, j)) / 2.f;
         if (j == 0) dlam = (-3.f * lo(i, 0) + 4.f * lo(i, 1) - lo(i, 2)) / 2.f;
         else if (j == w - 1) dlam = (3.f * lo(i, w - 1) - 4.f * lo(i, w - 2) + lo(i, w - 3)) / 2.f;
@@ -301,7 +315,7 @@ class PostBlock {
         dlam = t - pi;
         a[(size_t)i * w + j] = std::fabs((float)(kRadEarth * kRadEarth) * dphi * dlam);
       }
-    area = upload(a.data(), a.size());
+    area = upload(a.data() + (size_t)row0 * w, std::max<size_t>((size_t)h * w, 1));
   }
   void set_stats(const float* mi, const float* si, const float* mo, const float* so) {
     WX_HIP(hipSetDevice(device));
@@ -390,39 +404,56 @@ class PostBlock {
     for (int s : {T0, q0, U0, V0}) { check_block(s, op.nlev, cout, "3-D block (output)"); check_block(s, op.nlev, cin, "3-D block (input)"); }
     for (int k = 0; k < op.toa_n; ++k) check_block(op.toa_i[k], 1, cout, "flux channel");
     for (int k = 0; k < op.srf_n; ++k) check_block(op.srf_i[k], 1, cout, "flux channel");
-    op.gph = upload(gph_surf, (size_t)h * w);
+    op.gph = upload(gph_surf + (size_t)row0 * w, std::max<size_t>((size_t)h * w, 1));
     ops.push_back(op);
   }
 
+  FixParams fix_params(const PostOp& op, const float* x, float* y) const {
+    FixParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = x; p.y = y; p.hw = h * w; p.c_in = cin; p.frames = fr; p.c_out = cout;
+    p.area = area; p.p = plev; p.ca = coef_a; p.cb = coef_b; p.sigma = sigma; p.sp_ind = sp_ind; p.n_p = n_p; p.midpoint = midpoint;
+    if (op.denorm) { p.mean_in = mean_in; p.std_in = std_in; p.mean_out = mean_out; p.std_out = std_out; }
+    p.kind = op.kind; p.q0 = op.q0; p.nlev = op.nlev;
+    p.ind_fix = n_p - op.fix_level_num + 1;                 // gen1.py:224 / :264
+    p.ind_fix_start = midpoint ? p.ind_fix : p.ind_fix - 1;  // gen1.py:267-270
+    p.precip = op.precip; p.evapor = op.evapor;
+    p.T0 = op.T0; p.U0 = op.U0; p.V0 = op.V0;
+    p.toa_n = op.toa_n; p.srf_n = op.srf_n;
+    for (int k = 0; k < 4; ++k) { p.toa_i[k] = op.toa_i[k]; p.toa_s[k] = op.toa_s[k]; }
+    for (int k = 0; k < 8; ++k) { p.srf_i[k] = op.srf_i[k]; p.srf_s[k] = op.srf_s[k]; }
+    p.gph = op.gph; p.n_seconds = op.n_seconds;
+    p.partial = partial; p.sums = sums; p.ratio = ratio; p.n_blocks = n_blocks;
+    return p;
+  }
+  void tracer_op(const PostOp& op, float* y, hipStream_t stream) {
+    if (n_blocks <= 0) return;
+    hipLaunchKernelGGL(fix_tracer_kernel, dim3(n_blocks), dim3(256), 0, stream, y, h * w, op.n_tr, op.tr_inds, op.tr_lo, op.tr_hi,
+                       op.denorm ? mean_out : nullptr, op.denorm ? std_out : nullptr);
+    WX_HIP(hipGetLastError());
+  }
+  // a fixer in two halves: the (local) integrals -> sums[4] ...
+  void reduce_op(const PostOp& op, const float* x, float* y, hipStream_t stream) {
+    const FixParams p = fix_params(op, x, y);
+    if (n_blocks > 0) hipLaunchKernelGGL(fix_reduce_kernel, dim3(n_blocks), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(fix_sum_kernel, dim3(1), dim3(256), 0, stream, p);
+    WX_HIP(hipGetLastError());
+  }
+  // ... and, once sums[4] hold the integrals over the whole globe, the ratio and the correction
+  void finish_op(const PostOp& op, const float* x, float* y, hipStream_t stream) {
+    const FixParams p = fix_params(op, x, y);
+    hipLaunchKernelGGL(fix_ratio_kernel, dim3(1), dim3(1), 0, stream, p);
+    if (n_blocks > 0) hipLaunchKernelGGL(fix_apply_kernel, dim3(n_blocks), dim3(256), 0, stream, p);
+    WX_HIP(hipGetLastError());
+  }
+  int n_fixers() const { int n = 0; for (const PostOp& op : ops) n += op.kind != 0; return n; }
   void apply(const float* x, float* y, hipStream_t stream) {
     WX_HIP(hipSetDevice(device));
-    const int hw = h * w;
+    if (h != h_full) throw std::runtime_error("wx_post_apply: this block covers a latitude band; it only runs inside a lat-band engine");
     for (const PostOp& op : ops) {
-      if (op.kind == 0) {
-        hipLaunchKernelGGL(fix_tracer_kernel, dim3(n_blocks), dim3(256), 0, stream, y, hw, op.n_tr, op.tr_inds, op.tr_lo, op.tr_hi,
-                           op.denorm ? mean_out : nullptr, op.denorm ? std_out : nullptr);
-        WX_HIP(hipGetLastError());
-        continue;
-      }
-      FixParams p;
-      std::memset(&p, 0, sizeof(p));
-      p.x = x; p.y = y; p.hw = hw; p.c_in = cin; p.frames = fr; p.c_out = cout;
-      p.area = area; p.p = plev; p.ca = coef_a; p.cb = coef_b; p.sigma = sigma; p.sp_ind = sp_ind; p.n_p = n_p; p.midpoint = midpoint;
-      if (op.denorm) { p.mean_in = mean_in; p.std_in = std_in; p.mean_out = mean_out; p.std_out = std_out; }
-      p.kind = op.kind; p.q0 = op.q0; p.nlev = op.nlev;
-      p.ind_fix = n_p - op.fix_level_num + 1;                 // gen1.py:224 / :264
-      p.ind_fix_start = midpoint ? p.ind_fix : p.ind_fix - 1;  // gen1.py:267-270
-      p.precip = op.precip; p.evapor = op.evapor;
-      p.T0 = op.T0; p.U0 = op.U0; p.V0 = op.V0;
-      p.toa_n = op.toa_n; p.srf_n = op.srf_n;
-      for (int k = 0; k < 4; ++k) { p.toa_i[k] = op.toa_i[k]; p.toa_s[k] = op.toa_s[k]; }
-      for (int k = 0; k < 8; ++k) { p.srf_i[k] = op.srf_i[k]; p.srf_s[k] = op.srf_s[k]; }
-      p.gph = op.gph; p.n_seconds = op.n_seconds;
-      p.partial = partial; p.sums = sums; p.ratio = ratio; p.n_blocks = n_blocks;
-      hipLaunchKernelGGL(fix_reduce_kernel, dim3(n_blocks), dim3(256), 0, stream, p);
-      hipLaunchKernelGGL(fix_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
-      hipLaunchKernelGGL(fix_apply_kernel, dim3(n_blocks), dim3(256), 0, stream, p);
-      WX_HIP(hipGetLastError());
+      if (op.kind == 0) { tracer_op(op, y, stream); continue; }
+      reduce_op(op, x, y, stream);
+      finish_op(op, x, y, stream);
     }
   }
 };

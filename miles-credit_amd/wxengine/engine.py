@@ -90,6 +90,7 @@ _PROTOTYPES = {
     "wx_profile_read": ([C.c_void_p, C.POINTER(wx_kernel_stat), C.c_int, C.POINTER(C.c_int)], C.c_int),
     "wx_post_create": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     "wx_post_destroy": ([C.c_void_p], C.c_int),
+    "wx_post_set_band": ([C.c_void_p, C.c_int, C.c_int], C.c_int),
     "wx_pre_create": ([C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                        C.POINTER(C.c_void_p)], C.c_int),
     "wx_pre_destroy": ([C.c_void_p], C.c_int),
@@ -342,6 +343,10 @@ class WXPostBlock:
     @staticmethod
     def _ptr(a):
         return a.ctypes.data_as(C.POINTER(C.c_float))
+
+    def set_band(self, row0: int, rows: int):
+        """Lat-band mode: this block sees rows [row0, row0+rows) only (call before set_grid*; the grid arrays stay whole-grid)."""
+        _check(self.lib.wx_post_set_band(self._p, int(row0), int(rows)))
 
     def set_grid(self, lat2d, lon2d, p_levels, midpoint: bool = False):
         la, lo, pl = _fp(lat2d), _fp(lon2d), _fp(p_levels)

@@ -127,15 +127,22 @@ class VirtualBands:
     """n ranks of one sharded forecast inside ONE process on ONE GPU; exchanges are device copies between the ranks'
     staging buffers.  Used by the parity tests (sharded == unsharded) and to exercise the sharded algorithm without a node."""
 
-    def __init__(self, cfg: WXConfig, state_dict, nranks: int, precision: str = "bf16", device: int = 0, setup=None):
+    def __init__(self, cfg: WXConfig, state_dict, nranks: int, precision: str = "bf16", device: int = 0, setup=None,
+                 post_factory=None):
+        """setup(engine): denorm / layout / tracer configuration of every rank's engine.
+        post_factory(rank, row0, rows) -> WXPostBlock already restricted to those rows (WXPostBlock.set_band) and carrying
+        the same fixers on every rank; it is attached before the engine is switched to band mode."""
         self.cfg, self.n = cfg, nranks
         self.ranks: List[BandRank] = []
+        own = BandPlan(cfg, nranks, precision).partition(8)
         for r in range(nranks):
             eng = WXEngine(cfg, precision=precision, device=device)
             eng.load_state_dict(state_dict)
             eng.finalize()
             if setup is not None:
                 setup(eng)
+            if post_factory is not None:
+                eng.attach_postblock(post_factory(r, own[r], own[r + 1] - own[r]))
             self.ranks.append(BandRank(eng, r, nranks))
         self.starts = [b.row0 for b in self.ranks] + [self.ranks[-1].row0 + self.ranks[-1].rows]
         self.exchanged_bytes = 0
