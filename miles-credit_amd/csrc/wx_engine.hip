@@ -1545,8 +1545,9 @@ class Engine : public EngineBase {
   void band_rowcopy(const BRow& d, const BRow& s, const int2* map, int n) {
     if (n <= 0) return;
     if (d.width != s.width || d.hpr != s.hpr || (d.width & 15)) throw StateError("band: row shape mismatch");
-    const int64_t total = (int64_t)n * d.hpr * (d.width / 16);
-    hipLaunchKernelGGL(band_rowcopy_kernel, dim3((unsigned)std::min<int64_t>(8192, cdiv(total, 256))), dim3(256), 0, cur_stream, d.base,
+    const int64_t per_row = (int64_t)d.hpr * (d.width / 16);
+    const dim3 grid((unsigned)std::min<int64_t>(64, cdiv(per_row, 256)), (unsigned)std::min(n, 16384));
+    hipLaunchKernelGGL(band_rowcopy_kernel, grid, dim3(256), 0, cur_stream, d.base,
                        d.row_stride, d.pitch, s.base, s.row_stride, s.pitch, (int)(d.width / 16), d.hpr, n, map);
     WX_HIP(hipGetLastError());
   }
@@ -1566,8 +1567,9 @@ class Engine : public EngineBase {
     band_rowcopy(dv, band_staging(b_recv, dv), d.unpack, d.n_unpack);
     if (d.n_self > 0) band_rowcopy(dv, band_row(x.src_buf, x), d.self, d.n_self);
     if (d.n_zero > 0) {   // beyond the pole: the convolution's zero padding
-      const int64_t total = (int64_t)d.n_zero * dv.hpr * (dv.width / 16);
-      hipLaunchKernelGGL(band_rowzero_kernel, dim3((unsigned)std::min<int64_t>(8192, cdiv(total, 256))), dim3(256), 0, cur_stream, dv.base,
+      const int64_t per_row = (int64_t)dv.hpr * (dv.width / 16);
+      const dim3 grid((unsigned)std::min<int64_t>(64, cdiv(per_row, 256)), (unsigned)std::min(d.n_zero, 16384));
+      hipLaunchKernelGGL(band_rowzero_kernel, grid, dim3(256), 0, cur_stream, dv.base,
                          dv.row_stride, dv.pitch, (int)(dv.width / 16), dv.hpr, d.n_zero, d.zero);
       WX_HIP(hipGetLastError());
     }
