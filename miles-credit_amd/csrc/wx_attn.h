@@ -335,6 +335,12 @@ inline int attn_nkf_tokens(int n) {
   if (n <= 64) return 4;
   if (n <= 112) return 7;
   if (n <= 128) return 8;
+  // larger windows (the reference's own unit test uses a 16 x 16 long window, tests/test_crossformer.py:46): same kernel,
+  // more key fragments per wave; a correctness path (2 waves per SIMD at best), none of the benchmark configs takes it
+  if (n <= 160) return 10;
+  if (n <= 192) return 12;
+  if (n <= 224) return 14;
+  if (n <= 256) return 16;
   return -1;
 }
 inline int attn_pack(int wsz) { const int n = wsz * wsz; return n <= 8 ? 16 / n : 1; }
@@ -367,7 +373,11 @@ inline void launch_window_attn(const AttnParams& p, hipStream_t stream, int spli
       else if (bt) launch_window_attn_n<T, 8, false, true>(p, stream);
       else launch_window_attn_n<T, 8, false>(p, stream);
       break;
-    default: throw std::runtime_error("window attention supports at most 128 tokens per window (wsz <= 11)");
+    case 10: if (bt) launch_window_attn_n<T, 10, false, true>(p, stream); else launch_window_attn_n<T, 10, false>(p, stream); break;
+    case 12: if (bt) launch_window_attn_n<T, 12, false, true>(p, stream); else launch_window_attn_n<T, 12, false>(p, stream); break;
+    case 14: if (bt) launch_window_attn_n<T, 14, false, true>(p, stream); else launch_window_attn_n<T, 14, false>(p, stream); break;
+    case 16: if (bt) launch_window_attn_n<T, 16, false, true>(p, stream); else launch_window_attn_n<T, 16, false>(p, stream); break;
+    default: throw std::runtime_error("window attention supports at most 256 tokens per window (wsz <= 16)");
   }
 }
 

@@ -190,7 +190,7 @@ class Engine : public EngineBase {
       if (cfg.dim[s] % 32) throw ConfigError("dim must be a multiple of 32");
       for (int wsz : {cfg.local_window_size[s], cfg.global_window_size[s]}) {
         if (wsz < 1 || h % wsz || w % wsz) throw ConfigError("stage map not divisible by window size");
-        if (attn_nkf(wsz) < 0) throw ConfigError("window size > 11 (more than 128 tokens) unsupported");
+        if (attn_nkf(wsz) < 0) throw ConfigError("window size > 16 (more than 256 tokens) unsupported");
       }
     }
     for (int s = 0; s < 3; ++s) {

@@ -320,6 +320,14 @@ def named_config(name: str) -> WXConfig:
         return WXConfig.from_model_conf(_t0_conf(base), arch="wxformer")
     elif name == "T0U":  # T0 geometry, upsample_v_conv=True decoder (credit/models/crossformer.py:87-92, 560-570)
         return WXConfig.from_model_conf(dict(_t0_conf(base), upsample_v_conv=True))
+    elif name == "RT":  # the reference's own unit-test model, tests/test_crossformer.py:5-52: three CrossEmbed kernels (no k=32),
+        # a 16 x 16 long window (256 tokens) at stage 0, pads as large as the image half, upsample_v_conv decoder
+        mc = dict(frames=1, output_frames=1, channels=4, surface_channels=1, input_only_channels=4, levels=3,
+                  image_height=128, image_width=128, patch_width=1, patch_height=1,
+                  cross_embed_kernel_sizes=[[4, 8, 16], [2, 4], [2, 4], [2, 4]], cross_embed_strides=[2, 2, 2, 2],
+                  dim=[32, 64, 128, 256], depth=[2, 2, 4, 2], global_window_size=[16, 8, 4, 2], local_window_size=4,
+                  upsample_v_conv=True, interp=True, use_spectral_norm=True,
+                  padding_conf=dict(activate=True, mode="earth", pad_lat=[64, 64], pad_lon=[64, 64]))
     elif name == "C1W":  # config/gen_2/examples/example-v2026.2.yml-style 1deg wxformer (C1 geometry, PS decoder)
         mc = dict(base, image_height=181, image_width=360, levels=18,
                   dim=[64, 128, 256, 512], depth=[2, 2, 4, 2], global_window_size=[8, 4, 2, 1], local_window_size=3,

@@ -72,9 +72,11 @@ def test_forward_and_every_block_vs_oracle(name, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", ["C1", "C1W"])
+@pytest.mark.parametrize("name", ["C1", "C1W", "RT"])
 def test_c1_vs_oracle_and_reference_golden(name, prec):
-    """1-degree configs of both reference classes (legacy ConvTranspose decoder, wxformer PixelShuffle decoder)."""
+    """1-degree configs of both reference classes (legacy ConvTranspose decoder, wxformer PixelShuffle decoder), and RT = the
+    model of the reference's own unit test (tests/test_crossformer.py): 256-token long windows, three CrossEmbed kernels,
+    pads of half the image, upsample_v_conv decoder."""
     cfg = named_config(name)
     x = synth_input(cfg)
     y = get_engine(name, prec).forward(torch.from_numpy(x).cuda()).cpu()

@@ -45,7 +45,7 @@ def test_earth_pad_asymmetric_181x360():
 _SLOW = os.environ.get("WX_SLOW", "0") == "1"
 
 
-@pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W", "T0U",
+@pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W", "T0U", "RT",
                                   pytest.param("C3", marks=pytest.mark.skipif(
                                       not _SLOW, reason="~1.5 min of CPU; set WX_SLOW=1"))])
 def test_forward_matches_reference_golden(name):
