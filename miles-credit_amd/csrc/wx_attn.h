@@ -317,10 +317,10 @@ inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
   constexpr int VT_COLS = (sizeof(T) == 2) ? (NKB * 32 + 8) : (NKF * 16 + 4);
   constexpr int LDS = (SPLIT ? 1 : 4) * 32 * VT_COLS * (int)sizeof(T) + (BT ? 1024 * 4 + NKF * 16 * 4 : 0);
   auto kern = window_attn_kernel<T, NKF, SPLIT, BT>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
+  if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
+    attr_mark_device(attr_done_mask);
   }
   const int n_win = (p.H / p.wsz) * (p.W / p.wsz);
   const int64_t tasks = (int64_t)((n_win + p.pack - 1) / p.pack) * p.heads;

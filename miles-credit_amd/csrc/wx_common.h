@@ -168,4 +168,17 @@ __device__ inline void gelu4(float* v) {  // exact (erff) for the fp32 engine, t
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// "this kernel's launch attributes are set" flags: hipFuncSetAttribute applies to the CURRENT device only, so a process that
+// drives several GPUs (one engine per device) must set them once per device
+inline bool attr_done_on_device(uint64_t mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev >= 0 && dev < 64 && ((mask >> dev) & 1ull);
+}
+inline void attr_mark_device(uint64_t& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64) mask |= 1ull << dev;
+}
+
 }  // namespace wx

@@ -213,10 +213,10 @@ inline void launch_embed_patch_part(EmbedPatchParams p, int row0, int rows, cons
   constexpr int NT = NW * 64;
   constexpr int LDS = (((PH * PW) + NT - 1) / NT) * NT * 16;
   auto kern = embed_patch_kernel<T, NW, TH>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
+  if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
+    attr_mark_device(attr_done_mask);
   }
   p.row0 = row0;
   const int blocks = cdiv(rows, TH) * cdiv(p.out_w, 32);

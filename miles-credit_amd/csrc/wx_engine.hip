@@ -1291,10 +1291,10 @@ class Engine : public EngineBase {
     p.tracer_denorm = tracer_denorm;
     p.oy0 = 0; p.dec_row0 = 0; p.Hloc = Ho;
     const size_t lds = (size_t)C_out * 65 * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
+    if (!attr_done_on_device(attr_done_mask)) {
       WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done = true;
+      attr_mark_device(attr_done_mask);
     }
     if (lds > 160 * 1024) throw ConfigError("too many output channels for the tail kernel");
     const double plane = (double)Ho * Wo * C_out;

@@ -416,10 +416,13 @@ template <int C, int PXF, int OCC, int GP, bool PRE, bool POST>
 inline void launch_ff_fused_v(const FFParams& p, const void* zero_page, hipStream_t stream) {
   const int LDS = 2 * 128 * C + 8 * p.hidden + 24 * C + 8 * C;  // ring | cs1,b1 | csq,bq | b2,bo
   auto kern = ff_fused_kernel<C, PXF, OCC, GP, PRE, POST>;
-  static int attr_lds = 0;
-  if (LDS > attr_lds) {
+  static int attr_lds[64] = {};   // per device: hipFuncSetAttribute applies to the current device only
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = dev >= 0 && dev < 64 ? dev : 0;
+  if (LDS > attr_lds[dev]) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_lds = LDS;
+    attr_lds[dev] = LDS;
   }
   const int tile = 4 * PXF * 16;
   hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(p.M, tile)), dim3(256), LDS, stream, p, reinterpret_cast<const char*>(zero_page));

@@ -827,10 +827,10 @@ inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_pag
   constexpr int CT = BM * BN * (int)sizeof(T);
   constexpr int LDS = (STAGES > CT ? STAGES : CT) + 1024 + BM * 8;  // + epilogue parameter block
   auto kern = conv_gemm_dma_kernel<T, BM, BN, KB, ONE, NST, TAPIN>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
+  if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
+    attr_mark_device(attr_done_mask);
   }
   const int M = p.out_h * p.out_w;
   const int64_t blocks = (int64_t)cdiv(M, BM) * cdiv(p.n, BN);
@@ -843,10 +843,10 @@ inline void launch_conv_gemm_cfg(const ConvGemmParams& p, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int LDS = 2 * (BM + BN) * (KB + 16);
   auto kern = conv_gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, KB>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
+  if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
+    attr_mark_device(attr_done_mask);
   }
   const int M = p.out_h * p.out_w;
   const int64_t blocks = (int64_t)cdiv(M, BM) * cdiv(p.n, BN);
