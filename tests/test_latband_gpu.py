@@ -90,6 +90,26 @@ def test_sharded_step_equals_unsharded(name, prec, n):
         assert vb.exchanged_bytes > 0
 
 
+def test_baseline_config4_geometry_eight_ranks_fp32():
+    """BASELINE config 4: the 0.25-degree model over 8 ranks (ragged stage-1/2 bands, three ranks without stage-3 rows),
+    fp32 engine so that the comparison is not blurred by bf16: sharded == unsharded to 1e-5 * max|y| (observed 1.5e-6)."""
+    cfg = named_config("C3")
+    sd = synth_state_dict(cfg)
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    ref = WXEngine(cfg, "fp32", 0)
+    ref.load_state_dict(sd)
+    ref.finalize()
+    y0 = ref.forward(x).clone()
+    del ref
+    vb = VirtualBands(cfg, sd, 8, "fp32")
+    assert vb.starts == [0, 61, 161, 261, 361, 461, 561, 661, 721]
+    y, _, _ = vb.step(x)
+    _close(y, y0, "fp32")
+    assert 1.5e9 < vb.exchanged_bytes < 3.5e9          # ~3.2 GB in fp32 (1.6 GB in bf16) cross the ranks per step
+    del vb
+    torch.cuda.empty_cache()
+
+
 def test_sharded_rollout_feeds_bands_back():
     """3 steps: every rank keeps only its own band of x between steps (no gather in the loop)."""
     cfg = named_config("T1")
