@@ -763,6 +763,7 @@ class Engine : public EngineBase {
   bool fuse_ln = true;
   bool fuse_ff = true, fuse_out = true, fuse_qkv = true;          // stages with C in {128, 256}: FeedForward as one kernel (wx_ff.h), bf16 engine
   int ff_variant = 0, ff_dbg = 0, attn_split = 0;
+  int ff_min_wgs = 256;         // fused feed-forward only when it yields at least this many workgroups (WX_FF_MIN_WGS)
   float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
   int stat_tiles_ready = 0;     // > 0: `statpart` holds partials of the current stream contents (that many per row)
@@ -815,6 +816,7 @@ class Engine : public EngineBase {
     if (const char* e = getenv("WX_GEMM_CFG")) gemm_cfg = atoi(e);
     if (const char* e = getenv("WX_NO_LNFUSE")) fuse_ln = !(e[0] == '1');
     if (const char* e = getenv("WX_NO_FFFUSE")) fuse_ff = !(e[0] == '1');
+    if (const char* e = getenv("WX_FF_MIN_WGS")) ff_min_wgs = atoi(e);
     if (const char* e = getenv("WX_NO_OUTFUSE")) fuse_out = !(e[0] == '1');
     if (const char* e = getenv("WX_NO_QKVFUSE")) fuse_qkv = !(e[0] == '1');
     if (const char* e = getenv("WX_FF_VARIANT")) ff_variant = atoi(e);
@@ -1067,14 +1069,21 @@ class Engine : public EngineBase {
     stat_tiles_ready = st ? conv_gemm_n_tiles(c) : 0;
     capture(dbg_name, x, h, w, c, ld, w);
   }
-  bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on; }
+  // The fused feed-forward kernel gives every workgroup 128 (C = 128) or 64 (C = 256) pixels: below one workgroup per CU the
+  // plain GEMM chain fills the chip better (1-degree model: 45 and 22 workgroups; 507 -> 527 steps/s without the fusion)
+  bool ff_big_enough() const {
+    if (cur_stage < 0 || cur_stage > 3) return true;
+    const int64_t m = (int64_t)sh[cur_stage] * sw[cur_stage];
+    return cdiv(m, cfg.dim[cur_stage] == 128 ? 128 : 64) >= ff_min_wgs;
+  }
+  bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on && ff_big_enough(); }
   bool ff_makes_qkv(const FFL& f) const { return ff_takes_out(f) && fuse_qkv && f.pack_pp >= 0 && !band_on; }
   void feedforward(const FFL& f, int s, const std::string& dbg_name, const AttnL* pre = nullptr) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
     const int64_t ld = stream_ld(s);
     if constexpr (sizeof(T) == 2) {
-      if (f.pack >= 0 && fuse_ff) {
+      if (f.pack >= 0 && fuse_ff && ff_big_enough()) {
         FFParams fp;
         fp.x = reinterpret_cast<const bf16_t*>(x); fp.ld = ld; fp.out = reinterpret_cast<bf16_t*>(x); fp.out_ld = ld;
         const bool post = pre && ff_makes_qkv(f);

@@ -87,6 +87,32 @@ def test_c1_vs_oracle_and_reference_golden(name, prec):
     check(y[0, :, 0, ::s, ::s].numpy(), g["y"], prec)
 
 
+@pytest.mark.parametrize("name", ["T1", "C1"])
+def test_fused_feed_forward_kernel_on_small_maps(name, monkeypatch):
+    """By default the fused feed-forward kernel (wx_ff.h) only runs where it yields >= 256 workgroups (0.25-degree stages 0/1);
+    WX_FF_MIN_WGS=0 forces it onto the small maps so that its every variant (plain, +out-proj, +out-proj+qkv) is also checked
+    against the oracle at sizes the oracle finishes in seconds, ragged last tiles included."""
+    monkeypatch.setenv("WX_FF_MIN_WGS", "0")
+    cfg = named_config(name)
+    sd = synth_state_dict(cfg)
+    eng = WXEngine(cfg, "bf16", 0)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    eng.profile(1)
+    x = synth_input(cfg)
+    y = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    names = {r["name"] for r in eng.profile_read()}
+    assert "out_ff_qkv_fused" in names and "out_ff_fused" in names
+    check(y, O.forward(cfg, sd, x).numpy(), "bf16")
+    monkeypatch.delenv("WX_FF_MIN_WGS")
+    eng2 = WXEngine(cfg, "bf16", 0)
+    eng2.load_state_dict(sd)
+    eng2.finalize()
+    eng2.profile(1)
+    eng2.forward(torch.from_numpy(x).cuda())
+    assert not any("fused" in r["name"] for r in eng2.profile_read())       # small maps: the plain GEMM chain
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", ["C3S", "C3"])
 def test_full_size_vs_reference_golden(name, prec):
