@@ -230,6 +230,12 @@ template <typename T>
 inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream, int n_cu = 256) {
   if (p.dbg & 256) { launch_embed_patch_part<T, 4, 16>(p, 0, p.out_h, zero_page, stream); return; }  // A/B switch
   const int tiles_x = cdiv(p.out_w, 32), tile_rows = cdiv(p.out_h, 16);
+  if (!(p.dbg & 8192) && tile_rows * tiles_x < n_cu / 2) {
+    // small maps (1 degree: 120 x 192 outputs = 48 tiles of 16 rows on 256 CUs): 4-row tiles of 4 waves, two workgroups per
+    // CU -- four times the workgroups for 2.4x the patch traffic
+    launch_embed_patch_part<T, 4, 4>(p, 0, p.out_h, zero_page, stream);
+    return;
+  }
   const int full_rounds = (tile_rows * tiles_x) / n_cu;
   const int r1 = (full_rounds * n_cu) / tiles_x;            // tile rows that fill whole rounds
   const int rem = p.out_h - 16 * r1;
