@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void fix_reduce_kernel(const FixParams p) {
   }
   for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = s[k];
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (unsigned o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o)
       for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
     __syncthreads();
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void fix_sum_kernel(const FixParams p) {
     for (int k = 0; k < 4; ++k) s[k] += p.partial[(int64_t)b * 4 + k];
   for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = s[k];
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (unsigned o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o)
       for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
     __syncthreads();
