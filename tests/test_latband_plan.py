@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from wxengine.config import named_config
 from wxengine.engine import WXEngineError
-from wxengine.latband import BandPlan, p2p_exchange
+from wxengine.latband import BandPlan, join_rows, p2p_exchange, split_rows
 
 
 def _stage_rows(cfg):
@@ -88,6 +88,19 @@ def test_unsupported_worlds_raise():
     assert BandPlan(named_config("T0W"), 2, "bf16").num_exchanges == BandPlan(named_config("T0"), 2, "bf16").num_exchanges + 1
     with pytest.raises(WXEngineError):
         BandPlan(named_config("T0"), 0, "bf16")
+
+
+def test_split_and_join_rows_follow_the_plan_partition():
+    """shard_spatial / gather_spatial (credit/parallel/domain.py:25, :94) with the engine's own (ragged) row partition"""
+    cfg = named_config("T1")
+    starts = BandPlan(cfg, 3, "fp32").partition(8)
+    x = torch.arange(cfg.base_input_channels * cfg.image_height * cfg.image_width, dtype=torch.float32).reshape(
+        1, cfg.base_input_channels, 1, cfg.image_height, cfg.image_width)
+    bands = split_rows(x, starts)
+    assert [b.shape[1] for b in bands] == [b_ - a for a, b_ in zip(starts, starts[1:])]
+    assert all(b.is_contiguous() and b.shape[0] == cfg.base_input_channels and b.shape[2] == cfg.image_width for b in bands)
+    assert torch.equal(join_rows(bands), x[0, :, 0])
+    assert torch.equal(join_rows(split_rows(x[0, :, 0], starts)), x[0, :, 0])
 
 
 # ---- transport: the plan's messages over torch.distributed (gloo, world_size 2), CPU staging buffers -----------------
