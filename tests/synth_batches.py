@@ -45,3 +45,27 @@ def conservation_batch(seed=31, midpoint=True):
     x["cam/dynamic_forcing/2d/SOLIN"] = t(np.abs(300.0 * g.standard_normal((B, 1, 2, H, W))))
     gph = (50.0 + 20.0 * g.standard_normal((H, W))).astype(np.float32)
     return {"y_processed": {"cam": y}, "x_physical": {"cam": x}}, gph
+
+
+def odd_config(h3, w3, lw, gw, pad=None, depth=(1, 1, 1, 1), arch="crossformer"):
+    """Small CrossFormer geometries outside the BASELINE family (stage-3 map h3 x w3, local window lw, long windows gw, optional
+    asymmetric earth padding ((top, bottom), (left, right))): used to sweep the lat-band plan and the engine over window / rank
+    combinations the named configs do not hit."""
+    from wxengine.config import WXConfig
+    mc = dict(frames=1, channels=2, surface_channels=2, input_only_channels=2, output_only_channels=1, levels=2,
+              image_height=16 * h3 - (sum(pad[0]) if pad else 0), image_width=16 * w3 - (sum(pad[1]) if pad else 0),
+              patch_width=1, patch_height=1, cross_embed_kernel_sizes=[[4, 8, 16, 32], [2, 4], [2, 4], [2, 4]],
+              cross_embed_strides=[2, 2, 2, 2], dim=[32, 64, 128, 256], depth=list(depth), global_window_size=list(gw),
+              local_window_size=lw, interp=True, use_spectral_norm=True,
+              padding_conf=dict(activate=bool(pad), mode="earth", pad_lat=list(pad[0]) if pad else [0, 0],
+                                pad_lon=list(pad[1]) if pad else [0, 0]))
+    return WXConfig.from_model_conf(mc, arch=arch)
+
+
+ODD_CONFIGS = {
+    "w2": dict(h3=2, w3=4, lw=2, gw=(4, 4, 2, 2)),                         # a long window at the deepest stage too
+    "w3": dict(h3=3, w3=3, lw=3, gw=(8, 4, 2, 1)),
+    "w1": dict(h3=4, w3=4, lw=1, gw=(2, 2, 2, 2)),                         # 1-token local windows
+    "w16": dict(h3=6, w3=6, lw=2, gw=(16, 8, 4, 2), depth=(1, 1, 2, 1)),   # 256-token long windows
+    "w5p": dict(h3=5, w3=5, lw=5, gw=(8, 4, 2, 1), pad=((13, 11), (9, 7))),  # asymmetric pads, odd image
+}

@@ -90,6 +90,30 @@ def test_sharded_step_equals_unsharded(name, prec, n):
         assert vb.exchanged_bytes > 0
 
 
+@pytest.mark.parametrize("key", ["w2", "w3", "w1", "w16", "w5p"])
+def test_odd_geometries_engine_vs_oracle_and_sharded(key):
+    """Window / pad combinations outside the BASELINE family: the unsharded fp32 engine against the CPU oracle (1e-4 * max|y|),
+    then 2 and 3 lat-band ranks against the unsharded engine (1e-5 * max|y|)."""
+    from oracle import wxformer_oracle as O
+    from synth_batches import ODD_CONFIGS, odd_config
+    cfg = odd_config(**ODD_CONFIGS[key])
+    sd = synth_state_dict(cfg)
+    x = synth_input(cfg)
+    y_ref = O.forward(cfg, sd, x)
+    eng = WXEngine(cfg, "fp32", 0)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    xg = torch.from_numpy(x).cuda()
+    y0 = eng.forward(xg)
+    err = (y0.cpu() - y_ref).abs().max().item()
+    assert err <= 1e-4 * y_ref.abs().max().item(), f"{key}: engine vs oracle {err:.3e}"
+    for n in (2, 3):
+        if n > cfg.stage_hw[0][0] // cfg.local_window_size[0]:
+            continue
+        y, _, _ = VirtualBands(cfg, sd, n, "fp32").step(xg)
+        _close(y, y0, "fp32")
+
+
 def test_baseline_config4_geometry_eight_ranks_fp32():
     """BASELINE config 4: the 0.25-degree model over 8 ranks (ragged stage-1/2 bands, three ranks without stage-3 rows),
     fp32 engine so that the comparison is not blurred by bf16: sharded == unsharded to 1e-5 * max|y| (observed 1.5e-6)."""

@@ -62,6 +62,35 @@ def test_every_send_has_its_receive(name, n):
         assert sum(b for m in msgs for _, _, b in m[0]) == sum(b for m in msgs for _, _, b in m[1])
 
 
+@pytest.mark.parametrize("n", [2, 3, 5])
+@pytest.mark.parametrize("key", ["w2", "w3", "w1", "w16", "w5p"])
+def test_plan_over_window_and_rank_combinations(key, n):
+    """Geometries outside the BASELINE family (1-token and 256-token windows, long windows at the deepest stage, asymmetric pads,
+    rank counts that divide nothing): partitions stay window aligned, every message pairs up."""
+    from synth_batches import ODD_CONFIGS, odd_config
+    cfg = odd_config(**ODD_CONFIGS[key])
+    rows = _stage_rows(cfg)
+    if n > rows[0] // cfg.local_window_size[0]:
+        with pytest.raises(WXEngineError, match="more ranks than window rows"):
+            BandPlan(cfg, n, "fp32")
+        return
+    pl = BandPlan(cfg, n, "fp32")
+    for s in range(4):
+        ps, ph = pl.partition(s), pl.partition(4 + s)
+        assert ps[0] == 0 and ps[-1] == rows[s] and all(v % cfg.local_window_size[s] == 0 for v in ps)
+        assert ph[0] == 0 and ph[-1] == rows[s] // cfg.global_window_size[s]
+    po = pl.partition(8)
+    assert po[0] == 0 and po[-1] == cfg.image_height and all(b >= a for a, b in zip(po, po[1:]))
+    n_long = sum(cfg.depth[s] for s in range(4) if cfg.global_window_size[s] > 1)
+    assert sum(pl.name(x).startswith("to_long") for x in range(pl.num_exchanges)) == n_long
+    for x in range(pl.num_exchanges):
+        msgs = [pl.messages(x, r) for r in range(n)]
+        for r in range(n):
+            for peer, _, nbytes in msgs[r][0]:
+                assert [b for q, _, b in msgs[peer][1] if q == r] == [nbytes], (pl.name(x), r, peer)
+        assert sum(b for m in msgs for _, _, b in m[0]) == sum(b for m in msgs for _, _, b in m[1])
+
+
 def test_halo_messages_go_to_neighbours_only_and_carry_one_row():
     cfg = named_config("C1")
     n = 4
