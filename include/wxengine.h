@@ -97,11 +97,18 @@ int wx_tensor_info(wx_handle h, int index, const char** key, int* ndim, int64_t 
  *                         (thres_max may be NULL); denorm != 0 clamps in physical units using the wx_set_denorm stats
  * wx_set_layout       <-> build_channel_layout (credit/datasets/gen_2/channel_utils.py:161-250), single source:
  *                         x = [n_prog prognostic | n_static | n_dyn dynamic forcing]
+ * wx_set_layout_groups <-> the same function for ANY number of data sources (its ChannelGroup list, :140-250): group i covers
+ *                         input channels [x_start, x_start+count); kind 0 = prognostic, replaced at the next step by output
+ *                         channels [src_start, ...) of y (update_x, :253-291); kind 1 = dynamic_forcing, replaced by channels
+ *                         [src_start, ...) of the forcing tensor; kind 2 = fixed (static), carried forward.  The groups must
+ *                         cover every input channel exactly once.  Call after wx_finalize_weights.
  */
 int wx_set_denorm(wx_handle h, const float* mean, const float* std, int n_out);
 int wx_set_tracer_fixer(wx_handle h, const int32_t* inds, const float* thres, const float* thres_max, int n,
                         int denorm);
 int wx_set_layout(wx_handle h, int n_prog, int n_static, int n_dyn);
+int wx_set_layout_groups(wx_handle h, int n_groups, const int32_t* kind, const int32_t* x_start, const int32_t* src_start,
+                         const int32_t* count);
 
 /* ---- the hot path ---------------------------------------------------------
  * wx_forward <-> y = model(x) under eval()/no_grad() (rollout_to_netcdf.py:275):

@@ -114,6 +114,7 @@ class EngineBase {
   virtual void set_denorm(const float* mean, const float* stdv, int n) = 0;
   virtual void set_tracer(const int32_t* inds, const float* thres, const float* thres_max, int n, int denorm) = 0;
   virtual void set_layout(int n_prog, int n_static, int n_dyn) = 0;
+  virtual void set_layout_groups(int n, const int32_t* kind, const int32_t* x_start, const int32_t* src_start, const int32_t* count) = 0;
   virtual int num_tensors() = 0;
   virtual void tensor_info(int i, const char** key, int* ndim, int64_t shape[8]) = 0;
   virtual void set_debug(int on) = 0;
@@ -869,10 +870,64 @@ class Engine : public EngineBase {
     have_tracer = true;
     tracer_denorm = denorm;
   }
+  // a14: which input channels the next step takes from y (prognostic), from the forcing tensor (dynamic_forcing) or keeps
+  // (static), as explicit groups -- channel_utils.py:140-250 build_channel_layout: with several data sources a field type's
+  // channels are contiguous only within a source
+  struct LGroup { int kind, x0, src0, n; };   // kind 0 prognostic, 1 dynamic_forcing, 2 fixed
+  std::vector<LGroup> lgroups;
+  int* d_xmap = nullptr;                       // [C_out] -> input channel, or -1
   void set_layout(int np, int ns, int nd) override {
     if (np < 0 || ns < 0 || nd < 0 || np + ns + nd != C_in / cfg.frames || np > C_out)
       throw ConfigError("wx_set_layout: n_prog + n_static + n_dyn must equal the input channels");
-    n_prog = np; n_static = ns; n_dyn = nd;
+    const int32_t kind[3] = {0, 2, 1}, x0[3] = {0, np, np + ns}, s0[3] = {0, 0, 0}, cnt[3] = {np, ns, nd};
+    set_layout_groups(3, kind, x0, s0, cnt);
+  }
+  void set_layout_groups(int n, const int32_t* kind, const int32_t* x_start, const int32_t* src_start, const int32_t* count) override {
+    if (!acts_ready) throw StateError("call wx_finalize_weights before wx_set_layout");
+    WX_HIP(hipSetDevice(device));
+    if (n < 0 || (n > 0 && (!kind || !x_start || !src_start || !count))) throw ConfigError("wx_set_layout_groups: null argument");
+    const int cx = C_in / cfg.frames;
+    std::vector<int> owner(cx, -1), xmap(C_out, -1);
+    std::vector<LGroup> gs;
+    int np = 0, ns = 0, nd = 0;
+    for (int i = 0; i < n; ++i) {
+      const LGroup g{kind[i], x_start[i], src_start[i], count[i]};
+      if (g.n == 0) continue;
+      if (g.kind < 0 || g.kind > 2 || g.n < 0 || g.x0 < 0 || g.x0 + g.n > cx) throw ConfigError("wx_set_layout_groups: group outside the input channels");
+      for (int c = g.x0; c < g.x0 + g.n; ++c) {
+        if (owner[c] >= 0) throw ConfigError("wx_set_layout_groups: input channel claimed by two groups");
+        owner[c] = i;
+      }
+      if (g.kind == 0) {
+        if (g.src0 < 0 || g.src0 + g.n > C_out) throw ConfigError("wx_set_layout_groups: prognostic source outside the output channels");
+        for (int k = 0; k < g.n; ++k) {
+          if (xmap[g.src0 + k] >= 0) throw ConfigError("wx_set_layout_groups: output channel feeds two input channels");
+          xmap[g.src0 + k] = g.x0 + k;
+        }
+        np += g.n;
+      } else if (g.kind == 1) {
+        if (g.src0 < 0) throw ConfigError("wx_set_layout_groups: negative forcing offset");
+        nd = std::max(nd, g.src0 + g.n);
+      } else {
+        ns += g.n;
+      }
+      gs.push_back(g);
+    }
+    for (int c = 0; c < cx; ++c)
+      if (owner[c] < 0) throw ConfigError("wx_set_layout_groups: the groups must cover every input channel");
+    if (!d_xmap) d_xmap = (int*)dalloc((size_t)C_out * sizeof(int));
+    WX_HIP(hipMemcpy(d_xmap, xmap.data(), (size_t)C_out * sizeof(int), hipMemcpyHostToDevice));
+    lgroups = gs;
+    n_prog = np; n_static = ns; n_dyn = nd;   // n_dyn = channels of the forcing tensor
+  }
+  // the channels of x_next that do not come from y: fixed groups from x, dynamic-forcing groups from frc (planes of `plane` floats)
+  void copy_layout_groups(const float* x, const float* frc, float* x_next, int64_t plane, hipStream_t s) {
+    for (const LGroup& g : lgroups) {
+      if (g.kind == 2)
+        WX_HIP(hipMemcpyAsync(x_next + g.x0 * plane, x + g.x0 * plane, g.n * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
+      else if (g.kind == 1)
+        WX_HIP(hipMemcpyAsync(x_next + g.x0 * plane, frc + g.src0 * plane, g.n * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
   }
   void alloc_small() {
     if (!acts_ready) throw StateError("call wx_finalize_weights before configuring the step glue");
@@ -951,7 +1006,7 @@ class Engine : public EngineBase {
     if (y_phys || x_next) {
       const int64_t plane = (int64_t)Ho * Wo;
       hipLaunchKernelGGL(finish_kernel, dim3(2048), dim3(256), 0, cur_stream, y, plane, C_out, have_denorm ? d_mean : nullptr,
-                         have_denorm ? d_std : nullptr, y_phys, x_next, n_prog < 0 ? 0 : n_prog);
+                         have_denorm ? d_std : nullptr, y_phys, x_next, n_prog < 0 ? 0 : n_prog, d_xmap);
       WX_HIP(hipGetLastError());
     }
   }
@@ -1294,7 +1349,7 @@ class Engine : public EngineBase {
     p.dec = dec; p.ld = ld_dec; p.Hd = Hd; p.Wd = Wd;
     p.off_y = cfg.pad_activate ? cfg.pad_lat[0] : 0; p.off_x = cfg.pad_activate ? cfg.pad_lon[0] : 0;
     p.Hu = Hu; p.Wu = Wu; p.H = Ho; p.W = Wo; p.C = C_out; p.interp = cfg.interp;
-    p.y = y; p.y_phys = y_phys; p.x_next = x_next; p.n_prog = n_prog < 0 ? 0 : n_prog;
+    p.y = y; p.y_phys = y_phys; p.x_next = x_next; p.n_prog = n_prog < 0 ? 0 : n_prog; p.xmap = d_xmap;
     p.mean = have_denorm ? d_mean : nullptr; p.stdv = have_denorm ? d_std : nullptr;
     p.thr_lo = have_tracer ? d_lo : nullptr; p.thr_hi = have_tracer ? d_hi : nullptr;
     p.tracer_denorm = tracer_denorm;
@@ -1781,16 +1836,13 @@ class Engine : public EngineBase {
     const int own = b_own_rows();
     if (!bx_next || own <= 0) return;
     const int64_t plane_b = (int64_t)own * cfg.image_width;
-    if (n_static > 0)
-      WX_HIP(hipMemcpyAsync(bx_next + n_prog * plane_b, bx_own + n_prog * plane_b, n_static * plane_b * sizeof(float), hipMemcpyDeviceToDevice, cur_stream));
-    if (n_dyn > 0)
-      WX_HIP(hipMemcpyAsync(bx_next + (n_prog + n_static) * plane_b, bfrc_own, n_dyn * plane_b * sizeof(float), hipMemcpyDeviceToDevice, cur_stream));
+    copy_layout_groups(bx_own, bfrc_own, bx_next, plane_b, cur_stream);
   }
   void band_finish_post() {   // after the post block: y_phys and the prognostic channels of x_next from the corrected y
     const int own = b_own_rows();
     if (own > 0 && (by_phys || bx_next)) {
       hipLaunchKernelGGL(finish_kernel, dim3(2048), dim3(256), 0, cur_stream, by ? by : by_internal, (int64_t)own * Wo, C_out,
-                         have_denorm ? d_mean : nullptr, have_denorm ? d_std : nullptr, by_phys, bx_next, n_prog < 0 ? 0 : n_prog);
+                         have_denorm ? d_mean : nullptr, have_denorm ? d_std : nullptr, by_phys, bx_next, n_prog < 0 ? 0 : n_prog, d_xmap);
       WX_HIP(hipGetLastError());
     }
     band_x_next_copies();
@@ -1803,7 +1855,7 @@ class Engine : public EngineBase {
     p.off_y = cfg.pad_activate ? cfg.pad_lat[0] : 0; p.off_x = cfg.pad_activate ? cfg.pad_lon[0] : 0;
     p.Hu = Hu; p.Wu = Wu; p.H = Ho; p.W = Wo; p.C = C_out; p.interp = cfg.interp;
     p.y = post_mode ? (by ? by : by_internal) : by; p.y_phys = post_mode ? nullptr : by_phys; p.x_next = post_mode ? nullptr : bx_next;
-    p.n_prog = n_prog < 0 ? 0 : n_prog;
+    p.n_prog = n_prog < 0 ? 0 : n_prog; p.xmap = d_xmap;
     p.mean = have_denorm ? d_mean : nullptr; p.stdv = have_denorm ? d_std : nullptr;
     p.thr_lo = have_tracer ? d_lo : nullptr; p.thr_hi = have_tracer ? d_hi : nullptr;
     p.tracer_denorm = tracer_denorm;
@@ -1921,10 +1973,7 @@ class Engine : public EngineBase {
     finish_item(x, y, y_phys, x_next);
     if (x_next) {
       const int64_t plane = (int64_t)cfg.image_height * cfg.image_width;
-      if (n_static > 0)
-        WX_HIP(hipMemcpyAsync(x_next + n_prog * plane, x + n_prog * plane, n_static * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
-      if (n_dyn > 0)
-        WX_HIP(hipMemcpyAsync(x_next + (n_prog + n_static) * plane, frc, n_dyn * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
+      copy_layout_groups(x, frc, x_next, plane, s);
     }
     if (prof_on) drain();
   }
@@ -1986,6 +2035,9 @@ int wx_set_tracer_fixer(wx_handle h, const int32_t* inds, const float* thres, co
 }
 int wx_set_layout(wx_handle h, int n_prog, int n_static, int n_dyn) {
   return guarded([&] { WX_NEED(h); h->impl->set_layout(n_prog, n_static, n_dyn); });
+}
+int wx_set_layout_groups(wx_handle h, int n_groups, const int32_t* kind, const int32_t* x_start, const int32_t* src_start, const int32_t* count) {
+  return guarded([&] { WX_NEED(h); h->impl->set_layout_groups(n_groups, kind, x_start, src_start, count); });
 }
 int wx_forward(wx_handle h, const float* x_dev, float* y_dev, int batch, void* stream) {
   return guarded([&] { WX_NEED(h); if (!x_dev || !y_dev) throw wx::ConfigError("wx_forward: null pointer"); h->impl->forward(x_dev, y_dev, batch, (hipStream_t)stream); });

@@ -63,6 +63,7 @@ _PROTOTYPES = {
     "wx_set_denorm": ([C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int], C.c_int),
     "wx_set_tracer_fixer": ([C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int], C.c_int),
     "wx_set_layout": ([C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_int),
+    "wx_set_layout_groups": ([C.c_void_p, C.c_int] + [C.POINTER(C.c_int32)] * 4, C.c_int),
     "wx_forward": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     "wx_step": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "wx_set_comm": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int], C.c_int),
@@ -238,6 +239,15 @@ class WXEngine:
 
     def set_layout(self, n_prog: int, n_static: int, n_dyn: int) -> None:
         _check(self.lib.wx_set_layout(self._h, n_prog, n_static, n_dyn))
+
+    def set_layout_groups(self, groups) -> None:
+        """groups: iterable of (kind, x_start, src_start, count) with kind in {"prognostic", "dynamic_forcing", "static"} (or
+        0 / 1 / 2), i.e. the ChannelGroup list of credit/datasets/gen_2/channel_utils.py:140-250 for any number of sources
+        (wxengine.rollout.build_channel_layout produces it from a CREDIT config)."""
+        code = {"prognostic": 0, "dynamic_forcing": 1, "static": 2}
+        rows = [(code.get(k, k), int(x0), int(0 if s0 is None else s0), int(n)) for k, x0, s0, n in groups]
+        arr = [np.ascontiguousarray([r[i] for r in rows], dtype=np.int32) for i in range(4)]
+        _check(self.lib.wx_set_layout_groups(self._h, len(rows), *[a.ctypes.data_as(C.POINTER(C.c_int32)) for a in arr]))
 
     # ---- hot path -------------------------------------------------------------------
     @staticmethod

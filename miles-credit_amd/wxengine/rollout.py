@@ -23,6 +23,51 @@ def channel_layout(cfg, n_static: int, n_dyn: int):
     return n_prog, n_static, n_dyn
 
 
+_INPUT_FIELD_TYPES = ("prognostic", "static", "dynamic_forcing")   # canonical concat rank (channel_utils.py:88-93)
+
+
+def build_channel_layout(conf):
+    """Mirror of credit/datasets/gen_2/channel_utils.py:161-250 for any number of data sources.
+
+    Returns (groups, n_pred): groups = [(field_type, x_start, src_start or None, count), ...] in input-channel order, one per
+    (source, field_type) run -- with several sources a field type's channels are contiguous only within a source -- ready for
+    WXEngine.set_layout_groups; n_pred = number of prognostic channels.  Source blocks of y run prognostic-then-diagnostic, the
+    forcing tensor holds the dynamic-forcing channels source-major.  Raises ValueError like the reference (history_len != 1,
+    3-D variables without a level count)."""
+    data = conf["data"]
+    groups, x_cur, pred_cur, dyn_cur = [], 0, 0, 0
+    for name, src in data["source"].items():
+        src = src or {}
+        variables = src.get("variables") or {}
+        levels = src.get("levels")
+        n_levels = len(levels) if levels else int((conf.get("model") or {}).get("levels") or 0)
+        if src.get("history_len", data.get("history_len", 1)) != 1:
+            raise ValueError(f"build_channel_layout: source '{name}' has history_len != 1; the flat rollout cannot shift a history window")
+
+        def width(ft):
+            grp = variables.get(ft) or {}
+            n3, n2 = len(grp.get("vars_3D") or []), len(grp.get("vars_2D") or [])
+            if n3 and not n_levels:
+                raise ValueError(f"build_channel_layout: source '{name}' defines 3D variables but no level count is set")
+            return n3 * n_levels + n2
+        prog_src = pred_cur
+        pred_cur += width("prognostic") + width("diagnostic")
+        for ft in _INPUT_FIELD_TYPES:
+            w = width(ft)
+            if w == 0:
+                continue
+            if ft == "prognostic":
+                s0 = prog_src
+            elif ft == "dynamic_forcing":
+                s0 = dyn_cur
+                dyn_cur += w
+            else:
+                s0 = None
+            groups.append((ft, x_cur, s0, w))
+            x_cur += w
+    return groups, sum(g[3] for g in groups if g[0] == "prognostic")
+
+
 def rollout(engine: WXEngine, x0: torch.Tensor, forcings: Sequence[Optional[torch.Tensor]],
             keep_phys: bool = True, keep_y: bool = False):
     """Run len(forcings) forecast steps. forcings[t] feeds the input of step t+2 (None on the last step).

@@ -450,6 +450,19 @@ def update_x(x_prev: Tensor, x_frc: Tensor, y: Tensor, n_prog: int, n_static: in
     return x
 
 
+def update_x_groups(x_prev: Tensor, x_frc: Tensor, y: Tensor, groups) -> Tensor:
+    """Next-input assembly for ANY number of data sources (credit/datasets/gen_2/channel_utils.py:253-291 with the ChannelGroup
+    list of :140-250).  groups: (field_type | code, x_start, src_start or None / -1, count); prognostic (0) <- y, dynamic_forcing
+    (1) <- x_frc, anything else is carried forward."""
+    x = x_prev.clone()
+    for kind, x0, s0, n in groups:
+        if kind in ("prognostic", 0):
+            x[:, x0:x0 + n] = y[:, s0:s0 + n]
+        elif kind in ("dynamic_forcing", 1):
+            x[:, x0:x0 + n] = x_frc[:, s0:s0 + n]
+    return x
+
+
 def rollout(cfg, sd, x0, forcings, n_static: int, mean=None, std=None, tracer=None, dtype=torch.float32):
     """predict()'s hot loop (credit/applications/rollout_to_netcdf.py:274-310) on synthetic forcing.
 

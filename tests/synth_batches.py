@@ -69,3 +69,18 @@ ODD_CONFIGS = {
     "w16": dict(h3=6, w3=6, lw=2, gw=(16, 8, 4, 2), depth=(1, 1, 2, 1)),   # 256-token long windows
     "w5p": dict(h3=5, w3=5, lw=5, gw=(8, 4, 2, 1), pad=((13, 11), (9, 7))),  # asymmetric pads, odd image
 }
+
+
+def two_source_conf():
+    """A CREDIT config whose model input interleaves two data sources (channel_utils.py:161-250: a field type's channels are
+    contiguous only within a source).  x: 14 channels, y: 11, forcing tensor: 3."""
+    def grp(v3=(), v2=()):
+        return {"vars_3D": list(v3), "vars_2D": list(v2)}
+    return {"model": {"levels": 3},
+            "data": {"history_len": 1, "source": {
+                "era5": {"levels": [500, 700, 850], "variables": {
+                    "prognostic": grp(("U", "T"), ("SP",)), "static": grp(v2=("LSM",)),
+                    "dynamic_forcing": grp(v2=("tsi",)), "diagnostic": grp(v2=("precip",))}},
+                "aux": {"levels": None, "variables": {
+                    "prognostic": grp(v2=("sst", "ice")), "static": grp(v2=("depth",)),
+                    "dynamic_forcing": grp(v2=("tide", "wind")), "diagnostic": grp(v2=("flux",))}}}}}

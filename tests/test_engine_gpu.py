@@ -87,6 +87,43 @@ def test_c1_vs_oracle_and_reference_golden(name, prec):
     check(y[0, :, 0, ::s, ::s].numpy(), g["y"], prec)
 
 
+def test_step_with_two_interleaved_sources():
+    """wx_set_layout_groups: the next input is assembled per (source, field type) group -- prognostic channels of two sources
+    come from non-adjacent blocks of y (each source's diagnostics sit in between), forcing channels from one forcing tensor,
+    statics are carried.  Copies are exact; the prognostic channels equal the step's own y."""
+    from synth_batches import two_source_conf
+    from wxengine.config import WXConfig
+    from wxengine.latband import VirtualBands
+    from wxengine.rollout import build_channel_layout
+    mc = dict(frames=1, channels=2, surface_channels=3, input_only_channels=5, output_only_channels=2, levels=3,
+              image_height=37, image_width=72, patch_width=1, patch_height=1, cross_embed_kernel_sizes=[[4, 8, 16, 32], [2, 4], [2, 4], [2, 4]],
+              cross_embed_strides=[2, 2, 2, 2], dim=[32, 64, 128, 256], depth=[1, 1, 1, 1], global_window_size=[4, 2, 2, 1],
+              local_window_size=3, interp=True, use_spectral_norm=True,
+              padding_conf=dict(activate=True, mode="earth", pad_lat=[6, 6], pad_lon=[12, 12]))
+    cfg = WXConfig.from_model_conf(mc)
+    groups, n_pred = build_channel_layout(two_source_conf())
+    assert cfg.base_input_channels == 14 and cfg.base_output_channels == 11 and n_pred == 9
+    sd = synth_state_dict(cfg)
+    eng = WXEngine(cfg, "fp32", 0)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    eng.set_layout_groups(groups)
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    frc = torch.from_numpy(synth_forcing(cfg, 3, 1)).cuda()
+    y, _, xn = eng.step(x, frc, want_phys=False)
+    want = O.update_x_groups(x.cpu(), frc.cpu(), y.cpu(), groups)
+    assert torch.equal(xn.cpu(), want)
+    # the same layout on three lat-band ranks
+    vb = VirtualBands(cfg, sd, 3, "fp32", setup=lambda e: e.set_layout_groups(groups))
+    ys, _, xs = vb.step(x, frc, want_next=True)
+    assert torch.equal(xs.cpu(), O.update_x_groups(x.cpu(), frc.cpu(), ys.cpu(), groups))
+    assert (ys - y).abs().max().item() <= 1e-5 * y.abs().max().item()
+    with pytest.raises(WXEngineError, match="cover every input channel"):
+        eng.set_layout_groups(groups[:-1])
+    with pytest.raises(WXEngineError, match="two groups"):
+        eng.set_layout_groups(groups + [("static", 0, None, 1)])
+
+
 @pytest.mark.parametrize("name", ["T1", "C1"])
 def test_fused_feed_forward_kernel_on_small_maps(name, monkeypatch):
     """By default the fused feed-forward kernel (wx_ff.h) only runs where it yields >= 256 workgroups (0.25-degree stages 0/1);

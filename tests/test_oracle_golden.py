@@ -93,6 +93,25 @@ def test_rollout_glue_matches_reference_golden():
         assert float(q.min()) >= tracer["thres"][0] - 1e-7
 
 
+def test_two_source_channel_layout_matches_reference_golden():
+    """build_channel_layout / update_x with interleaving sources (channel_utils.py:161-291): the host mirror reproduces the
+    reference's groups, the oracle's group-wise update reproduces its x_new bit for bit."""
+    from synth_batches import two_source_conf
+    from wxengine.rollout import build_channel_layout
+    g = _load("channel_layout_two_sources.npz")
+    groups, n_pred = build_channel_layout(two_source_conf())
+    code = {"prognostic": 0, "dynamic_forcing": 1, "static": 2}
+    mine = [(code[k], x0, -1 if s0 is None else s0, n) for k, x0, s0, n in groups]
+    assert mine == [tuple(int(v) for v in row) for row in g["groups"]]
+    assert n_pred == int(g["n_pred"]) == 9
+    xn = O.update_x_groups(torch.from_numpy(g["x"]), torch.from_numpy(g["frc"]), torch.from_numpy(g["y"]), groups)
+    np.testing.assert_array_equal(xn.numpy(), g["x_new"])
+    with pytest.raises(ValueError, match="history_len"):
+        bad = two_source_conf()
+        bad["data"]["source"]["aux"]["history_len"] = 2
+        build_channel_layout(bad)
+
+
 def test_tracer_fix_denorm_roundtrip():
     """denorm: True branch (gen1.py:147-161): clamp happens in physical units."""
     torch.manual_seed(1)

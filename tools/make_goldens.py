@@ -91,6 +91,28 @@ def model_golden(name, stride, capture_layers):
           f"y sample {out['y'].shape}")
 
 
+def layout_golden():
+    """build_channel_layout + update_x (credit/datasets/gen_2/channel_utils.py:161-291) on a TWO-source config: the prognostic /
+    static / forcing channels of the sources interleave in x, and y carries each source's diagnostics after its prognostics."""
+    from credit.datasets.gen_2.channel_utils import build_channel_layout, update_x
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth_batches import two_source_conf
+    conf = two_source_conf()
+    groups, n_pred = build_channel_layout(conf)
+    code = {"prognostic": 0, "dynamic_forcing": 1, "static": 2}
+    rows = [(code[g.field_type], g.x_slice.start, -1 if g.src_slice is None else g.src_slice.start, g.x_slice.stop - g.x_slice.start)
+            for g in groups.values()]
+    c_in = max(g.x_slice.stop for g in groups.values())
+    g = np.random.Generator(np.random.Philox(key=[11, 3]))
+    x = torch.from_numpy(g.standard_normal((1, c_in, 1, 5, 6), dtype=np.float32))
+    frc = torch.from_numpy(g.standard_normal((1, 3, 1, 5, 6), dtype=np.float32))
+    y = torch.from_numpy(g.standard_normal((1, 11, 1, 5, 6), dtype=np.float32))
+    xn = update_x(x, frc, y, groups)
+    np.savez_compressed(os.path.join(GOLD, "channel_layout_two_sources.npz"), groups=np.array(rows, dtype=np.int64), n_pred=np.int64(n_pred),
+                        keys=np.array(list(groups.keys())), x=x.numpy(), frc=frc.numpy(), y=y.numpy(), x_new=xn.numpy())
+    print(f"[golden] layout: {len(rows)} groups, n_pred {n_pred}, c_in {c_in}: {rows}")
+
+
 def pad_golden():
     """credit/boundary_padding.py earth mode, incl. asymmetric pads (tests/test_bondary_padding.py:37-44 shapes)."""
     from credit.boundary_padding import TensorPadding
@@ -421,7 +443,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
+    ap.add_argument("--only", default="pad,T0,T1,glue,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -430,6 +452,8 @@ def main():
             pad_golden()
         elif item == "glue":
             glue_golden()
+        elif item == "layout":
+            layout_golden()
         elif item == "fixers":
             fixers_golden()
         elif item == "sigma":
