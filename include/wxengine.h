@@ -123,6 +123,18 @@ int wx_set_layout_groups(wx_handle h, int n_groups, const int32_t* kind, const i
 int wx_forward(wx_handle h, const float* x_dev, float* y_dev, int batch, void* stream);
 int wx_step(wx_handle h, const float* x_dev, const float* frc_dev, float* y_dev, float* y_phys_dev,
             float* x_next_dev, void* stream);
+/* wx_rollout <-> the whole predict() loop (rollout_to_netcdf.py:262-316), B = 1: n_steps iterations of wx_step with the state
+ *     kept in engine-owned buffers, no host code between steps.
+ *     x0_dev         float32 [1, C_in, 1, H, W], not modified
+ *     frc_dev        HOST array of n_steps device pointers, frc_dev[t] = dynamic forcing [1, n_dyn, 1, H, W] entering the input of
+ *                    step t+1 (what update_x receives after step t); NULL entries / NULL array allowed where no next input is built
+ *     y_phys_dev     HOST array of n_steps device pointers (or NULL): de-normalised output of step t goes to y_phys_dev[t];
+ *                    NULL entries skip that step's output.  Pointers may repeat (a ring the host drains asynchronously).
+ *     x_final_dev    optional: receives the model input that would feed step n_steps (needs frc_dev[n_steps-1])
+ *     The results are bit-identical to n_steps calls of wx_step.  On launch-bound (small) grids every step is replayed from a
+ *     captured hipGraph (one per ping-pong parity and y_phys destination; WX_GRAPH=0/1 overrides the automatic choice). */
+int wx_rollout(wx_handle h, const float* x0_dev, const float* const* frc_dev, int n_steps, float* const* y_phys_dev,
+               float* x_final_dev, void* stream);
 
 /* ---- conservation fixers (PostBlock) -------------------------------------------
  * A wx_post is the device-side counterpart of credit/postblock/gen1.py::PostBlock for pressure-level grids: an ordered

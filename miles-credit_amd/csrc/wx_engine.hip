@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "wx_attn.h"
@@ -24,6 +25,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: the library is bound with dlopen when a communicator is requested
 #include "wx_gemm.h"
+#include "wx_gemm_stream.h"
 #include "wx_post.h"
 #include "wx_pre.h"
 
@@ -49,6 +51,7 @@ struct ConvW {          // one repacked GEMM operand in the weight arena
   int64_t bias = -1;    // float-arena offsets (-1 = absent)
   int64_t colsum = -1;
   int cin_true = 0;     // unpadded channels (flop accounting)
+  int64_t wt_kb = -1;   // bf16 engine, 1x1 layers with n % 256 == 0: second copy, k-blocked [cin/32][n][32] (wx_gemm_stream.h)
 };
 struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1, bias_tb = -1; int wsz = 0, kind = 0; };
 struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1, pack_pp = -1; const AttnL* next = nullptr; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset; pack_pre: the same preceded by the attention's Wout blocks
@@ -111,6 +114,7 @@ class EngineBase {
   virtual void finalize() = 0;
   virtual void forward(const float* x, float* y, int batch, hipStream_t s) = 0;
   virtual void step(const float* x, const float* frc, float* y, float* y_phys, float* x_next, hipStream_t s) = 0;
+  virtual void rollout(const float* x0, const float* const* frc, int n_steps, float* const* y_phys, float* x_final, hipStream_t s) = 0;
   virtual void set_denorm(const float* mean, const float* stdv, int n) = 0;
   virtual void set_tracer(const int32_t* inds, const float* thres, const float* thres_max, int n, int denorm) = 0;
   virtual void set_layout(int n_prog, int n_static, int n_dyn) = 0;
@@ -330,9 +334,16 @@ class Engine : public EngineBase {
     HostTensor& t = it->second;
     int64_t n = 1;
     for (int i = 0; i < ndim; ++i) n *= shape[i];
-    if (n != t.numel())
-      throw ShapeError(std::string("tensor '") + key + "' has " + std::to_string(n) + " elements, expected " +
-                       std::to_string(t.numel()));
+    // torch semantics: the shapes must agree.  Only singleton dimensions may differ ((1, C, 1, 1) vs (C,)): the same
+    // element count in another layout ([128, 256, 2, 2] for a [256, 128, 2, 2] ConvTranspose weight) would load scrambled.
+    std::vector<int64_t> got, want;
+    for (int i = 0; i < ndim; ++i) if (shape[i] != 1) got.push_back(shape[i]);
+    for (int64_t d : t.shape) if (d != 1) want.push_back(d);
+    if (n != t.numel() || got != want) {
+      auto fmt = [](const int64_t* d, size_t k) { std::string r = "("; for (size_t i = 0; i < k; ++i) r += (i ? ", " : "") + std::to_string(d[i]); return r + ")"; };
+      throw ShapeError(std::string("size mismatch for ") + key + ": checkpoint " + fmt(shape, (size_t)ndim) + " vs model " +
+                       fmt(t.shape.data(), t.shape.size()));
+    }
     t.data.assign(data, data + n);
     t.loaded = true;
     finalized = false;
@@ -413,6 +424,19 @@ class Engine : public EngineBase {
     wt_host.resize(off + (int64_t)n * k);
     for (int64_t i = 0; i < (int64_t)n * k; ++i) wt_host[off + i] = Elem<T>::from_f((float)rows[i]);
     return off;
+  }
+  // k-blocked copy of a 1x1 layer's ROUNDED arena weights for the persistent GEMM (same values, other order): a K = 32 stage of
+  // 256 output channels is then 16 contiguous KB (full cache lines per LDS-DMA piece instead of half-used ones)
+  void pack_kblocked(ConvW& cw) {
+    if constexpr (sizeof(T) != 2) return;
+    if (!use_stream || cw.kh != 1 || cw.kw != 1 || cw.n % 256 != 0 || cw.cin % 32 != 0 || cw.cin < 512) return;
+    while (wt_host.size() % 8) wt_host.push_back(Elem<T>::from_f(0.f));
+    const int64_t off = (int64_t)wt_host.size();
+    wt_host.resize(off + (int64_t)cw.n * cw.cin);
+    for (int n = 0; n < cw.n; ++n)
+      for (int k = 0; k < cw.cin; ++k)
+        wt_host[off + ((int64_t)(k / 32) * cw.n + n) * 32 + k % 32] = wt_host[cw.wt + (int64_t)n * cw.cin + k];
+    cw.wt_kb = off;
   }
   // Conv2d weight W[n][c][kh][kw] (rows [r0, r1)) -> [n][kh][kw][cpad]; optional LayerNorm fold (g, b per input channel)
   // row_src (optional): output row o takes reference row row_src[o] (-1 = all-zero row) instead of r0 + o
@@ -585,8 +609,10 @@ class Engine : public EngineBase {
     if (wsz == 1) {
       // one token per window: softmax == 1, attention output == v (crossformer.py:286-295) -> only the v rows
       a.vonly = make_conv(p + ".to_qkv", 2 * c, 3 * c, c, c, 1, 1, false, g.data.data(), b.data.data());
+      pack_kblocked(a.vonly);
     } else {
       a.qkv = make_conv(p + ".to_qkv", 0, 3 * c, c, c, 1, 1, false, g.data.data(), b.data.data());
+      pack_kblocked(a.qkv);
       a.bias_tab = make_bias_table(p + ".dpb", wsz, c / 4, &a.bias_tb);
     }
     a.out = make_conv(p + ".to_out", 0, c, c, c, 1, 1, true, nullptr, nullptr);
@@ -629,6 +655,7 @@ class Engine : public EngineBase {
     FFL f;
     const HostTensor &g = need(p + ".layers.0.g"), &b = need(p + ".layers.0.b");
     f.w1 = make_conv(p + ".layers.1", 0, 4 * c, c, c, 1, 1, true, g.data.data(), b.data.data());
+    pack_kblocked(f.w1);
     f.w2 = make_conv(p + ".layers.4", 0, c, 4 * c, 4 * c, 1, 1, true, nullptr, nullptr);
     if constexpr (sizeof(T) == 2) {
       if (ff_fused_supported(c, 4 * c)) {
@@ -759,6 +786,9 @@ class Engine : public EngineBase {
   float2* rowstat = nullptr;
   char* zero_page = nullptr;
   bool use_dma = true;
+  bool use_stream = !(getenv("WX_NO_STREAM") && getenv("WX_NO_STREAM")[0] == '1');   // persistent large-tile GEMM (wx_gemm_stream.h) for the LN-folded 1x1 layers of the deep stages
+  int stream_min_rows = 4096;
+  char* stream_sink = nullptr;
   int dbg_flags = 0;
   int gemm_cfg = 0;
   bool fuse_ln = true;
@@ -813,7 +843,9 @@ class Engine : public EngineBase {
     zero_page = (char*)dalloc(256);
     WX_HIP(hipMemset(zero_page, 0, 256));
     if (const char* e = getenv("WX_NO_DMA")) use_dma = !(e[0] == '1');
+    stream_sink = (char*)dalloc(4096);
     if (const char* e = getenv("WX_DBG")) dbg_flags = atoi(e);
+    if (const char* e = getenv("WX_STREAM_MIN_ROWS")) stream_min_rows = atoi(e);
     if (const char* e = getenv("WX_GEMM_CFG")) gemm_cfg = atoi(e);
     if (const char* e = getenv("WX_NO_LNFUSE")) fuse_ln = !(e[0] == '1');
     if (const char* e = getenv("WX_NO_FFFUSE")) fuse_ff = !(e[0] == '1');
@@ -1068,6 +1100,28 @@ class Engine : public EngineBase {
     if (want_gn && fuse_ln && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr)) {
       p.gn_out = gnpart;
       made_stats = true;
+    }
+    if constexpr (sizeof(T) == 2) {
+      // LayerNorm-folded 1x1 layers with many rows and K >= 512 (to_qkv, FeedForward layer 1 of stages 2-3): the persistent
+      // 128 x 256-tile kernel; measured per shape against the 128 x 128 kernel in tools/gemm_stream_probe
+      const bool one = w.kh == 1 && w.kw == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && in_h == out_h && in_w == out_w;
+      if (use_stream && use_dma && w.wt_kb >= 0 && one && rs && !res && out_mode == 0 && !want_stats && !want_gn && !dbg_flags &&
+          (int64_t)out_h * out_w >= stream_min_rows && stream_gemm_ok((int64_t)out_h * out_w, w.n, w.cin)) {
+        StreamGemmParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.a = reinterpret_cast<const bf16_t*>(in); q.lda = in_ld; q.w = reinterpret_cast<const bf16_t*>(wt_dev + w.wt_kb);
+        q.M = out_h * out_w; q.N = w.n; q.K = w.cin;
+        q.bias = p.bias; q.colsum = p.colsum; q.rowstat = rs; q.stat_tiles = p.stat_tiles; q.stat_inv_c = p.stat_inv_c;
+        q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
+        // tile per epilogue (tools/gemm_stream_probe, MI355X): with GELU the 160-row tile on a 2-stage ring (256 VGPRs, 2 x 54 KB of
+        // LDS) wins -- 54.6 / 46.8 us on the stage-2 / stage-3 FeedForward shapes against 56.4 / 58.5 -- without it the 128-row tile
+        // on 3 stages does (39.8 vs 46.4 us on to_qkv)
+        timed(cls, flops, bytes, [&] {
+          if (act == 1) launch_gemm_stream<5, 2>(q, 2, cur_stream);
+          else launch_gemm_stream<4, 3>(q, 1, cur_stream);
+        });
+        return false;
+      }
     }
     timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream, gemm_cfg); });
     return made_stats;
@@ -1977,6 +2031,110 @@ class Engine : public EngineBase {
     }
     if (prof_on) drain();
   }
+
+  // ------------------------------------------------------------------ wx_rollout
+  // The predict() loop of credit/applications/rollout_to_netcdf.py:262-316 inside the library: n steps of
+  // (forward, fixers, de-normalise, update_x) with the state ping-ponging between two engine-owned buffers -- no host code
+  // between steps.  On small grids (1-degree model: ~170 launches of ~10 us per step) a step is launch-bound, so it is captured
+  // once as a hipGraph per (ping-pong parity, y_phys destination, need-next) and replayed; big grids run eagerly (at 0.25
+  // degree the wall time already equals the sum of the kernel times).  Both ways issue exactly the launches of wx_step.
+  float* roll_x[2] = {nullptr, nullptr};
+  float* roll_frc = nullptr;
+  hipStream_t roll_stream = nullptr;
+  hipEvent_t roll_ev_in = nullptr, roll_ev_out = nullptr;
+  std::map<std::tuple<int, const void*, int>, hipGraphExec_t> roll_graphs;
+  bool roll_warm = false;
+  int graph_mode = getenv("WX_GRAPH") ? atoi(getenv("WX_GRAPH")) : -1;   // -1 automatic, 0 never, 1 always
+  bool want_graph() const {
+    if (graph_mode == 0 || prof_on || dbg_on || band_on || post) return false;
+    if (graph_mode == 1) return true;
+    return (int64_t)Hp * Wp <= 320 * 640;   // launch-bound regime
+  }
+  void step_body(const float* x, const float* frc, float* y_phys, float* x_next, hipStream_t s) {
+    cur_stream = s;
+    core(x);
+    finish_item(x, nullptr, y_phys, x_next);
+    if (x_next) copy_layout_groups(x, frc, x_next, (int64_t)cfg.image_height * cfg.image_width, s);
+  }
+  void rollout(const float* x0, const float* const* frc, int n, float* const* y_phys, float* x_final, hipStream_t s) override {
+    check_ready();
+    if (band_on) throw StateError("this engine is in lat-band mode: drive it with wx_band_begin / wx_band_resume");
+    if (cfg.frames != 1 || cfg.output_frames != 1) throw ConfigError("wx_rollout needs frames == output_frames == 1");
+    if (n < 1) throw ConfigError("wx_rollout: n_steps must be >= 1");
+    if (!x0) throw ConfigError("wx_rollout: x0 is NULL");
+    if (n_prog < 0) throw StateError("wx_rollout needs wx_set_layout first");
+    if (Ho != cfg.image_height || Wo != cfg.image_width) throw ConfigError("wx_rollout needs output size == input size");
+    if (!have_denorm && y_phys) {
+      for (int t = 0; t < n; ++t) if (y_phys[t]) throw StateError("wx_rollout with y_phys needs wx_set_denorm first");
+    }
+    const int64_t plane = (int64_t)cfg.image_height * cfg.image_width;
+    const size_t x_bytes = (size_t)C_in * plane * sizeof(float);
+    if (n_dyn > 0)
+      for (int t = 0; t < n; ++t)
+        if ((t < n - 1 || x_final) && (!frc || !frc[t])) throw ConfigError("wx_rollout: forcing pointer is NULL but the layout has dynamic forcing channels");
+    if (!roll_x[0]) {
+      roll_x[0] = (float*)dalloc(x_bytes);
+      roll_x[1] = (float*)dalloc(x_bytes);
+      if (n_dyn > 0) roll_frc = (float*)dalloc((size_t)n_dyn * plane * sizeof(float));
+    }
+    const bool graph = want_graph() && roll_warm;
+    if (!graph) {
+      const float* x = x0;
+      for (int t = 0; t < n; ++t) {
+        const bool next = t < n - 1 || x_final;
+        float* xn = next ? roll_x[t & 1] : nullptr;
+        if (xn == x) throw ConfigError("wx_rollout: x0 aliases an internal state buffer");
+        step_body(x, frc ? frc[t] : nullptr, y_phys ? y_phys[t] : nullptr, xn, s);
+        if (xn) x = xn;
+      }
+      if (x_final) WX_HIP(hipMemcpyAsync(x_final, roll_x[(n - 1) & 1], x_bytes, hipMemcpyDeviceToDevice, s));
+      roll_warm = true;   // every kernel's launch attributes are set now: later calls may capture
+      if (prof_on) drain();
+      return;
+    }
+    // graph path: the caller's stream may be the legacy default stream (not capturable) -> own stream, fenced by events
+    if (!roll_stream) {
+      WX_HIP(hipStreamCreateWithFlags(&roll_stream, hipStreamNonBlocking));
+      WX_HIP(hipEventCreateWithFlags(&roll_ev_in, hipEventDisableTiming));
+      WX_HIP(hipEventCreateWithFlags(&roll_ev_out, hipEventDisableTiming));
+    }
+    WX_HIP(hipEventRecord(roll_ev_in, s));
+    WX_HIP(hipStreamWaitEvent(roll_stream, roll_ev_in, 0));
+    WX_HIP(hipMemcpyAsync(roll_x[1], x0, x_bytes, hipMemcpyDeviceToDevice, roll_stream));   // step t reads roll_x[(t + 1) & 1]
+    for (int t = 0; t < n; ++t) {
+      const bool next = t < n - 1 || x_final;
+      float* yp = y_phys ? y_phys[t] : nullptr;
+      if (next && n_dyn > 0)
+        WX_HIP(hipMemcpyAsync(roll_frc, frc[t], (size_t)n_dyn * plane * sizeof(float), hipMemcpyDeviceToDevice, roll_stream));
+      const auto key = std::make_tuple(t & 1, (const void*)yp, next ? 1 : 0);
+      auto it = roll_graphs.find(key);
+      if (it == roll_graphs.end()) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        WX_HIP(hipStreamBeginCapture(roll_stream, hipStreamCaptureModeRelaxed));
+        try {
+          step_body(roll_x[(t + 1) & 1], roll_frc, yp, next ? roll_x[t & 1] : nullptr, roll_stream);
+        } catch (...) {
+          (void)hipStreamEndCapture(roll_stream, &g);
+          if (g) (void)hipGraphDestroy(g);
+          throw;
+        }
+        WX_HIP(hipStreamEndCapture(roll_stream, &g));
+        WX_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        WX_HIP(hipGraphDestroy(g));
+        if (roll_graphs.size() >= 64) {   // callers that hand out a fresh y_phys pointer every step: do not grow without bound
+          for (auto& kv : roll_graphs) (void)hipGraphExecDestroy(kv.second);
+          roll_graphs.clear();
+        }
+        it = roll_graphs.emplace(key, ge).first;
+      }
+      WX_HIP(hipGraphLaunch(it->second, roll_stream));
+    }
+    if (x_final) WX_HIP(hipMemcpyAsync(x_final, roll_x[(n - 1) & 1], x_bytes, hipMemcpyDeviceToDevice, roll_stream));
+    WX_HIP(hipEventRecord(roll_ev_out, roll_stream));
+    WX_HIP(hipStreamWaitEvent(s, roll_ev_out, 0));
+    cur_stream = s;
+  }
 };
 
 }  // namespace wx
@@ -2044,6 +2202,10 @@ int wx_forward(wx_handle h, const float* x_dev, float* y_dev, int batch, void* s
 }
 int wx_step(wx_handle h, const float* x_dev, const float* frc_dev, float* y_dev, float* y_phys_dev, float* x_next_dev, void* stream) {
   return guarded([&] { WX_NEED(h); if (!x_dev) throw wx::ConfigError("wx_step: null input"); h->impl->step(x_dev, frc_dev, y_dev, y_phys_dev, x_next_dev, (hipStream_t)stream); });
+}
+int wx_rollout(wx_handle h, const float* x0_dev, const float* const* frc_dev, int n_steps, float* const* y_phys_dev, float* x_final_dev,
+               void* stream) {
+  return guarded([&] { WX_NEED(h); h->impl->rollout(x0_dev, frc_dev, n_steps, y_phys_dev, x_final_dev, (hipStream_t)stream); });
 }
 int wx_set_comm(wx_handle h, void* nccl_comm, int rank, int nranks) {
   return guarded([&] {
@@ -2265,6 +2427,11 @@ int wx_attach_postblock(wx_handle h, wx_post_handle p) {
 }
 
 const char* wx_last_error(void) { return wx::g_last_error.c_str(); }
-const char* wx_version(void) { return "wxengine 0.1 (gfx950)"; }
+#ifndef WX_SOURCE_HASH
+#define WX_SOURCE_HASH "unhashed"
+#endif
+// "wxsrc:<hash of csrc/*.h, wx_engine.hip, include/wxengine.h>" is set by miles-credit_amd/build.py; the Python loader compares
+// it with the sources next to the library and refuses a stale build
+const char* wx_version(void) { return "wxengine 0.2 (gfx950) wxsrc:" WX_SOURCE_HASH; }
 
 }  // extern "C"

@@ -66,6 +66,7 @@ _PROTOTYPES = {
     "wx_set_layout_groups": ([C.c_void_p, C.c_int] + [C.POINTER(C.c_int32)] * 4, C.c_int),
     "wx_forward": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     "wx_step": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "wx_rollout": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p], C.c_int),
     "wx_set_comm": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int], C.c_int),
     "wx_band_enable": ([C.c_void_p, C.c_int, C.c_int], C.c_int),
     "wx_band_info": ([C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
@@ -134,8 +135,26 @@ def load_library():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res
+    _check_not_stale(lib)
     _lib = lib
     return lib
+
+
+def _check_not_stale(lib):
+    """The .so is git-ignored and ships prebuilt: make sure it was built from the sources lying next to it (build.py embeds
+    their hash in wx_version()).  WX_ALLOW_STALE=1 downgrades the error for bisecting with an old library."""
+    build_py = os.path.join(os.path.dirname(_HERE), "build.py")
+    if not os.path.isfile(build_py) or not os.path.isdir(os.path.join(os.path.dirname(_HERE), "csrc")):
+        return   # installed without sources: nothing to compare with
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_wx_build", build_py)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = mod.source_hash()
+    have = lib.wx_version().decode().rsplit("wxsrc:", 1)[-1]
+    if have != want and os.environ.get("WX_ALLOW_STALE") != "1":
+        raise WXEngineError(f"{LIB_PATH} was built from other sources (library wxsrc:{have}, sources wxsrc:{want}): "
+                            "rebuild with `python miles-credit_amd/build.py`")
 
 
 def _check(status: int):
@@ -239,6 +258,7 @@ class WXEngine:
 
     def set_layout(self, n_prog: int, n_static: int, n_dyn: int) -> None:
         _check(self.lib.wx_set_layout(self._h, n_prog, n_static, n_dyn))
+        self._n_dyn = int(n_dyn)
 
     def set_layout_groups(self, groups) -> None:
         """groups: iterable of (kind, x_start, src_start, count) with kind in {"prognostic", "dynamic_forcing", "static"} (or
@@ -248,6 +268,7 @@ class WXEngine:
         rows = [(code.get(k, k), int(x0), int(0 if s0 is None else s0), int(n)) for k, x0, s0, n in groups]
         arr = [np.ascontiguousarray([r[i] for r in rows], dtype=np.int32) for i in range(4)]
         _check(self.lib.wx_set_layout_groups(self._h, len(rows), *[a.ctypes.data_as(C.POINTER(C.c_int32)) for a in arr]))
+        self._n_dyn = sum(r[3] for r in rows if r[0] == 1)
 
     # ---- hot path -------------------------------------------------------------------
     @staticmethod
@@ -276,6 +297,30 @@ class WXEngine:
         _check(self.lib.wx_forward(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), b, self._stream()))
         return out
 
+    def _chk_shape(self, t, name, tail):
+        """`t` must hold exactly the trailing dims `tail` after dropping singleton dims (B = 1, T = 1): raw pointers go to the
+        library next, so a short forcing tensor or a wrong grid would read / write out of bounds there."""
+        if t is None:
+            return
+        self._chk_in(t, name)
+        got = [d for d in t.shape if d != 1]
+        want = [d for d in tail if d != 1]
+        if got != want:
+            raise WXEngineError(f"{name} has shape {tuple(t.shape)}, expected [1, {', '.join(str(d) for d in tail)}] (singleton dims optional)")
+
+    def _chk_step_io(self, x, frc, y, yp, xn):
+        cfg = self.cfg
+        oh, ow = cfg.out_hw
+        self._chk_shape(x, "x", (cfg.base_input_channels, cfg.image_height, cfg.image_width))
+        self._chk_shape(y, "y_out", (cfg.base_output_channels, oh, ow))
+        self._chk_shape(yp, "phys_out", (cfg.base_output_channels, oh, ow))
+        self._chk_shape(xn, "next_out", (cfg.base_input_channels, cfg.image_height, cfg.image_width))
+        if frc is not None:
+            n_dyn = getattr(self, "_n_dyn", None)
+            if n_dyn is None:
+                raise WXEngineError("frc given but no channel layout is set (set_layout / set_layout_groups)")
+            self._chk_shape(frc, "frc", (n_dyn, cfg.image_height, cfg.image_width))
+
     def step(self, x, frc=None, want_y=True, want_phys=True, want_next=True, y_out=None, phys_out=None, next_out=None):
         """One rollout iteration. Returns (y, y_phys, x_next); entries are None when not requested.
         Pre-allocated outputs may be passed (y_out / phys_out / next_out) to keep the loop allocation-free."""
@@ -288,12 +333,31 @@ class WXEngine:
         yp = phys_out if phys_out is not None else (
             torch.empty((1, cfg.base_output_channels, oh, ow), dtype=torch.float32, device=x.device) if want_phys else None)
         xn = next_out if next_out is not None else (torch.empty_like(x) if want_next else None)
-        for t, name in ((y, "y_out"), (yp, "phys_out"), (xn, "next_out"), (frc, "frc")):
-            if t is not None:
-                self._chk_in(t, name)
+        self._chk_step_io(x, frc, y, yp, xn)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         _check(self.lib.wx_step(self._h, p(x), p(frc), p(y), p(yp), p(xn), self._stream()))
         return y, yp, xn
+
+    def rollout(self, x0, forcings, phys_out=None, x_final=None):
+        """wx_rollout: len(forcings) forecast steps inside the library (the predict() loop of rollout_to_netcdf.py:262-316).
+        forcings[t] enters the input of step t+1 (None entries allowed where no next input is built); phys_out: list of
+        len(forcings) tensors / Nones receiving each step's de-normalised output (entries may repeat: a ring); x_final: optional
+        tensor receiving the input of the step after the last one.  Bit-identical to calling `step` in a loop."""
+        n = len(forcings)
+        if n < 1:
+            raise WXEngineError("rollout needs at least one step")
+        if phys_out is None:
+            phys_out = [None] * n
+        if len(phys_out) != n:
+            raise WXEngineError("phys_out must have one entry per step")
+        for t in range(n):
+            self._chk_step_io(x0, forcings[t], None, phys_out[t], x_final if t == n - 1 else None)
+        vp = C.c_void_p * n
+        fa = vp(*[None if f is None else f.data_ptr() for f in forcings])
+        ya = vp(*[None if y is None else y.data_ptr() for y in phys_out])
+        _check(self.lib.wx_rollout(self._h, C.c_void_p(x0.data_ptr()), fa, n, ya,
+                                   None if x_final is None else C.c_void_p(x_final.data_ptr()), self._stream()))
+        return phys_out, x_final
 
     # ---- introspection -----------------------------------------------------------------
     def set_debug(self, on: bool) -> None:

@@ -173,30 +173,69 @@ class WXFormerHIP(_Base):
             out[prefix + key] = p if keep_vars else p.detach()
         return out
 
-    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        missing, unexpected = [], []
+    def _legacy_aliases(self):
+        """{legacy key: spec key} for `wxformer` CrossEmbed parameters.  Checkpoints written before the convs were wrapped
+        in ZeroPad2d keep them at `...convs.<i>.<suffix>`; the reference moves them to `...convs.<i>.1.<suffix>` while
+        loading (credit/models/wxformer/crossformer.py:247-283, 335-352)."""
+        out = {}
+        if self.cfg.arch != "wxformer":
+            return out
         for key in self._spec:
-            if key not in state_dict:
+            parts = key.split(".")
+            for i in range(len(parts) - 3):
+                if parts[i] == "convs" and parts[i + 1].isdigit() and parts[i + 2] == "1":
+                    out[".".join(parts[:i + 2] + parts[i + 3:])] = key
+        return out
+
+    @staticmethod
+    def _same_layout(a, b) -> bool:
+        """Shapes agree up to singleton dimensions ((1, C, 1, 1) vs (C,)); anything else is torch's "size mismatch"."""
+        return [d for d in a if d != 1] == [d for d in b if d != 1]
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """torch semantics (missing / unexpected lists, size-mismatch RuntimeError) plus the two rewrites reference
+        checkpoints need: a uniform DistributedDataParallel `module.` prefix is dropped and legacy CrossEmbed keys migrate."""
+        keys = list(state_dict.keys())
+        if keys and all(k.startswith("module.") for k in keys):
+            state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
+        alias = self._legacy_aliases()
+        source, migrated = {}, 0
+        for k, v in state_dict.items():
+            tgt = alias.get(k)
+            if tgt is not None and tgt not in state_dict:   # never clobber a key the checkpoint already has in the new layout
+                source[tgt] = v
+                migrated += 1
+            else:
+                source[k] = v
+        if migrated:
+            logger.warning("Legacy checkpoint: remapped %d CrossEmbedLayer conv key(s) (convs.<i>.X -> convs.<i>.1.X).", migrated)
+        missing, errors = [], []
+        for key in self._spec:
+            if key not in source:
                 missing.append(key)
                 continue
-            src = state_dict[key]
+            src = source[key]
             src = src.detach() if isinstance(src, torch.Tensor) else torch.as_tensor(np.asarray(src))
             dst = self._store[_mangle(key)]
-            if src.numel() != dst.numel():
-                raise RuntimeError(f"size mismatch for {key}: checkpoint {tuple(src.shape)} vs model {tuple(dst.shape)}")
+            if not self._same_layout(tuple(src.shape), tuple(dst.shape)):
+                errors.append(f"size mismatch for {key}: copying a param with shape {tuple(src.shape)} from checkpoint, "
+                              f"the shape in current model is {tuple(dst.shape)}.")
+                continue
             with torch.no_grad():
                 dst.copy_(src.reshape(dst.shape).to(dst.dtype))
-        for key in state_dict:
-            if key not in self._spec:
-                unexpected.append(key)
+        unexpected = [k for k in source if k not in self._spec]
         if strict and (missing or unexpected):
-            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+            errors.insert(0, f"Missing key(s) in state_dict: {missing[:8]}{' ...' if len(missing) > 8 else ''}; "
+                             f"Unexpected key(s) in state_dict: {unexpected[:8]}{' ...' if len(unexpected) > 8 else ''}.")
+        if errors:
+            raise RuntimeError("Error(s) in loading state_dict for {}:\n\t{}".format(type(self).__name__, "\n\t".join(errors)))
         self._dirty = True
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     @classmethod
     def load_model(cls, conf):
-        """Mirror of BaseModel.load_model (credit/models/base_model.py:57-87)."""
+        """Mirror of BaseModel.load_model (credit/models/base_model.py:57-87), including what it does with the result of
+        `load_state_dict(strict=False)` (credit/models/checkpoint.py:25-31): unexpected keys raise, missing keys warn."""
         conf = copy.deepcopy(conf)
         save_loc = os.path.expandvars(conf["save_loc"])
         ckpt = os.path.join(save_loc, "model_checkpoint.pt")
@@ -208,7 +247,13 @@ class WXFormerHIP(_Base):
         conf["model"].pop("type", None)
         model = cls(**conf["model"])
         sd = checkpoint["model_state_dict"] if "model_state_dict" in checkpoint else checkpoint
-        model.load_state_dict(sd, strict=False)
+        msg = model.load_state_dict(sd, strict=False)
+        if msg.unexpected_keys:
+            raise RuntimeError(str(msg))
+        if msg.missing_keys:
+            logger.warning("Loaded partial model %s", msg)
+        else:
+            logger.info("All keys matched successfully")
         return model
 
     # ---- engine ---------------------------------------------------------------------------------------
