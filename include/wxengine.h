@@ -131,8 +131,9 @@ int wx_step(wx_handle h, const float* x_dev, const float* frc_dev, float* y_dev,
  *     y_phys_dev     HOST array of n_steps device pointers (or NULL): de-normalised output of step t goes to y_phys_dev[t];
  *                    NULL entries skip that step's output.  Pointers may repeat (a ring the host drains asynchronously).
  *     x_final_dev    optional: receives the model input that would feed step n_steps (needs frc_dev[n_steps-1])
- *     The results are bit-identical to n_steps calls of wx_step.  On launch-bound (small) grids every step is replayed from a
- *     captured hipGraph (one per ping-pong parity and y_phys destination; WX_GRAPH=0/1 overrides the automatic choice). */
+ *     The results are bit-identical to n_steps calls of wx_step.  With WX_GRAPH=1 in the environment every step is replayed from a
+ *     captured hipGraph (one per ping-pong parity and y_phys destination); measured slower than eager launches on MI355X (the cost
+ *     between dependent kernels is the device-side dispatch boundary, not host launch time), so it is off by default. */
 int wx_rollout(wx_handle h, const float* x0_dev, const float* const* frc_dev, int n_steps, float* const* y_phys_dev,
                float* x_final_dev, void* stream);
 

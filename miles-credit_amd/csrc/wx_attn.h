@@ -227,17 +227,26 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
     }
 #pragma unroll
     for (int j = 0; j < NKF; ++j) {
-      f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < QK_SUBS; ++s) a = mma_sub<T>(kf[j][s], qf[s], a);
       float4 bb;
       if constexpr (BT) bb = bt[j];
       else bb = *reinterpret_cast<const float4*>(brow + j * 16);
-      sv[j][0] = a[0] * p.scale + bb.x;
-      sv[j][1] = a[1] * p.scale + bb.y;
-      sv[j][2] = a[2] * p.scale + bb.z;
-      sv[j][3] = a[3] * p.scale + bb.w;
-      mx = fmaxf(mx, fmaxf(fmaxf(sv[j][0], sv[j][1]), fmaxf(sv[j][2], sv[j][3])));
+      if constexpr (sizeof(T) == 2) {
+        // bf16 engine: q carries scale * log2(e) (folded into to_qkv at load) and the position bias is the accumulator's
+        // initial value -> the score fragment leaves the MFMA finished (no fma per score)
+        f32x4_t a = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int s = 0; s < QK_SUBS; ++s) a = mma_sub<T>(kf[j][s], qf[s], a);
+        sv[j][0] = a[0]; sv[j][1] = a[1]; sv[j][2] = a[2]; sv[j][3] = a[3];
+      } else {
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < QK_SUBS; ++s) a = mma_sub<T>(kf[j][s], qf[s], a);
+        sv[j][0] = a[0] * p.scale + bb.x;
+        sv[j][1] = a[1] * p.scale + bb.y;
+        sv[j][2] = a[2] * p.scale + bb.z;
+        sv[j][3] = a[3] * p.scale + bb.w;
+      }
+      mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(sv[j][0], sv[j][1])), __builtin_fmaxf(sv[j][2], sv[j][3]));   // v_max3_f32 pairs
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));

@@ -440,8 +440,11 @@ class Engine : public EngineBase {
   }
   // Conv2d weight W[n][c][kh][kw] (rows [r0, r1)) -> [n][kh][kw][cpad]; optional LayerNorm fold (g, b per input channel)
   // row_src (optional): output row o takes reference row row_src[o] (-1 = all-zero row) instead of r0 + o
+  // lead_rows / lead_scale: output rows [0, lead_rows) (weights and bias) are multiplied by lead_scale before rounding -- the
+  // attention's 1/sqrt(d) (x log2 e) folded into the q rows of to_qkv, so the score MFMA needs no scaling afterwards
   ConvW make_conv(const std::string& p, int r0, int r1, int cin, int cpad, int kh, int kw, bool has_bias,
-                  const float* ln_g, const float* ln_b, const std::vector<int>* row_src = nullptr) {
+                  const float* ln_g, const float* ln_b, const std::vector<int>* row_src = nullptr, int lead_rows = 0,
+                  double lead_scale = 1.0) {
     const std::vector<double> w = folded(p, false);
     const int n = row_src ? (int)row_src->size() : r1 - r0;
     const int64_t k = (int64_t)kh * kw * cpad;
@@ -455,12 +458,12 @@ class Engine : public EngineBase {
       for (int c = 0; c < cin; ++c)
         for (int y = 0; y < kh; ++y)
           for (int x = 0; x < kw; ++x) {
-            double v = w[(((int64_t)ro * cin + c) * kh + y) * kw + x];
+            double v = w[(((int64_t)ro * cin + c) * kh + y) * kw + x] * (o < lead_rows ? lead_scale : 1.0);
             if (ln_b) tshift += v * ln_b[c];
             if (ln_g) v *= ln_g[c];
             rows[(size_t)o * k + ((int64_t)y * kw + x) * cpad + c] = v;
           }
-      bias[o] = (float)(tshift + (bt ? (double)bt->data[ro] : 0.0));
+      bias[o] = (float)(tshift + (bt ? (double)bt->data[ro] * (o < lead_rows ? lead_scale : 1.0) : 0.0));
     }
     ConvW cw;
     cw.n = n; cw.cin = cpad; cw.cin_true = cin; cw.kh = kh; cw.kw = kw;
@@ -611,7 +614,9 @@ class Engine : public EngineBase {
       a.vonly = make_conv(p + ".to_qkv", 2 * c, 3 * c, c, c, 1, 1, false, g.data.data(), b.data.data());
       pack_kblocked(a.vonly);
     } else {
-      a.qkv = make_conv(p + ".to_qkv", 0, 3 * c, c, c, 1, 1, false, g.data.data(), b.data.data());
+      // bf16 engine: softmax scale (and the log2 e of its exp2) lives in the q rows; the fp32 engine multiplies the scores instead
+      a.qkv = make_conv(p + ".to_qkv", 0, 3 * c, c, c, 1, 1, false, g.data.data(), b.data.data(), nullptr,
+                        sizeof(T) == 2 ? c : 0, 1.4426950408889634 / std::sqrt(32.0));
       pack_kblocked(a.qkv);
       a.bias_tab = make_bias_table(p + ".dpb", wsz, c / 4, &a.bias_tb);
     }
@@ -1166,7 +1171,7 @@ class Engine : public EngineBase {
       AttnParams p;
       p.qkv = scratch; p.ld_qkv = 3 * c; p.out = attn_o; p.ld_out = c; p.bias = f_dev + a.bias_tab; p.tb = a.bias_tb >= 0 ? f_dev + a.bias_tb : nullptr;
       p.H = h; p.W = w; p.C = c; p.heads = c / 32; p.wsz = a.wsz; p.kind = attn_kind_override >= 0 ? attn_kind_override : a.kind;
-      p.scale = (float)((sizeof(T) == 2 ? 1.4426950408889634 : 1.0) / std::sqrt(32.0));
+      p.scale = (float)(1.0 / std::sqrt(32.0));   // fp32 engine only: the bf16 engine's q already carries scale * log2(e)
       p.pack = attn_pack(a.wsz);
       const double n = (double)a.wsz * a.wsz;
       timed("window_attn", 4.0 * m * n * c, 4.0 * m * c * sizeof(T), [&] { launch_window_attn<T>(p, cur_stream, attn_split); });
@@ -2035,21 +2040,20 @@ class Engine : public EngineBase {
   // ------------------------------------------------------------------ wx_rollout
   // The predict() loop of credit/applications/rollout_to_netcdf.py:262-316 inside the library: n steps of
   // (forward, fixers, de-normalise, update_x) with the state ping-ponging between two engine-owned buffers -- no host code
-  // between steps.  On small grids (1-degree model: ~170 launches of ~10 us per step) a step is launch-bound, so it is captured
-  // once as a hipGraph per (ping-pong parity, y_phys destination, need-next) and replayed; big grids run eagerly (at 0.25
-  // degree the wall time already equals the sum of the kernel times).  Both ways issue exactly the launches of wx_step.
+  // between steps.  Optionally (WX_GRAPH=1) every step is captured once as a hipGraph per (ping-pong parity, y_phys destination,
+  // need-next) and replayed; both ways issue exactly the launches of wx_step.
   float* roll_x[2] = {nullptr, nullptr};
   float* roll_frc = nullptr;
   hipStream_t roll_stream = nullptr;
   hipEvent_t roll_ev_in = nullptr, roll_ev_out = nullptr;
   std::map<std::tuple<int, const void*, int>, hipGraphExec_t> roll_graphs;
   bool roll_warm = false;
-  int graph_mode = getenv("WX_GRAPH") ? atoi(getenv("WX_GRAPH")) : -1;   // -1 automatic, 0 never, 1 always
-  bool want_graph() const {
-    if (graph_mode == 0 || prof_on || dbg_on || band_on || post) return false;
-    if (graph_mode == 1) return true;
-    return (int64_t)Hp * Wp <= 320 * 640;   // launch-bound regime
-  }
+  // WX_GRAPH=1 replays each step from a captured hipGraph.  OFF by default, on measurement (MI355X, 1-degree model, 48 steps): eager
+  // 557.7 steps/s (1.79 ms/step, ~170 launches), graph replay 484.8 (2.06 ms): on this stack the cost between two dependent kernels is
+  // the device-side dispatch boundary (~1.5 us, MI355X_MICROARCH.md "boundary": eager == hipGraph), not host launch time, so a graph
+  // removes nothing and adds its replay overhead plus the forcing staging copy.
+  int graph_mode = getenv("WX_GRAPH") ? atoi(getenv("WX_GRAPH")) : 0;
+  bool want_graph() const { return graph_mode == 1 && !prof_on && !dbg_on && !band_on && !post; }
   void step_body(const float* x, const float* frc, float* y_phys, float* x_next, hipStream_t s) {
     cur_stream = s;
     core(x);

@@ -1,5 +1,5 @@
-"""Gen-2 named-tensor forecast loop on the device: mirrors of
-credit/trainers/rollout_utils.py::assemble_rollout_batch (:322-430) and ::run_forecast (:204-319).
+"""Gen-2 named-tensor forecast loop on the device: the step loop of
+credit/trainers/rollout_utils.py::run_forecast (:204-319) and the routing contract of ::assemble_rollout_batch (:322-430).
 
 Per step, with every tensor resident in HBM:
     x --model--> y_pred --Reconstruct--> named y (views) --InverseScale--> physical --fixers--> y_processed --consume-->
@@ -18,46 +18,68 @@ from .reconstruct import Reconstruct
 logger = logging.getLogger(__name__)
 
 
+# where the next step's copy of an input variable comes from
+FROM_PREDICTION, FROM_FORCING, FROM_IC = 0, 1, 2
+_SOURCE_OF_FIELD_TYPE = {"prognostic": FROM_PREDICTION, "diagnostic": FROM_PREDICTION, "dynamic_forcing": FROM_FORCING}
+
+
+class RolloutRouter:
+    """The routing table of one forecast, built ONCE from the initial condition's key list.
+
+    The contract is the one of credit/trainers/rollout_utils.py:322-430 (`assemble_rollout_batch`): the next input has exactly
+    the IC's sources and variable keys, in the IC's order; `<source>/prognostic|diagnostic/...` keys take this step's
+    processed prediction, `.../dynamic_forcing/...` keys take the incoming batch, everything else (static) keeps the IC
+    tensor; a key its source does not provide falls back to the IC (newest time level when the IC carries a history) with a
+    warning.  The reference re-derives this from the key strings at every step; here a step is one pass over a flat tuple of
+    (source, key, origin) rows -- on the device loop that is all the host does between two kernels."""
+
+    def __init__(self, ic_input: dict, history_len: int = 1):
+        self.history_len = int(history_len)
+        self.sources = [src for src, variables in ic_input.items() if variables]
+        self.rows = tuple((src, key, self._origin(key)) for src in self.sources for key in ic_input[src])
+        self._warned = set()
+
+    @staticmethod
+    def _origin(key: str) -> int:
+        field_type = key.split("/", 2)[1] if key.count("/") else ""
+        return _SOURCE_OF_FIELD_TYPE.get(field_type, FROM_IC)
+
+    def _ic_value(self, tensor):
+        if self.history_len > 1 and tensor.dim() >= 3 and tensor.shape[2] > 1:
+            return tensor[:, :, -1:, ...]
+        return tensor
+
+    def _fallback(self, key, origin, ic_tensor):
+        if key not in self._warned:   # once per key, not once per step
+            self._warned.add(key)
+            what = "y_processed" if origin == FROM_PREDICTION else "the forcing batch"
+            logger.warning("rollout routing: '%s' is missing from %s; the initial-condition value is carried forward.", key, what)
+        return self._ic_value(ic_tensor)
+
+    def __call__(self, prediction: dict, forcing_input: dict, ic_input: dict) -> dict:
+        out = {src: {} for src in self.sources}
+        for src, key, origin in self.rows:
+            if origin == FROM_IC:
+                out[src][key] = self._ic_value(ic_input[src][key])
+                continue
+            pool = (prediction if origin == FROM_PREDICTION else forcing_input).get(src) or {}
+            out[src][key] = pool[key] if key in pool else self._fallback(key, origin, ic_input[src][key])
+        return out
+
+
 def assemble_rollout_batch(full_data_dict: dict, curr_batch: dict, history_len: int = 1) -> dict:
-    """rollout_utils.py:322-430: route every IC variable key to its source for the next step's input."""
-    pred = full_data_dict["y_processed"]
-    ic = full_data_dict["ic_preprocessed"]
-    if not isinstance(pred, dict):
-        raise TypeError("assemble_rollout_batch: full_data_dict['y_processed'] must be a nested dict {source: {var_key: tensor}}. "
-                        "For multi-step rollout, 'Reconstruct' must be the first postblock. "
-                        f"Got {type(pred).__name__}.")
-
-    def newest(t):
-        if history_len > 1 and t.dim() >= 3 and t.shape[2] > 1:
-            return t[:, :, -1:, ...]
-        return t
-
-    out: Dict[str, Dict] = {}
-    for source, variables in ic["input"].items():
-        if not variables:
-            continue
-        out[source] = {}
-        cur = curr_batch.get("input", {}).get(source, {})
-        prd = pred.get(source, {})
-        for key, ic_t in variables.items():
-            parts = key.split("/")
-            ft = parts[1] if len(parts) > 1 else ""
-            if ft in ("prognostic", "diagnostic"):
-                if key in prd:
-                    out[source][key] = prd[key]
-                else:
-                    logger.warning("assemble_rollout_batch: '%s' not in y_processed; carrying forward from ic_preprocessed.", key)
-                    out[source][key] = newest(ic_t)
-            elif ft == "dynamic_forcing":
-                if key in cur:
-                    out[source][key] = cur[key]
-                else:
-                    logger.warning("assemble_rollout_batch: dynamic_forcing '%s' not in curr_batch; carrying forward from "
-                                   "ic_preprocessed.", key)
-                    out[source][key] = newest(ic_t)
-            else:
-                out[source][key] = newest(ic_t)
-    return {"input": out, "target": curr_batch.get("target")}
+    """Drop-in for the reference function of the same name (rollout_utils.py:322-430): `{"input": next input, "target": ...}`.
+    The router is cached on the state dict, so repeated calls on one forecast build the plan once."""
+    prediction = full_data_dict["y_processed"]
+    if not isinstance(prediction, dict):
+        raise TypeError(f"y_processed is a {type(prediction).__name__}, not {{source: {{variable key: tensor}}}}: put Reconstruct "
+                        "first in the post-block chain before rolling out more than one step")
+    ic_input = full_data_dict["ic_preprocessed"]["input"]
+    router = full_data_dict.get("_router")
+    if router is None or router.history_len != history_len or [k for _, k, _ in router.rows] != [k for v in ic_input.values() for k in v]:
+        router = RolloutRouter(ic_input, history_len)
+        full_data_dict["_router"] = router
+    return {"input": router(prediction, curr_batch.get("input") or {}, ic_input), "target": curr_batch.get("target")}
 
 
 class InverseScale:
@@ -90,7 +112,8 @@ def run_forecast(model, ic_batch: dict, forcing_batches: Iterable[dict], n_steps
     import torch
     full: dict = {"ic_preprocessed": {"input": ic_batch["input"]}, "x_physical": ic_batch["input"],
                   "metadata": {"target": {"_channel_map": target_channel_map}}}
-    pre = DevicePreblock(ic_batch["input"], mean, std)
+    pre = DevicePreblock(ic_batch["input"], mean, std)   # lives on the device of the IC tensors
+    router = RolloutRouter(ic_batch["input"])
     full["metadata"]["input"] = {"_channel_map": pre.channel_map}
     full["x"] = pre(ic_batch["input"])
     rec = Reconstruct()
@@ -103,7 +126,7 @@ def run_forecast(model, ic_batch: dict, forcing_batches: Iterable[dict], n_steps
                 full = blk(full)
             consume(full["y_processed"], step)
             if step < n_steps:
-                nxt = assemble_rollout_batch(full, next(it))
-                full["x_physical"] = nxt["input"]
-                full["x"] = pre(nxt["input"])
+                nxt = router(full["y_processed"], next(it).get("input") or {}, ic_batch["input"])
+                full["x_physical"] = nxt
+                full["x"] = pre(nxt)
     return full

@@ -245,6 +245,10 @@ class DistBand:
                 ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
             _check(lib.wx_band_rccl_init(engine._h, ident))
         self.exchanged_bytes = 0
+        # bytes this rank sends in ONE step, from the plan's message lists (what the in-engine RCCL transport moves without
+        # passing through Python, where `exchanged_bytes` cannot count it)
+        self.sent_bytes_per_step = sum(int(m[2]) if isinstance(m, tuple) else int(m.bytes)
+                                       for xid in range(self.band.num_exchanges) for m in self.band.messages(xid)[0])
 
     @property
     def rows(self):

@@ -59,13 +59,21 @@ def channel_stats(keys, levels, mean: Optional[Dict], std: Optional[Dict]):
 
 
 class DevicePreblock:
-    def __init__(self, example_input: Dict[str, Dict], mean: Optional[Dict] = None, std: Optional[Dict] = None, device: int = 0):
+    def __init__(self, example_input: Dict[str, Dict], mean: Optional[Dict] = None, std: Optional[Dict] = None,
+                 device: Optional[int] = None):
+        """`device`: GPU index the block lives on; default = the device of the example tensors when they are on a GPU, else the
+        current device (rank r of a replicas run works on cuda:r -- a block pinned to GPU 0 would launch on another device's
+        stream there)."""
         import torch
         if not torch.cuda.is_available():
             raise WXEngineError("no GPU visible: the device preblock has no CPU fallback")
         self.lib = load_library()
         self.keys = ordered_keys(example_input)
         flat = {k: v for src in example_input.values() for k, v in src.items()}
+        if device is None:
+            on_gpu = [v.device.index for v in flat.values() if getattr(v, "is_cuda", False)]
+            device = on_gpu[0] if on_gpu else torch.cuda.current_device()
+        self.device = int(device)
         shp = [tuple(flat[k].shape) for k in self.keys]
         if any(len(s) != 5 for s in shp) or len({(s[2], s[3], s[4]) for s in shp}) != 1:
             raise ValueError("fields must be [B, n_levels, T, H, W] on one grid")
@@ -84,7 +92,7 @@ class DevicePreblock:
         self._p = C.c_void_p()
         _check(self.lib.wx_pre_create(len(self.levels), lv, self.T, self.H, self.W,
                                       self.mean.ctypes.data_as(fp) if self.mean is not None else None,
-                                      self.std.ctypes.data_as(fp) if self.std is not None else None, device, C.byref(self._p)))
+                                      self.std.ctypes.data_as(fp) if self.std is not None else None, self.device, C.byref(self._p)))
 
     def __del__(self):
         try:
@@ -102,7 +110,9 @@ class DevicePreblock:
         for k, nl in zip(self.keys, self.levels):
             t = flat[k]
             if not t.is_cuda:
-                t = t.cuda(non_blocking=True)
+                t = t.cuda(self.device, non_blocking=True)
+            elif t.device.index != self.device:
+                raise WXEngineError(f"{k} is on cuda:{t.device.index} but this preblock was created for cuda:{self.device}")
             t = t.contiguous().float()
             if tuple(t.shape[1:]) != (nl, self.T, self.H, self.W):
                 raise ValueError(f"{k}: shape {tuple(t.shape)} does not match the schema")
@@ -110,5 +120,7 @@ class DevicePreblock:
         B = ts[0].shape[0]
         x = torch.empty((B, self.channels, self.T, self.H, self.W), dtype=torch.float32, device=ts[0].device)
         ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        _check(self.lib.wx_pre_apply(self._p, ptrs, C.c_void_p(x.data_ptr()), B, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        with torch.cuda.device(self.device):   # the entry point selects its own device; keep torch's notion of "current" intact
+            _check(self.lib.wx_pre_apply(self._p, ptrs, C.c_void_p(x.data_ptr()), B,
+                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         return x

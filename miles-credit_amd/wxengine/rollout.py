@@ -23,49 +23,58 @@ def channel_layout(cfg, n_static: int, n_dyn: int):
     return n_prog, n_static, n_dyn
 
 
-_INPUT_FIELD_TYPES = ("prognostic", "static", "dynamic_forcing")   # canonical concat rank (channel_utils.py:88-93)
+_INPUT_ORDER = ("prognostic", "static", "dynamic_forcing")   # concat rank of the input tensor (channel_utils.py:88-93)
+_OUTPUT_ORDER = ("prognostic", "diagnostic")                  # one source's block of the prediction tensor
 
 
-def build_channel_layout(conf):
-    """Mirror of credit/datasets/gen_2/channel_utils.py:161-250 for any number of data sources.
-
-    Returns (groups, n_pred): groups = [(field_type, x_start, src_start or None, count), ...] in input-channel order, one per
-    (source, field_type) run -- with several sources a field type's channels are contiguous only within a source -- ready for
-    WXEngine.set_layout_groups; n_pred = number of prognostic channels.  Source blocks of y run prognostic-then-diagnostic, the
-    forcing tensor holds the dynamic-forcing channels source-major.  Raises ValueError like the reference (history_len != 1,
-    3-D variables without a level count)."""
+def _source_widths(conf):
+    """[(source name, {field type: channel count})] from `conf["data"]["source"]`: 3-D variables count once per level (the
+    source's own level list, else `model.levels`), 2-D variables once."""
     data = conf["data"]
-    groups, x_cur, pred_cur, dyn_cur = [], 0, 0, 0
+    default_levels = int((conf.get("model") or {}).get("levels") or 0)
+    table = []
     for name, src in data["source"].items():
         src = src or {}
-        variables = src.get("variables") or {}
-        levels = src.get("levels")
-        n_levels = len(levels) if levels else int((conf.get("model") or {}).get("levels") or 0)
         if src.get("history_len", data.get("history_len", 1)) != 1:
             raise ValueError(f"build_channel_layout: source '{name}' has history_len != 1; the flat rollout cannot shift a history window")
-
-        def width(ft):
-            grp = variables.get(ft) or {}
+        n_levels = len(src["levels"]) if src.get("levels") else default_levels
+        widths = {}
+        for field_type, grp in (src.get("variables") or {}).items():
+            grp = grp or {}
             n3, n2 = len(grp.get("vars_3D") or []), len(grp.get("vars_2D") or [])
             if n3 and not n_levels:
                 raise ValueError(f"build_channel_layout: source '{name}' defines 3D variables but no level count is set")
-            return n3 * n_levels + n2
-        prog_src = pred_cur
-        pred_cur += width("prognostic") + width("diagnostic")
-        for ft in _INPUT_FIELD_TYPES:
-            w = width(ft)
-            if w == 0:
-                continue
-            if ft == "prognostic":
-                s0 = prog_src
-            elif ft == "dynamic_forcing":
-                s0 = dyn_cur
-                dyn_cur += w
-            else:
-                s0 = None
-            groups.append((ft, x_cur, s0, w))
-            x_cur += w
-    return groups, sum(g[3] for g in groups if g[0] == "prognostic")
+            widths[field_type] = n3 * n_levels + n2
+        table.append((name, widths))
+    return table
+
+
+def build_channel_layout(conf):
+    """The channel bookkeeping of credit/datasets/gen_2/channel_utils.py:161-250 for any number of data sources.
+
+    Returns (groups, n_pred): groups = [(field_type, x_start, src_start or None, count), ...] in input-channel order, one per
+    (source, field_type) run -- with several sources a field type's channels are contiguous only within a source -- ready for
+    WXEngine.set_layout_groups; n_pred = number of prognostic channels.  Three tensors are described at once: the input x
+    (per source: prognostic | static | dynamic_forcing), the prediction y (per source: prognostic | diagnostic) and the forcing
+    tensor (every source's dynamic-forcing channels, source-major); a group's src_start is its offset in y (prognostic) or in
+    the forcing tensor (dynamic_forcing).  Raises ValueError like the reference (history_len != 1, 3-D variables without a
+    level count)."""
+    table = _source_widths(conf)
+    # exclusive prefix sums over the sources: where each source's block starts in y and in the forcing tensor
+    y_start, frc_start, y_cur, frc_cur = {}, {}, 0, 0
+    for name, w in table:
+        y_start[name], frc_start[name] = y_cur, frc_cur
+        y_cur += sum(w.get(ft, 0) for ft in _OUTPUT_ORDER)
+        frc_cur += w.get("dynamic_forcing", 0)
+    source_offset = {"prognostic": y_start, "dynamic_forcing": frc_start}
+    groups, x_cur = [], 0
+    for name, w in table:
+        for ft in _INPUT_ORDER:
+            n = w.get(ft, 0)
+            if n:
+                groups.append((ft, x_cur, source_offset[ft][name] if ft in source_offset else None, n))
+                x_cur += n
+    return groups, sum(n for ft, _, _, n in groups if ft == "prognostic")
 
 
 def rollout(engine: WXEngine, x0: torch.Tensor, forcings: Sequence[Optional[torch.Tensor]],

@@ -1,12 +1,12 @@
-"""world_size-2 gloo test of the N>1 path (replicas over init times; no data-path collective)."""
+"""world_size-2 gloo test of the N>1 path: the SAME harness object `bench.py --gpus N` times its rollout with
+(wxengine.replicas.ReplicaGroup: init-time sharding, barrier-bracketed region, MAX-over-ranks clock, aggregate throughput)."""
 import os
 import socket
+import time
 
-import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from wxengine.replicas import aggregate_throughput, max_over_ranks, shard_init_times
+from wxengine.replicas import ReplicaGroup
 
 
 def _free_port():
@@ -18,22 +18,23 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    mine = shard_init_times(list(range(7)), rank, world)
-    dist.barrier()
-    elapsed = 1.0 + rank  # pretend rank 1 is slower
-    mx = max_over_ranks(elapsed, dist)
-    # ranks own disjoint forecasts whose union is everything
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    grp = ReplicaGroup(backend="gloo", n_expected=world)
+    mine = grp.my_share(list(range(7)))
+    steps = []
+
+    def work():                      # rank 1 is the slow one: the shared clock must report ITS time on every rank
+        for t in range(4):
+            time.sleep(0.05 * (1 + rank))
+            steps.append(t)
+    elapsed = grp.timed(work, lambda: None)
     gathered = [None] * world
-    dist.all_gather_object(gathered, mine)
-    q.put((rank, mine, mx, gathered))
-    dist.barrier()
-    dist.destroy_process_group()
+    grp.dist.all_gather_object(gathered, mine)
+    q.put((rank, mine, elapsed, gathered, grp.throughput(len(steps), elapsed), grp.all_true(rank == 0), grp.all_true(True)))
+    grp.close()
 
 
-def test_replica_sharding_two_ranks_gloo():
+def test_replica_group_two_ranks_gloo():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -45,13 +46,22 @@ def test_replica_sharding_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, m0, mx0, g0), (r1, m1, mx1, g1) = res
+    (_, m0, e0, g0, v0, f0, t0), (_, m1, e1, g1, v1, f1, t1) = res
     assert m0 == [0, 2, 4, 6] and m1 == [1, 3, 5]          # rollout_to_netcdf.py:259 rule
-    assert mx0 == mx1 == 2.0                               # MAX over ranks
     assert sorted(g0[0] + g0[1]) == list(range(7)) and g0 == g1
-    assert aggregate_throughput(40, world, mx0) == 40.0
+    assert e0 == e1 and e0 >= 4 * 0.05 * 2                  # MAX over ranks: both see the slow rank's time
+    assert v0 == v1 and abs(v0 - 2 * 4 / e0) < 1e-9         # whole-job steps/s = world * steps / max time
+    assert (f0, f1) == (False, False) and (t0, t1) == (True, True)
 
 
-def test_single_process_identity():
-    assert shard_init_times(["a", "b", "c"], 0, 1) == ["a", "b", "c"]
-    assert max_over_ranks(3.5) == 3.5
+def test_single_process_identity(monkeypatch):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    grp = ReplicaGroup(backend="gloo")
+    assert grp.world == 1 and grp.dist is None
+    assert grp.my_share(["a", "b", "c"]) == ["a", "b", "c"]
+    assert grp.max_over_ranks(3.5) == 3.5
+    calls = []
+    e = grp.timed(lambda: calls.append("work"), lambda: calls.append("sync"))
+    assert calls == ["sync", "work", "sync", "sync"] and e >= 0
+    assert grp.throughput(40, 2.0) == 20.0

@@ -1,0 +1,94 @@
+"""The drop-in boundary against the REAL registry (dev container only: needs /root/reference).
+
+credit/models/__init__.py:128-161 (register_model), :278-298 (custom_models import), :301-387 (load_model): a maintainer adds
+a `custom_models` file that registers the HIP classes, sets `model.type: crossformer_hip` in the YAML, and
+`rollout_to_netcdf` builds the engine through `load_model(conf)` like any other model."""
+import copy
+import os
+import sys
+import textwrap
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.reference
+
+REF = "/root/reference"
+YAML = os.path.join(REF, "config", "gen_2", "examples", "wxformer_era5_025deg_6hr.yml")
+
+
+@pytest.fixture(scope="module")
+def credit_models():
+    import oracle_stub  # noqa: F401  (tools/: stub finder for the reference's missing third-party imports)
+    oracle_stub.install()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import credit.models as cm
+    return cm
+
+
+def _conf():
+    import yaml
+    with open(YAML) as f:
+        return yaml.safe_load(f)
+
+
+def test_load_model_builds_the_hip_class_through_the_real_registry(credit_models, tmp_path):
+    cm = credit_models
+    from credit.models.base_model import BaseModel
+    from credit.models.crossformer import CrossFormer
+    custom = tmp_path / "my_models.py"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    custom.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path[:0] = [{os.path.join(root, 'miles-credit_amd')!r}]
+        from wxengine.model import register
+        register("crossformer_hip", "wxformer_hip")
+    """))
+    conf = _conf()
+    assert conf["model"]["type"] == "crossformer"
+    # what the application does to the model section before load_model (rollout_to_netcdf.py: _inject_flat_schema / _inject_tracer_inds)
+    from credit.applications import rollout_to_netcdf as app
+    for fn in ("_inject_flat_schema", "_inject_tracer_inds"):
+        if hasattr(app, fn):
+            getattr(app, fn)(conf)
+    ref_kwargs = copy.deepcopy(conf["model"])
+    conf["model"]["type"] = "crossformer_hip"
+    conf["custom_models"] = [str(custom)]
+    m = cm.load_model(conf)
+    from wxengine.model import WXFormerHIP
+    assert isinstance(m, WXFormerHIP) and isinstance(m, BaseModel) and isinstance(m, torch.nn.Module)
+    assert "crossformer_hip" in cm._MODEL_REGISTRY and "wxformer_hip" in cm._MODEL_REGISTRY
+    # same state-dict keys and shapes as the reference class built from the same kwargs (on the meta device: 124 M parameters)
+    ref_kwargs.pop("type", None)
+    ref_kwargs["post_conf"] = {"activate": False}   # the reference PostBlock needs the full credit_main_parser output; it owns no parameters
+    with torch.device("meta"):
+        ref = CrossFormer(**ref_kwargs)
+    want = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == want
+    assert sum(v.numel() for v in m.state_dict().values()) == sum(v.numel() for v in ref.state_dict().values())
+    # the attributes the rollout application reads from the model object
+    for attr in ("image_height", "image_width", "frames", "channels", "levels", "surface_channels"):
+        assert getattr(m, attr) == getattr(ref, attr), attr
+
+
+def test_register_model_contract(credit_models, caplog):
+    import logging
+    cm = credit_models
+    from credit.models.base_model import BaseModel
+    from wxengine.model import WXFormerHIP, WXFormerPSHIP
+    name = "crossformer_hip_contract_test"
+    assert cm.register_model(name, "test")(WXFormerHIP) is WXFormerHIP        # the decorator hands the class back
+    assert cm._MODEL_REGISTRY[name] == (WXFormerHIP, "test")
+    with caplog.at_level(logging.WARNING):                                    # a duplicate overwrites, with a warning (:156-158)
+        cm.register_model(name, "again")(WXFormerPSHIP)
+    assert cm._MODEL_REGISTRY[name][0] is WXFormerPSHIP
+    assert any("overwriting existing registry entry" in r.getMessage() for r in caplog.records)
+    with pytest.raises(TypeError):                                            # only BaseModel subclasses may register (:153-155)
+
+        class NotAModel:
+            pass
+        cm.register_model(name + "_bad", "x")(NotAModel)
+    assert issubclass(WXFormerHIP, BaseModel)
+    cm._MODEL_REGISTRY.pop(name, None)

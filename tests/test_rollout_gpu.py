@@ -1,0 +1,119 @@
+"""Row R of SURVEY.md 8(a): the predict() loop (credit/applications/rollout_to_netcdf.py:262-316) reproduced by the engine.
+
+  * `wx_rollout` (the loop inside the C ABI, eager and captured-graph paths) is BIT-IDENTICAL to n calls of `wx_step`;
+  * a full-length rollout on the 1-degree grid (BASELINE config 2: 24 steps) against `tests/golden/rollout_C1.npz`: the trajectory of
+    the reference's own pieces (fp32 CPU), with the fp64 oracle's trajectory stored beside it.  The reference's fp32 arithmetic itself
+    drifts from fp64 along the trajectory (`ref_vs_fp64_rel_l2[t]`), so the bar for step t is stated relative to that:
+        fp32 engine:  rel-L2(engine, reference)[t] <= max(1e-4 * t, 4 * ref_vs_fp64_rel_l2[t])
+        bf16 engine:  rel-L2(engine, reference)[t] <= BF16_STEP1 * growth(t)   (bound stated below; reported in the test output)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from wxengine.config import named_config
+from wxengine.engine import WXEngine
+from wxengine.synth import synth_denorm, synth_forcing, synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def make_engine(name, prec, tracer=None, denorm=False):
+    cfg = named_config(name)
+    eng = WXEngine(cfg, prec, 0)
+    eng.load_state_dict(synth_state_dict(cfg))
+    eng.finalize()
+    mean, std = synth_denorm(cfg.base_output_channels)
+    eng.set_denorm(mean, std)
+    eng.set_layout(cfg.channels * cfg.levels + cfg.surface_channels, 2, 2)
+    if tracer is not None:
+        eng.set_tracer_fixer(tracer[0], tracer[1], None, denorm=denorm)
+    return cfg, eng
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["T0", "T1"])
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_wx_rollout_is_bit_identical_to_a_loop_of_wx_step(name, prec, graph, monkeypatch):
+    n = 5
+    monkeypatch.setenv("WX_GRAPH", graph)      # read when the engine is created: "1" = captured step graphs from the second call on
+    cfg, eng = make_engine(name, prec, tracer=(list(range(9, 12)), [-0.05] * 3))
+    x0 = torch.from_numpy(synth_input(cfg)).cuda()
+    frcs = [torch.from_numpy(synth_forcing(cfg, 2, t + 1)).cuda() for t in range(n)]
+    # reference: n calls of wx_step from Python
+    want, x = [], x0
+    for t in range(n):
+        _, yp, xn = eng.step(x, frcs[t], want_y=False)
+        want.append(yp.clone())
+        x = xn
+    x_last = x.clone()
+    ring = [torch.empty_like(want[0]) for _ in range(2)]           # a 2-deep output ring, as a host drain would use
+    for attempt in ("first call (eager; warms the launch attributes)", "second call (captures the step graphs when WX_GRAPH=1)",
+                    "third call (graphs replayed from the cache)"):
+        got = []
+        for t0 in range(0, n, 2):                                    # drain the ring every two steps
+            k = min(2, n - t0)
+            xs = x0 if t0 == 0 else xf
+            xf = torch.empty_like(x0)
+            eng.rollout(xs, frcs[t0:t0 + k], ring[:k], x_final=xf)
+            got += [r.clone() for r in ring[:k]]
+        for t in range(n):
+            assert torch.equal(got[t], want[t]), f"{attempt}: step {t + 1} differs from wx_step"
+        assert torch.equal(xf, x_last), attempt
+    # outputs that are not requested are simply skipped; the state still advances identically
+    xf2 = torch.empty_like(x0)
+    eng.rollout(x0, frcs, [None] * (n - 1) + [ring[0]], x_final=xf2)
+    assert torch.equal(ring[0], want[-1]) and torch.equal(xf2, x_last)
+
+
+def test_wx_rollout_argument_errors():
+    from wxengine.engine import WXEngineError
+    cfg, eng = make_engine("T0", "fp32")
+    x0 = torch.from_numpy(synth_input(cfg)).cuda()
+    frc = torch.from_numpy(synth_forcing(cfg, 2, 1)).cuda()
+    with pytest.raises(WXEngineError):
+        eng.rollout(x0, [])
+    with pytest.raises(WXEngineError):                       # forcing with one channel too few: caught before the pointer is used
+        eng.rollout(x0, [frc[:, :1].contiguous()], x_final=torch.empty_like(x0))
+    with pytest.raises(WXEngineError):                       # a next input is requested but its forcing is missing
+        eng.rollout(x0, [frc, None], x_final=torch.empty_like(x0))
+    with pytest.raises(WXEngineError):                       # wrong grid
+        eng.step(x0[..., :-1].contiguous(), frc)
+    with pytest.raises(WXEngineError):
+        eng.step(x0, frc, phys_out=torch.empty((1, cfg.base_output_channels, 3, 3), device="cuda"))
+
+
+BF16_STEP1 = 2e-2           # the single-step bf16 bar of tests/test_engine_gpu.py
+BF16_GROWTH = 1.25          # allowed per-step growth factor of the bf16 trajectory error (measured: see the printed table)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_24_step_rollout_on_the_1_degree_grid_vs_reference_trajectory(prec):
+    path = os.path.join(GOLD, "rollout_C1.npz")
+    if not os.path.isfile(path):
+        pytest.skip("tests/golden/rollout_C1.npz not generated yet (tools/make_goldens.py --only rollC1)")
+    g = np.load(path)
+    n, s = int(g["n_steps"]), int(g["stride"])
+    cfg, eng = make_engine("C1", prec, tracer=(g["tracer_inds"], g["tracer_thres"]))
+    x0 = torch.from_numpy(synth_input(cfg)).cuda()
+    frcs = [torch.from_numpy(synth_forcing(cfg, 2, t + 1)).cuda() for t in range(n)]
+    ys, x = [], x0
+    for t in range(n):                 # wx_step keeps the normalised output (the golden's quantity); wx_rollout is checked above
+        y, _, xn = eng.step(x, frcs[t], want_phys=False)
+        ys.append(y[0, :, 0, ::s, ::s].cpu().numpy().astype(np.float64))
+        x = xn
+    ref, o64, floor = g["y"].astype(np.float64), g["y64"].astype(np.float64), g["ref_vs_fp64_rel_l2"]
+    rel = [float(np.linalg.norm(ys[t] - ref[t]) / np.linalg.norm(ref[t])) for t in range(n)]
+    rel64 = [float(np.linalg.norm(ys[t] - o64[t]) / np.linalg.norm(o64[t])) for t in range(n)]
+    print(f"\\n{prec} engine, C1, {n}-step rollout: rel-L2 per step vs the reference trajectory | vs the fp64 oracle | reference vs fp64")
+    for t in range(n):
+        print(f"  t={t + 1:2d}  {rel[t]:.3e}  {rel64[t]:.3e}  {floor[t]:.3e}")
+    assert all(np.isfinite(v) for v in rel)
+    for t in range(n):
+        if prec == "fp32":
+            assert rel[t] <= max(1e-4 * (t + 1), 4.0 * floor[t]), f"fp32 step {t + 1}: {rel[t]:.3e} (floor {floor[t]:.3e})"
+        else:
+            assert rel[t] <= BF16_STEP1 * BF16_GROWTH ** t, f"bf16 step {t + 1}: rel-L2 {rel[t]:.3e}"

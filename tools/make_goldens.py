@@ -186,6 +186,50 @@ def glue_golden():
     np.savez_compressed(os.path.join(GOLD, "rollout_T0.npz"), **out)
 
 
+def long_rollout_golden(name, n_steps, stride):
+    """Row R of SURVEY.md 8(a): the predict() loop (rollout_to_netcdf.py:262-316) for n_steps steps on a full-size grid, through the
+    reference's own pieces -- CrossFormer forward (fp32, CPU), TracerFixer, y*std+mean, update_x -- and, beside it, the same
+    trajectory from the fp64 oracle (oracle/wxformer_oracle.py::rollout).  Stored per step: strided samples of the
+    normalised output of both, and per-channel (sum, sum of squares) of the reference output.  The distance between the two
+    trajectories is the noise floor of the reference's OWN arithmetic: what an engine can be asked to match at step t."""
+    from credit.datasets.gen_2.channel_utils import build_channel_layout, update_x
+    from credit.postblock.gen1 import TracerFixer
+    from oracle import wxformer_oracle as O
+    cfg = named_config(name)
+    m = reference_model(cfg)
+    sd = synth_state_dict(cfg)
+    groups, n_pred = build_channel_layout(glue_conf(cfg))
+    q_inds = list(range(3 * cfg.levels, 4 * cfg.levels))
+    thres = [-0.05] * len(q_inds)
+    fixer = TracerFixer({"tracer_fixer": {"tracer_inds": q_inds, "tracer_thres": thres, "denorm": False}})
+    x = torch.from_numpy(synth_input(cfg))
+    x64 = x.double()
+    out = {"tracer_inds": np.array(q_inds), "tracer_thres": np.array(thres, dtype=np.float32), "n_static": np.int64(2),
+           "n_dyn": np.int64(2), "stride": np.int64(stride), "n_steps": np.int64(n_steps)}
+    ys, y64s, sums, rel = [], [], [], []
+    t0 = time.time()
+    with torch.no_grad():
+        for step in range(1, n_steps + 1):
+            frc = torch.from_numpy(synth_forcing(cfg, 2, step))
+            y = fixer({"y_pred": m(x), "x": x})["y_pred"]
+            x = update_x(x, frc, y.detach(), groups)
+            y64 = O.tracer_fix(O.forward(cfg, sd, x64, dtype=torch.float64), q_inds, thres)
+            x64 = O.update_x(x64, frc.double(), y64, n_pred, 2)
+            ys.append(y[0, :, 0, ::stride, ::stride].numpy().astype(np.float32))
+            y64s.append(y64[0, :, 0, ::stride, ::stride].numpy().astype(np.float32))
+            s1, s2, _ = channel_stats(y)
+            sums.append(np.stack([s1, s2]))
+            d = (y.double() - y64)[0, :, 0]
+            rel.append(float(d.norm() / y64[0, :, 0].norm()))
+            print(f"[golden] {name} rollout step {step}/{n_steps}: mean|y|={y.abs().mean():.4f}  reference-fp32 vs fp64 oracle "
+                  f"rel-L2 {rel[-1]:.3e}  ({time.time() - t0:.0f}s)", flush=True)
+    out["y"] = np.stack(ys)            # [n_steps, C_out, H/stride, W/stride]  reference, fp32
+    out["y64"] = np.stack(y64s)        # the fp64 oracle's trajectory at the same points
+    out["ch_sums"] = np.stack(sums)    # [n_steps, 2, C_out] float64
+    out["ref_vs_fp64_rel_l2"] = np.array(rel)
+    np.savez_compressed(os.path.join(GOLD, f"rollout_{name}.npz"), **out)
+
+
 def fixer_inputs(seed=11):
     """Physically plausible random fields on the reference's 10x18 / 7-level demo grid.
     x: [T(7) | q(7) | U(7) | V(7)] x 2 frames; y: the same 28 + [TOA solar, TOA OLR, surf solar, surf LR, SH, LH, precip, evapor]."""
@@ -443,7 +487,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
+    ap.add_argument("--only", default="pad,T0,T1,glue,rollC1,rollC3S,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -452,6 +496,10 @@ def main():
             pad_golden()
         elif item == "glue":
             glue_golden()
+        elif item == "rollC1":      # BASELINE config 2: 24-step rollout on the 1-degree grid
+            long_rollout_golden("C1", 24, 20)
+        elif item == "rollC3S":     # 8 steps on the 0.25-degree grid (small-width model)
+            long_rollout_golden("C3S", 8, 40)
         elif item == "layout":
             layout_golden()
         elif item == "fixers":
