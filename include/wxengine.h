@@ -137,6 +137,34 @@ int wx_step(wx_handle h, const float* x_dev, const float* frc_dev, float* y_dev,
 int wx_rollout(wx_handle h, const float* x0_dev, const float* const* frc_dev, int n_steps, float* const* y_phys_dev,
                float* x_final_dev, void* stream);
 
+/* ---- window attention as an operator of its own (second architecture) --------------------------------
+ * The attention CORE of a windowed transformer block on a token-major map: out = softmax(scores + bias [+ mask]) v per window
+ * and head, everything between the qkv projection and the output projection.  Three window kinds:
+ *   0  contiguous wsz_y x wsz_x blocks            (CrossFormer short attention, crossformer.py:247-316)
+ *   1  dilated wsz x wsz grids                    (CrossFormer long attention)
+ *   3  blocks of the map rolled by (-shift_y, -shift_x), pairs across the latitude seam get `mask_value` added
+ *      (credit/models/swin.py:451-486 `_shifted_window_attn`, :411-427 `_make_attention_mask`; the FuXi stage
+ *      credit/models/fuxi.py:250-260 runs the same operator through timm)
+ * scores = q . k * softmax_scale, or -- when logit_scale is given -- normalize(q) . normalize(k) * logit_scale[head]
+ * (swin.py:305-309 scaled cosine attention; pass exp(clamp(logit_scale, max = log 100)) as the reference computes it).
+ * bias_host: [n_bias_heads][N][N] float32 (N = wsz_y * wsz_x; n_bias_heads = heads, 1 = shared, 0 = none), e.g. the output of
+ * swin.py:283-297 `_relative_positional_encodings`.
+ *     qkv_dev  [H * W][3 C]  q | k | v, each head-major (what `Linear(dim, 3 dim)` produces), bf16 or float32 per `precision`
+ *     out_dev  [H * W][C]    same element type */
+typedef struct wx_winattn_desc {
+  int32_t precision;           /* WX_PREC_FP32 / WX_PREC_BF16: element type of qkv / out and of the MFMA path */
+  int32_t H, W, C, heads, head_dim;
+  int32_t wsz_y, wsz_x;        /* wsz_x = 0: square */
+  int32_t kind, shift_y, shift_x;
+  float softmax_scale;         /* ignored when logit_scale is given */
+  float mask_value;            /* kind 3 (the reference: -100) */
+} wx_winattn_desc;
+typedef struct wx_winattn* wx_winattn_handle;
+int wx_winattn_create(const wx_winattn_desc* desc, const float* bias_host, int n_bias_heads, const float* logit_scale_host, int device,
+                      wx_winattn_handle* out);
+int wx_winattn_apply(wx_winattn_handle w, const void* qkv_dev, void* out_dev, void* stream);
+int wx_winattn_destroy(wx_winattn_handle w);
+
 /* ---- conservation fixers (PostBlock) -------------------------------------------
  * A wx_post is the device-side counterpart of credit/postblock/gen1.py::PostBlock for pressure-level grids: an ordered
  * list of TracerFixer (:111-167), GlobalMassFixer (:170-391), GlobalWaterFixer (:394-569) and GlobalEnergyFixer

@@ -26,7 +26,16 @@ struct AttnParams {
   const float* bias;  // [NP][NP] fp32, NP = 16*NKF; padded keys hold -1e30
   const float* tb;    // the same bias as its generating table [(2w-1)^2] (bias[i][j] depends on (row, col) offsets only):
                       // BT kernels keep it in LDS and never touch `bias` (49 KB of L2 reads per task otherwise)
-  int H, W, C, heads, wsz, kind;  // kind 0 short, 1 long, 2 long windows whose rows were made contiguous (lat-band layout)
+  int H, W, C, heads, wsz, kind;  // kind 0 short, 1 long, 2 long windows whose rows were made contiguous (lat-band layout),
+                                  // 3 Swin: wsz x wsz_x windows of the map rolled by (-shift_y, -shift_x) (credit/models/swin.py:451-486)
+  int wsz_x = 0;                  // window width (0 = wsz: the CrossFormer windows are square)
+  int shift_y = 0, shift_x = 0;   // kind 3: cyclic shift; tokens whose rolled row is >= H - shift_y form a second region and pairs
+  float mask_val = 0.f;           //         across the two regions get mask_val added (swin.py:411-427: -100, latitude only)
+  int64_t bias_head_stride = 0;   // floats between the [NP][NP] bias tables of consecutive heads (0 = one table for all heads)
+  float q_scale = 0.f;            // bf16 path, != 0: multiply the query fragments by this (softmax scale x log2 e) in the kernel -- the
+                                  // CrossFormer engine folds it into to_qkv's q rows instead and leaves 0 here
+  const float* logit_scale = nullptr;  // non-null: scaled COSINE attention (swin.py:305-309): q, k rows are L2-normalised and q is
+                                  // multiplied by logit_scale[head] (already clamped / exponentiated, x log2 e for bf16)
   float scale;                    // bf16 engine: scale * log2(e), and the bias table is pre-multiplied by log2(e)
   unsigned long long* trace;      // tools/attn_probe only (WX_ATTN_TRACE builds): [tasks][8] phase ticks
   int pack;                       // windows per 16-token tile (1, or 16 / wsz^2 for the 2x2 windows of the long
@@ -34,14 +43,39 @@ struct AttnParams {
                                   // block-diagonal with -1e30 between windows)
 };
 
+// L2-normalise (x / max(|x|, 1e-12), torch.nn.functional.normalize) and scale a token's head slice held as NS 16-byte pieces
+// per lane; the slice is spread over the four lanes that share lane & 15 (k-groups g = lane >> 4)
+template <typename T, int NS>
+__device__ __forceinline__ void cosine_normalise(uint4 (&f)[NS], float mul) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  float v[NS][VEC];
+  float ss = 0.f;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    unpack16<T>(f[s], v[s]);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ss += v[s][e] * v[s][e];
+  }
+  ss += __shfl_xor(ss, 16);
+  ss += __shfl_xor(ss, 32);
+  const float inv = mul / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[s][e] *= inv;
+    f[s] = pack16<T>(v[s]);
+  }
+}
+
 // SPLIT = false: one wave per (window tile, head), four independent tasks per workgroup.
 // SPLIT = true : the workgroup's four waves share one task -- V^T is staged once by all 256 threads and the query
 //                blocks are dealt round-robin to the waves.  Same work, a quarter of the per-task latency: the
 //                stage-2/3 launches have only 3-6 tasks per SIMD and were bound by the length of one task.
-template <typename T, int NKF, bool SPLIT, bool BT>
+template <typename T, int NKF, bool SPLIT, bool BT, int DH = 32>
 __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
   constexpr int TBN = 1024;  // LDS bias table: [0, (2w-1)^2) the offsets, the rest -1e30 (padded keys index there)
-  constexpr int D = 32;
+  constexpr int D = DH;      // head dimension: 32 (CrossFormer), up to 128 (FuXi's Swin stage)
+  constexpr int NDF = D / 16;
   constexpr int NP = NKF * 16;
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int QK_SUBS = D * (int)sizeof(T) / 64;       // 16-byte pieces per lane for a Q/K fragment
@@ -52,9 +86,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int NW1 = p.wsz * p.wsz;        // tokens per window
+  const int wsx = p.wsz_x > 0 ? p.wsz_x : p.wsz;
+  const int NW1 = p.wsz * wsx;          // tokens per window
   const int N = NW1 * p.pack;           // tokens per tile
-  const int wins_x = p.W / p.wsz, wins_y = p.H / p.wsz;
+  const int wins_x = p.W / wsx, wins_y = p.H / p.wsz;
   const int n_win = wins_x * wins_y;
   const int64_t task = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;
   const int64_t n_tasks = (int64_t)((n_win + p.pack - 1) / p.pack) * p.heads;
@@ -72,11 +107,16 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
       if (w >= n_win) return -1;
     }
     const int wy = w / wins_x, wx_ = w - wy * wins_x;
-    const int ty = tl / p.wsz, tx = tl - ty * p.wsz;
+    const int ty = tl / wsx, tx = tl - ty * wsx;
     int py, px;
     if (p.kind == 0) {
       py = wy * p.wsz + ty;
-      px = wx_ * p.wsz + tx;
+      px = wx_ * wsx + tx;
+    } else if (p.kind == 3) {  // window of the rolled map: rolled (r, c) holds pixel ((r + shift_y) % H, (c + shift_x) % W)
+      py = wy * p.wsz + ty + p.shift_y;
+      px = wx_ * wsx + tx + p.shift_x;
+      py -= py >= p.H ? p.H : 0;
+      px -= px >= p.W ? p.W : 0;
     } else if (p.kind == 2) {  // wx_band.h long layout: phase-major rows, columns still dilated
       py = wy * p.wsz + ty;
       px = tx * wins_x + wx_;
@@ -100,6 +140,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
   T* vt = reinterpret_cast<T*>(smem + (SPLIT ? 0 : wave) * VT_BYTES);
   float* s_tb = reinterpret_cast<float*>(smem + (SPLIT ? 1 : 4) * VT_BYTES);
   int* s_bk = reinterpret_cast<int*>(s_tb + TBN);   // [NP] byte offset 4*(ty*(2w-1)+tx) of token t, or -2048 when padded
+  int* s_row = BT ? s_bk + NP : reinterpret_cast<int*>(s_tb);   // [NP] window row ty of token t (kind 3: the shift mask's regions)
+  if (p.kind == 3 && threadIdx.x < NP) s_row[threadIdx.x] = (int)threadIdx.x / wsx;
   if constexpr (BT) {
     const int side = 2 * p.wsz - 1;
     for (int i = threadIdx.x; i < TBN; i += 256) s_tb[i] = i < side * side ? p.tb[i] : -1.0e30f;
@@ -143,6 +185,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
         kf[j][s] = *reinterpret_cast<const uint4*>(qkv + kp * p.ld_qkv + p.C + head * D + (s * 64 + g * 16) / (int)sizeof(T));
     }
   }
+  if (p.logit_scale) {
+#pragma unroll
+    for (int j = 0; j < NKF; ++j) cosine_normalise<T, QK_SUBS>(kf[j], 1.0f);
+  }
   // ---- V^T into this wave's LDS slice (zero-filled beyond N) -------------------------------
   {
 #pragma unroll
@@ -161,9 +207,9 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
   AT_TICK(at1);
 
   constexpr int NVF = (sizeof(T) == 2) ? NKB : NKF;
-  uint4 vf[2][NVF];
+  uint4 vf[NDF][NVF];
 #pragma unroll
-  for (int df = 0; df < 2; ++df) {
+  for (int df = 0; df < NDF; ++df) {
     const T* row = vt + (df * 16 + li) * VT_COLS;
 #pragma unroll
     for (int b = 0; b < NVF; ++b) {
@@ -208,11 +254,26 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
 #pragma unroll
     for (int s = 0; s < QK_SUBS; ++s) qf[s] = qnext[s];
     load_q(qb + QSTEP, qnext);
+    if (p.logit_scale) cosine_normalise<T, QK_SUBS>(qf, p.logit_scale[head]);
+    else if (sizeof(T) == 2 && p.q_scale != 0.f) {
+#pragma unroll
+      for (int s = 0; s < QK_SUBS; ++s) {
+        float v[VEC];
+        unpack16<T>(qf[s], v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] *= p.q_scale;
+        qf[s] = pack16<T>(v);
+      }
+    }
     // Scores/probabilities live in plain float arrays (not ext-vector elements): hipcc (ROCm 7.2) was
     // observed to fold element writes `vec[r] = expf(..)` so that all four PV B-operands read element 0.
     float sv[NKF][4];
     float mx = -3.0e38f;
-    const float* brow = p.bias + (int64_t)query * NP + g * 4;  // query < NP always
+    const float* brow = p.bias + (int64_t)head * p.bias_head_stride + (int64_t)query * NP + g * 4;  // query < NP always
+    // kind 3: region (0 / 1) of this lane's query under the shift mask; window row of the tile's window
+    const int reg_lim = p.H - p.shift_y - (win0 / wins_x) * p.wsz;   // token row ty is in region 1 iff ty >= reg_lim
+    const bool swin_mask = p.kind == 3 && p.shift_y > 0;
+    const int reg_q = swin_mask ? (int)(s_row[query < NP ? query : 0] >= reg_lim) : 0;
     float4 bt[BT ? NKF : 1];
     if constexpr (BT) {
       // bias[q][k] = tb[(qy - ky + w - 1) * (2w - 1) + (qx - kx + w - 1)]: one subtraction and one 4-byte LDS read per pair
@@ -230,6 +291,13 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
       float4 bb;
       if constexpr (BT) bb = bt[j];
       else bb = *reinterpret_cast<const float4*>(brow + j * 16);
+      if (swin_mask) {   // pairs across the wrap-around seam of the rolled map: + mask_val (the reference's -100)
+        const int4 rk = *reinterpret_cast<const int4*>(s_row + j * 16 + g * 4);
+        bb.x += ((int)(rk.x >= reg_lim) != reg_q) ? p.mask_val : 0.f;
+        bb.y += ((int)(rk.y >= reg_lim) != reg_q) ? p.mask_val : 0.f;
+        bb.z += ((int)(rk.z >= reg_lim) != reg_q) ? p.mask_val : 0.f;
+        bb.w += ((int)(rk.w >= reg_lim) != reg_q) ? p.mask_val : 0.f;
+      }
       if constexpr (sizeof(T) == 2) {
         // bf16 engine: q carries scale * log2(e) (folded into to_qkv at load) and the position bias is the accumulator's
         // initial value -> the score fragment leaves the MFMA finished (no fma per score)
@@ -268,7 +336,9 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
     const float inv = 1.0f / sum;
     AT_TICK(q2);
 
-    f32x4_t oacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    f32x4_t oacc[NDF];
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) oacc[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int b = 0; b < NKB; ++b) {
@@ -284,13 +354,13 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
         pf.z = pack_bf16x2(hi[0], hi[1]);
         pf.w = pack_bf16x2(hi[2], hi[3]);
 #pragma unroll
-        for (int df = 0; df < 2; ++df) oacc[df] = mma_sub<T>(vf[df][b], pf, oacc[df]);
+        for (int df = 0; df < NDF; ++df) oacc[df] = mma_sub<T>(vf[df][b], pf, oacc[df]);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NKF; ++j) {
 #pragma unroll
-        for (int df = 0; df < 2; ++df) {
+        for (int df = 0; df < NDF; ++df) {
           const uint4 va = vf[df][j];
           oacc[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, va.x), sv[j][0], oacc[df], 0, 0, 0);
           oacc[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, va.y), sv[j][1], oacc[df], 0, 0, 0);
@@ -302,7 +372,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
     AT_TICK(q3);
     if (qok) {
 #pragma unroll
-      for (int df = 0; df < 2; ++df) {
+      for (int df = 0; df < NDF; ++df) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = oacc[df][r] * inv;
@@ -320,18 +390,18 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
 #endif
 }
 
-template <typename T, int NKF, bool SPLIT, bool BT = false>
+template <typename T, int NKF, bool SPLIT, bool BT = false, int DH = 32>
 inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
   constexpr int NKB = (NKF + 1) / 2;
   constexpr int VT_COLS = (sizeof(T) == 2) ? (NKB * 32 + 8) : (NKF * 16 + 4);
-  constexpr int LDS = (SPLIT ? 1 : 4) * 32 * VT_COLS * (int)sizeof(T) + (BT ? 1024 * 4 + NKF * 16 * 4 : 0);
-  auto kern = window_attn_kernel<T, NKF, SPLIT, BT>;
+  constexpr int LDS = (SPLIT ? 1 : 4) * DH * VT_COLS * (int)sizeof(T) + (BT ? 1024 * 4 + NKF * 16 * 4 : 0) + NKF * 16 * 4;
+  auto kern = window_attn_kernel<T, NKF, SPLIT, BT, DH>;
   static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_mark_device(attr_done_mask);
   }
-  const int n_win = (p.H / p.wsz) * (p.W / p.wsz);
+  const int n_win = (p.H / p.wsz) * (p.W / (p.wsz_x > 0 ? p.wsz_x : p.wsz));
   const int64_t tasks = (int64_t)((n_win + p.pack - 1) / p.pack) * p.heads;
   hipLaunchKernelGGL(kern, dim3((unsigned)(SPLIT ? tasks : (tasks + 3) / 4)), dim3(256), LDS, stream, p);
   WX_HIP(hipGetLastError());
@@ -387,6 +457,31 @@ inline void launch_window_attn(const AttnParams& p, hipStream_t stream, int spli
     case 14: if (bt) launch_window_attn_n<T, 14, false, true>(p, stream); else launch_window_attn_n<T, 14, false>(p, stream); break;
     case 16: if (bt) launch_window_attn_n<T, 16, false, true>(p, stream); else launch_window_attn_n<T, 16, false>(p, stream); break;
     default: throw std::runtime_error("window attention supports at most 256 tokens per window (wsz <= 16)");
+  }
+}
+
+// Window attention with a caller-chosen head dimension (32 / 64 / 96 / 128) and the full [heads][NP][NP] bias table: the Swin /
+// FuXi mode (kind 3, rectangular windows, cyclic shift + seam mask, optional cosine attention).  wx_winattn_* in the C ABI.
+template <typename T, int DH>
+inline void launch_window_attn_dh(const AttnParams& p, hipStream_t stream) {
+  const int wsx = p.wsz_x > 0 ? p.wsz_x : p.wsz;
+  switch (attn_nkf_tokens(p.wsz * wsx * p.pack)) {
+    case 1: launch_window_attn_n<T, 1, false, false, DH>(p, stream); break;
+    case 2: launch_window_attn_n<T, 2, false, false, DH>(p, stream); break;
+    case 4: launch_window_attn_n<T, 4, false, false, DH>(p, stream); break;
+    case 7: launch_window_attn_n<T, 7, false, false, DH>(p, stream); break;
+    case 8: launch_window_attn_n<T, 8, false, false, DH>(p, stream); break;
+    default: throw std::runtime_error("window attention (general head dim): at most 128 tokens per window");
+  }
+}
+template <typename T>
+inline void launch_window_attn_any(const AttnParams& p, int head_dim, hipStream_t stream) {
+  switch (head_dim) {
+    case 32: launch_window_attn_dh<T, 32>(p, stream); break;
+    case 64: launch_window_attn_dh<T, 64>(p, stream); break;
+    case 96: launch_window_attn_dh<T, 96>(p, stream); break;
+    case 128: launch_window_attn_dh<T, 128>(p, stream); break;
+    default: throw std::runtime_error("window attention: head_dim must be 32, 64, 96 or 128");
   }
 }
 

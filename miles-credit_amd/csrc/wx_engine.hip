@@ -1169,6 +1169,7 @@ class Engine : public EngineBase {
     } else {
       if (!qkv_ready) gemm("gemm_qkv", a.qkv, x, h, w, ld, 1, 0, 0, h, w, scratch, 3 * c, rs, 0, nullptr, 0);
       AttnParams p;
+      p.trace = nullptr;
       p.qkv = scratch; p.ld_qkv = 3 * c; p.out = attn_o; p.ld_out = c; p.bias = f_dev + a.bias_tab; p.tb = a.bias_tb >= 0 ? f_dev + a.bias_tb : nullptr;
       p.H = h; p.W = w; p.C = c; p.heads = c / 32; p.wsz = a.wsz; p.kind = attn_kind_override >= 0 ? attn_kind_override : a.kind;
       p.scale = (float)(1.0 / std::sqrt(32.0));   // fp32 engine only: the bf16 engine's q already carries scale * log2(e)
@@ -2428,6 +2429,84 @@ int wx_post_apply(wx_post_handle p, const float* x_dev, float* y_dev, void* stre
 }
 int wx_attach_postblock(wx_handle h, wx_post_handle p) {
   return guarded([&] { WX_NEED(h); h->impl->attach_post(p ? p->impl.get() : nullptr); });
+}
+
+// ---- standalone window attention (the Swin / FuXi mode of the attention kernel) -----------------------
+struct wx_winattn {
+  wx_winattn_desc d;
+  int device = 0;
+  int NP = 0;
+  float* bias_dev = nullptr;     // [n_bias_heads][NP][NP], padded keys -1e30, x log2(e) for bf16
+  float* logit_dev = nullptr;    // [heads] or nullptr
+  int64_t n_bias_stride = 0;     // floats between two heads' tables (0: one table shared by every head)
+  ~wx_winattn() {
+    if (bias_dev) (void)hipFree(bias_dev);
+    if (logit_dev) (void)hipFree(logit_dev);
+  }
+};
+int wx_winattn_create(const wx_winattn_desc* d, const float* bias_host, int n_bias_heads, const float* logit_scale_host, int device,
+                      wx_winattn_handle* out) {
+  return guarded([&] {
+    if (!d || !out) throw wx::ConfigError("null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw wx::HipError("no HIP device visible: wxengine has no CPU fallback");
+    const int wsx = d->wsz_x > 0 ? d->wsz_x : d->wsz_y;
+    if (d->precision != WX_PREC_FP32 && d->precision != WX_PREC_BF16) throw wx::ConfigError("winattn: unknown precision");
+    if (d->head_dim != 32 && d->head_dim != 64 && d->head_dim != 96 && d->head_dim != 128) throw wx::ConfigError("winattn: head_dim must be 32, 64, 96 or 128");
+    if (d->heads < 1 || d->C != d->heads * d->head_dim) throw wx::ConfigError("winattn: C must equal heads * head_dim");
+    if (d->wsz_y < 1 || wsx < 1 || d->H % d->wsz_y || d->W % wsx) throw wx::ConfigError("winattn: the window must divide the token map");
+    if (d->kind != 0 && d->kind != 1 && d->kind != 3) throw wx::ConfigError("winattn: kind must be 0 (block), 1 (dilated) or 3 (shifted block)");
+    if (d->kind == 1 && wsx != d->wsz_y) throw wx::ConfigError("winattn: dilated windows must be square");
+    if (d->kind == 3 && (d->shift_y < 0 || d->shift_y >= d->wsz_y || d->shift_x < 0 || d->shift_x >= wsx)) throw wx::ConfigError("winattn: shift must lie inside the window");
+    const int N = d->wsz_y * wsx;
+    const int nkf = wx::attn_nkf_tokens(N);
+    if (nkf < 0 || nkf > 8) throw wx::ConfigError("winattn: at most 128 tokens per window");
+    if (n_bias_heads != 0 && n_bias_heads != 1 && n_bias_heads != d->heads) throw wx::ConfigError("winattn: bias for 0, 1 or `heads` heads");
+    WX_HIP(hipSetDevice(device));
+    auto w = std::make_unique<wx_winattn>();
+    w->d = *d; w->device = device; w->NP = nkf * 16;
+    const int NP = w->NP, nb = n_bias_heads > 0 ? n_bias_heads : 1;
+    const float l2e = d->precision == WX_PREC_BF16 ? 1.4426950408889634f : 1.0f;   // bf16 softmax runs on exp2
+    std::vector<float> tab((size_t)nb * NP * NP, -1.0e30f);
+    for (int h = 0; h < nb; ++h)
+      for (int q = 0; q < NP; ++q)
+        for (int k = 0; k < N; ++k)
+          tab[((size_t)h * NP + q) * NP + k] = (q < N && bias_host && n_bias_heads > 0) ? bias_host[((size_t)h * N + q) * N + k] * l2e : 0.f;
+    WX_HIP(hipMalloc(&w->bias_dev, tab.size() * sizeof(float)));
+    WX_HIP(hipMemcpy(w->bias_dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    w->n_bias_stride = nb > 1 ? (int64_t)NP * NP : 0;
+    if (logit_scale_host) {
+      std::vector<float> ls(d->heads);
+      for (int h = 0; h < d->heads; ++h) ls[h] = logit_scale_host[h] * l2e;
+      WX_HIP(hipMalloc(&w->logit_dev, ls.size() * sizeof(float)));
+      WX_HIP(hipMemcpy(w->logit_dev, ls.data(), ls.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *out = w.release();
+  });
+}
+int wx_winattn_destroy(wx_winattn_handle w) { return guarded([&] { delete w; }); }
+int wx_winattn_apply(wx_winattn_handle w, const void* qkv_dev, void* out_dev, void* stream) {
+  return guarded([&] {
+    if (!w) throw wx::StateError("null winattn handle");
+    if (!qkv_dev || !out_dev) throw wx::ConfigError("winattn: null tensor pointer");
+    WX_HIP(hipSetDevice(w->device));
+    const wx_winattn_desc& d = w->d;
+    wx::AttnParams p;
+    p.trace = nullptr; p.tb = nullptr; p.pack = 1;
+    p.qkv = qkv_dev; p.ld_qkv = 3 * (int64_t)d.C; p.out = out_dev; p.ld_out = d.C;
+    p.bias = w->bias_dev;
+    p.H = d.H; p.W = d.W; p.C = d.C; p.heads = d.heads; p.wsz = d.wsz_y; p.wsz_x = d.wsz_x > 0 ? d.wsz_x : d.wsz_y; p.kind = d.kind;
+    p.shift_y = d.kind == 3 ? d.shift_y : 0; p.shift_x = d.kind == 3 ? d.shift_x : 0;
+    const float l2e = d.precision == WX_PREC_BF16 ? 1.4426950408889634f : 1.0f;
+    p.mask_val = d.mask_value * l2e;
+    p.logit_scale = w->logit_dev;
+    // scores: cosine mode has its scale in q (logit_scale); otherwise softmax_scale (x log2 e on the exp2 path)
+    p.scale = w->logit_dev ? 1.0f : d.softmax_scale;                                             // fp32 path: scores * scale
+    p.q_scale = (!w->logit_dev && d.precision == WX_PREC_BF16) ? d.softmax_scale * l2e : 0.f;   // bf16 path: scale rides on q
+    p.bias_head_stride = w->n_bias_stride;
+    if (d.precision == WX_PREC_BF16) wx::launch_window_attn_any<wx::bf16_t>(p, d.head_dim, (hipStream_t)stream);
+    else wx::launch_window_attn_any<float>(p, d.head_dim, (hipStream_t)stream);
+  });
 }
 
 const char* wx_last_error(void) { return wx::g_last_error.c_str(); }

@@ -112,6 +112,9 @@ _PROTOTYPES = {
     "wx_post_add_energy_fixer": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_int], C.c_int),
     "wx_post_apply": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "wx_attach_postblock": ([C.c_void_p, C.c_void_p], C.c_int),
+    "wx_winattn_create": ([C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    "wx_winattn_apply": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "wx_winattn_destroy": ([C.c_void_p], C.c_int),
     "wx_last_error": ([], C.c_char_p),
     "wx_version": ([], C.c_char_p),
 }

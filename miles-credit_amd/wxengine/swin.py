@@ -1,0 +1,104 @@
+"""Window attention as an operator of its own: the Swin / FuXi mode of the engine's attention kernel.
+
+`WindowAttention` is the attention CORE of a windowed transformer block -- everything between the qkv projection and the output
+projection of credit/models/swin.py::WindowMultiHeadAttention.forward (:299-330) inside `_shifted_window_attn` (:451-486): cyclic
+shift, window partition, scaled cosine (or dot-product) scores + relative position bias + seam mask, softmax, P V, merge, shift
+back -- on a token-major map resident in HBM, through the C ABI (`wx_winattn_*`).  The FuXi stage (credit/models/fuxi.py:250-260)
+runs the same operator through timm's SwinTransformerV2Stage.  There is no CPU fallback.
+
+`relative_position_bias` / `effective_logit_scale` turn a reference checkpoint's `attn.meta_mlp.*` / `attn.logit_scale` tensors into
+the operator's inputs (swin.py:254-297, :307); they run once at load time on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from .engine import PREC, WXEngineError, _check, load_library
+
+KIND = {"block": 0, "dilated": 1, "shifted": 3}
+
+
+class wx_winattn_desc(C.Structure):
+    _fields_ = [("precision", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32),
+                ("head_dim", C.c_int32), ("wsz_y", C.c_int32), ("wsz_x", C.c_int32), ("kind", C.c_int32), ("shift_y", C.c_int32),
+                ("shift_x", C.c_int32), ("softmax_scale", C.c_float), ("mask_value", C.c_float)]
+
+
+def relative_position_bias(fc1_w, fc1_b, fc2_w, fc2_b, window: Tuple[int, int]) -> np.ndarray:
+    """[heads, N, N] from the meta network's weights (swin.py:254-297: log-spaced relative coordinates -> Linear, ReLU, Linear)."""
+    ys, xs = np.meshgrid(np.arange(window[0]), np.arange(window[1]), indexing="ij")
+    coords = np.stack([ys.ravel(), xs.ravel()]).astype(np.float64)                 # [2, N]
+    rel = (coords[:, :, None] - coords[:, None, :]).transpose(1, 2, 0).reshape(-1, 2)
+    rel = np.sign(rel) * np.log1p(np.abs(rel))
+    h = np.maximum(rel @ np.asarray(fc1_w, np.float64).T + np.asarray(fc1_b, np.float64), 0.0)
+    t = h @ np.asarray(fc2_w, np.float64).T + np.asarray(fc2_b, np.float64)         # [N*N, heads]
+    n = window[0] * window[1]
+    return np.ascontiguousarray(t.T.reshape(-1, n, n), dtype=np.float32)
+
+
+def effective_logit_scale(raw) -> np.ndarray:
+    """swin.py:307: exp(clamp(logit_scale, max = log(1 / 0.01)))."""
+    return np.exp(np.minimum(np.asarray(raw, np.float64), math.log(1.0 / 0.01))).astype(np.float32)
+
+
+class WindowAttention:
+    def __init__(self, feat: Tuple[int, int], heads: int, head_dim: int, window, shift: Sequence[int] = (0, 0), kind: Optional[str] = None,
+                 bias=None, logit_scale=None, softmax_scale: Optional[float] = None, mask_value: float = -100.0,
+                 precision: str = "bf16", device: Optional[int] = None):
+        """bias: [heads, N, N] or [1, N, N] or None; logit_scale: [heads] (already exponentiated) selects cosine attention."""
+        import torch
+        if not torch.cuda.is_available():
+            raise WXEngineError("no GPU visible: window attention has no CPU fallback")
+        self.lib = load_library()
+        ws = (int(window), int(window)) if np.isscalar(window) else (int(window[0]), int(window[1]))
+        self.feat, self.heads, self.head_dim, self.window, self.shift = tuple(feat), heads, head_dim, ws, (int(shift[0]), int(shift[1]))
+        self.precision = precision
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        if kind is None:
+            kind = "shifted" if any(self.shift) else "block"
+        d = wx_winattn_desc(PREC[precision], feat[0], feat[1], heads * head_dim, heads, head_dim, ws[0], ws[1], KIND[kind],
+                            self.shift[0], self.shift[1], float(softmax_scale if softmax_scale is not None else head_dim ** -0.5),
+                            float(mask_value))
+        fp = C.POINTER(C.c_float)
+        n = ws[0] * ws[1]
+        b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32).reshape(-1, n, n)
+        ls = None if logit_scale is None else np.ascontiguousarray(logit_scale, dtype=np.float32).ravel()
+        if ls is not None and ls.size != heads:
+            raise ValueError("logit_scale needs one value per head")
+        self._h = C.c_void_p()
+        self.lib.wx_winattn_create.argtypes = [C.POINTER(wx_winattn_desc), fp, C.c_int, fp, C.c_int, C.POINTER(C.c_void_p)]
+        _check(self.lib.wx_winattn_create(C.byref(d), None if b is None else b.ctypes.data_as(fp), 0 if b is None else b.shape[0],
+                                          None if ls is None else ls.ctypes.data_as(fp), self.device, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self.lib.wx_winattn_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def __call__(self, qkv, out=None):
+        """qkv [H, W, 3C] (or [H*W, 3C]) on the GPU, bf16 / float32 matching `precision`, q | k | v head-major -> [H, W, C]."""
+        import torch
+        want = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        H, W = self.feat
+        c = self.heads * self.head_dim
+        if not (isinstance(qkv, torch.Tensor) and qkv.is_cuda and qkv.dtype == want and qkv.is_contiguous()):
+            raise WXEngineError(f"qkv must be a contiguous {want} tensor on the GPU")
+        if qkv.numel() != H * W * 3 * c or qkv.shape[-1] != 3 * c:
+            raise WXEngineError(f"qkv has shape {tuple(qkv.shape)}, expected [{H}, {W}, {3 * c}]")
+        if qkv.device.index != self.device:
+            raise WXEngineError(f"qkv is on cuda:{qkv.device.index}, the operator was created for cuda:{self.device}")
+        if out is None:
+            out = torch.empty((H, W, c), dtype=want, device=qkv.device)
+        elif not (out.is_cuda and out.dtype == want and out.is_contiguous() and out.numel() == H * W * c):
+            raise WXEngineError("out must be a contiguous tensor of H*W*C elements in the operator's precision")
+        with torch.cuda.device(self.device):
+            _check(self.lib.wx_winattn_apply(self._h, C.c_void_p(qkv.data_ptr()), C.c_void_p(out.data_ptr()),
+                                             C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out

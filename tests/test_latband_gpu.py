@@ -134,6 +134,34 @@ def test_baseline_config4_geometry_eight_ranks_fp32():
     torch.cuda.empty_cache()
 
 
+def test_baseline_config4_geometry_eight_ranks_bf16_vs_unsharded_and_reference_golden():
+    """The same 8-rank split at the BENCHMARK dtype: the sharded bf16 forecast agrees with the unsharded bf16 engine to bf16
+    noise (two bf16 runs that differ in one GroupNorm ulp decorrelate at that level) AND -- in the same test -- with the
+    reference's own fp32 CPU output (tests/golden/model_C3.npz, strided samples + per-channel sums) inside the single-step
+    bf16 bar of tests/test_engine_gpu.py.  Observed: 6.7e-3 vs the unsharded engine, 8.6e-3 vs the reference."""
+    import os
+    cfg = named_config("C3")
+    sd = synth_state_dict(cfg)
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    ref = WXEngine(cfg, "bf16", 0)
+    ref.load_state_dict(sd)
+    ref.finalize()
+    y0 = ref.forward(x).clone()
+    del ref
+    vb = VirtualBands(cfg, sd, 8, "bf16")
+    y, _, _ = vb.step(x)
+    _close(y, y0, "bf16")
+    assert 0.7e9 < vb.exchanged_bytes < 1.8e9
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_C3.npz"))
+    st = int(g["stride"])
+    got = y[0, :, 0, ::st, ::st].double().cpu().numpy()
+    want = g["y"].astype(np.float64)
+    l2 = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert l2 <= 2e-2 and np.abs(got - want).max() <= 5e-2 * np.abs(want).max(), f"sharded bf16 vs reference golden: rel-L2 {l2:.3e}"
+    del vb
+    torch.cuda.empty_cache()
+
+
 def test_sharded_rollout_feeds_bands_back():
     """3 steps: every rank keeps only its own band of x between steps (no gather in the loop)."""
     cfg = named_config("T1")
@@ -318,6 +346,64 @@ def test_two_processes_gloo_on_one_gpu():
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] == 0 and res[0][1] + res[0][2] == res[1][1] and res[1][1] + res[1][2] == cfg.image_height
+    y = torch.from_numpy(np.concatenate([r[3] for r in res], axis=1))
+    xn = torch.from_numpy(np.concatenate([r[4] for r in res], axis=1))
+    _close(y, y0[0, :, 0].cpu(), "fp32")
+    _close(xn, x0[0, :, 0].cpu(), "fp32")
+    assert all(r[5] > 0 for r in res)
+
+
+# ---- two real processes, one GPU each, RCCL inside the engine -----------------------------------------------------------
+def _worker_rccl(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    cfg = named_config("T1")
+    sd = synth_state_dict(cfg)
+    eng = WXEngine(cfg, "fp32", rank)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    _setup(cfg)(eng)
+    db = DistBand(eng)                       # nccl backend -> transport "rccl": grouped ncclSend / ncclRecv issued by the engine
+    assert db.transport == "rccl"
+    r0, rows = db.rows
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    n_dyn = _layout(cfg)[2]
+    frc = torch.from_numpy(synth_forcing(cfg, n_dyn, 1)).cuda()
+    xb = x[0, :, 0, r0:r0 + rows].contiguous()
+    fb = frc[0, :, 0, r0:r0 + rows].contiguous()
+    xn = torch.empty_like(xb)
+    for _ in range(2):                        # twice: the second step reuses the communicator and the staging buffers
+        y, _, xn = db.step(xb, fb, x_next=xn)
+    torch.cuda.synchronize()
+    q.put((rank, r0, rows, y.cpu().numpy(), xn.cpu().numpy(), db.sent_bytes_per_step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_processes_rccl_two_gpus():
+    """The multi-rank branch of wx_band_step_rccl (grouped ncclSend / ncclRecv per exchange, csrc/wx_engine.hip) with a REAL peer
+    over xGMI: every earlier test of that driver ran a communicator of one.  Skipped on the single-GPU boxes of this round."""
+    world = 2
+    cfg = named_config("T1")
+    sd = synth_state_dict(cfg)
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    frc = torch.from_numpy(synth_forcing(cfg, _layout(cfg)[2], 1)).cuda()
+    y0, _, x0 = _reference(cfg, sd, "fp32").step(x, frc, want_phys=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rccl, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

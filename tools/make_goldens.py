@@ -230,6 +230,61 @@ def long_rollout_golden(name, n_steps, stride):
     np.savez_compressed(os.path.join(GOLD, f"rollout_{name}.npz"), **out)
 
 
+def swin_golden():
+    """the shifted-window attention of credit/models/swin.py, run through the reference's OWN code where it is
+    importable here: `SwinTransformerV2CrBlock._make_attention_mask` (:411-427) and `._shifted_window_attn` (:451-486) called on a
+    duck-typed `self`, `window_partition / window_reverse` (:88-118) and `WindowMultiHeadAttention.forward` (:299-330: qkv Linear,
+    scaled cosine attention, logit-scale clamp, mask, softmax, P V).  What is NOT reference code: the position-bias table fed into
+    that forward -- the class computes it with `timm.layers.Mlp`, and timm is neither vendored nor pinned by the reference
+    (SURVEY.md 8(c)), so the table is an input of the fixture (seeded) and the meta-MLP restatement in oracle/swin_oracle.py
+    stays unpinned.  Stored: inputs, the seam mask, and the attention core's output (the tensor entering `proj`), image layout."""
+    import types
+    from credit.models import swin as R
+    out = {}
+    cases = {"rect_shift": ((12, 16), (4, 8), (2, 4), 2, 32), "fuxi_like": ((14, 21), (7, 7), (3, 3), 1, 128),
+             "rect_noshift": ((12, 16), (4, 8), (0, 0), 2, 32), "lat_only_shift": ((16, 12), (8, 4), (5, 0), 3, 32)}
+    for name, (feat, ws, shift, heads, hd) in cases.items():
+        C = heads * hd
+        g = torch.Generator().manual_seed(abs(hash(name)) % 2 ** 31 if False else sum(map(ord, name)))
+        attn = R.WindowMultiHeadAttention.__new__(R.WindowMultiHeadAttention)
+        torch.nn.Module.__init__(attn)
+        attn.in_features, attn.window_size, attn.num_heads, attn.sequential_attn = C, ws, heads, False
+        attn.qkv = torch.nn.Linear(C, 3 * C)
+        attn.proj = torch.nn.Linear(C, C)
+        attn.attn_drop = torch.nn.Identity()
+        attn.proj_drop = torch.nn.Identity()
+        with torch.no_grad():
+            attn.qkv.weight.copy_(torch.randn(3 * C, C, generator=g) / C ** 0.5)
+            attn.qkv.bias.copy_(torch.randn(3 * C, generator=g) * 0.1)
+        attn.logit_scale = torch.nn.Parameter(torch.log(10 * torch.ones(heads)) + torch.randn(heads, generator=g) * 0.3)
+        n = ws[0] * ws[1]
+        bias = torch.randn(heads, n, n, generator=g) * 0.5
+        attn._relative_positional_encodings = lambda b=bias: b.unsqueeze(0)     # the timm-Mlp part: supplied, see the docstring
+        blk = types.SimpleNamespace(feat_size=feat, window_size=ws, shift_size=shift, window_area=n, attn=attn)
+        blk.register_buffer = lambda k, v, persistent=False, b=blk: setattr(b, k, v)
+        R.SwinTransformerV2CrBlock._make_attention_mask(blk)
+        captured = {}
+        h = attn.proj.register_forward_pre_hook(lambda _m, inp: captured.__setitem__("core", inp[0].detach().clone()))
+        x = torch.randn(1, feat[0], feat[1], C, generator=g)
+        with torch.no_grad():
+            R.SwinTransformerV2CrBlock._shifted_window_attn(blk, x)
+        h.remove()
+        core = captured["core"].view(-1, ws[0], ws[1], C)                           # windows of the ROLLED map
+        core = R.window_reverse(core, ws, feat)
+        if any(shift):
+            core = torch.roll(core, shifts=shift, dims=(1, 2))
+        out[f"{name}/x"] = x[0].numpy().astype(np.float32)
+        out[f"{name}/qkv_w"] = attn.qkv.weight.detach().numpy().astype(np.float32)
+        out[f"{name}/qkv_b"] = attn.qkv.bias.detach().numpy().astype(np.float32)
+        out[f"{name}/bias"] = bias.numpy().astype(np.float32)
+        out[f"{name}/logit_scale_raw"] = attn.logit_scale.detach().numpy().astype(np.float32)
+        out[f"{name}/core"] = core[0].numpy().astype(np.float32)
+        out[f"{name}/mask"] = (blk.attn_mask.numpy().astype(np.float32) if blk.attn_mask is not None else np.zeros((0,), np.float32))
+        out[f"{name}/geom"] = np.array([feat[0], feat[1], ws[0], ws[1], shift[0], shift[1], heads, hd], dtype=np.int64)
+        print(f"[golden] swin {name}: feat {feat} ws {ws} shift {shift} heads {heads} hd {hd}  mean|core|={core.abs().mean():.4f}")
+    np.savez_compressed(os.path.join(GOLD, "swin_attention.npz"), **out)
+
+
 def fixer_inputs(seed=11):
     """Physically plausible random fields on the reference's 10x18 / 7-level demo grid.
     x: [T(7) | q(7) | U(7) | V(7)] x 2 frames; y: the same 28 + [TOA solar, TOA OLR, surf solar, surf LR, SH, LH, precip, evapor]."""
@@ -487,7 +542,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,rollC1,rollC3S,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
+    ap.add_argument("--only", default="pad,T0,T1,glue,swin,rollC1,rollC3S,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -496,6 +551,8 @@ def main():
             pad_golden()
         elif item == "glue":
             glue_golden()
+        elif item == "swin":
+            swin_golden()
         elif item == "rollC1":      # BASELINE config 2: 24-step rollout on the 1-degree grid
             long_rollout_golden("C1", 24, 20)
         elif item == "rollC3S":     # 8 steps on the 0.25-degree grid (small-width model)
