@@ -62,7 +62,8 @@ typedef struct wx_config {
   int32_t n_embed_kernels[4];       /* branches per stage (<= 4) */
   int32_t embed_kernels[4][4];      /* cross_embed_kernel_sizes */
   int32_t embed_strides[4];         /* cross_embed_strides */
-  int32_t pad_activate;             /* padding_conf.activate (mode "earth" only) */
+  int32_t pad_activate;             /* padding_conf: 0 off, 1 mode "earth" (pole flip + 180-degree roll, boundary_padding.py:50-72),
+                                       2 mode "mirror" (reflect latitudes, wrap longitudes, :98-117) */
   int32_t pad_lat[2], pad_lon[2];
   int32_t interp;                   /* bilinear resize to (image_height, image_width) */
   int32_t use_spectral_norm;

@@ -71,8 +71,11 @@ __device__ __forceinline__ void cosine_normalise(uint4 (&f)[NS], float mul) {
 // SPLIT = true : the workgroup's four waves share one task -- V^T is staged once by all 256 threads and the query
 //                blocks are dealt round-robin to the waves.  Same work, a quarter of the per-task latency: the
 //                stage-2/3 launches have only 3-6 tasks per SIMD and were bound by the length of one task.
+#ifndef WX_ATTN_MINW
+#define WX_ATTN_MINW 1   // tools/attn_probe: minimum waves per SIMD asked of the register allocator
+#endif
 template <typename T, int NKF, bool SPLIT, bool BT, int DH = 32>
-__global__ __launch_bounds__(256) void window_attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, WX_ATTN_MINW) void window_attn_kernel(const AttnParams p) {
   constexpr int TBN = 1024;  // LDS bias table: [0, (2w-1)^2) the offsets, the rest -1e30 (padded keys index there)
   constexpr int D = DH;      // head dimension: 32 (CrossFormer), up to 128 (FuXi's Swin stage)
   constexpr int NDF = D / 16;

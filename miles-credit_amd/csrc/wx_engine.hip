@@ -429,7 +429,7 @@ class Engine : public EngineBase {
   // 256 output channels is then 16 contiguous KB (full cache lines per LDS-DMA piece instead of half-used ones)
   void pack_kblocked(ConvW& cw) {
     if constexpr (sizeof(T) != 2) return;
-    if (!use_stream || cw.kh != 1 || cw.kw != 1 || cw.n % 256 != 0 || cw.cin % 32 != 0 || cw.cin < 512) return;
+    if (!use_stream || cw.kh != 1 || cw.kw != 1 || cw.n % 128 != 0 || cw.cin % 32 != 0 || cw.cin < 512) return;
     while (wt_host.size() % 8) wt_host.push_back(Elem<T>::from_f(0.f));
     const int64_t off = (int64_t)wt_host.size();
     wt_host.resize(off + (int64_t)cw.n * cw.cin);
@@ -621,6 +621,7 @@ class Engine : public EngineBase {
       a.bias_tab = make_bias_table(p + ".dpb", wsz, c / 4, &a.bias_tb);
     }
     a.out = make_conv(p + ".to_out", 0, c, c, c, 1, 1, true, nullptr, nullptr);
+    pack_kblocked(a.out);
     return a;
   }
   // chunk blocks for ff_fused_kernel, built from the ROUNDED arena weights of w1 / w2 (same values as the unfused path)
@@ -662,6 +663,7 @@ class Engine : public EngineBase {
     f.w1 = make_conv(p + ".layers.1", 0, 4 * c, c, c, 1, 1, true, g.data.data(), b.data.data());
     pack_kblocked(f.w1);
     f.w2 = make_conv(p + ".layers.4", 0, c, 4 * c, 4 * c, 1, 1, true, nullptr, nullptr);
+    pack_kblocked(f.w2);
     if constexpr (sizeof(T) == 2) {
       if (ff_fused_supported(c, 4 * c)) {
         f.pack = pack_ff(f, c, 4 * c);
@@ -802,6 +804,7 @@ class Engine : public EngineBase {
   int ff_min_wgs = 256;         // fused feed-forward only when it yields at least this many workgroups (WX_FF_MIN_WGS)
   float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
+  int last_stat_slots = 0;      // partial slots per row the last statistics-producing gemm() wrote
   int stat_tiles_ready = 0;     // > 0: `statpart` holds partials of the current stream contents (that many per row)
   bool use_patch = true, planar_xin = true;
   double* gn_acc = nullptr;
@@ -1110,7 +1113,23 @@ class Engine : public EngineBase {
       // LayerNorm-folded 1x1 layers with many rows and K >= 512 (to_qkv, FeedForward layer 1 of stages 2-3): the persistent
       // 128 x 256-tile kernel; measured per shape against the 128 x 128 kernel in tools/gemm_stream_probe
       const bool one = w.kh == 1 && w.kw == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && in_h == out_h && in_w == out_w;
-      if (use_stream && use_dma && w.wt_kb >= 0 && one && rs && !res && out_mode == 0 && !want_stats && !want_gn && !dbg_flags &&
+      // residual layers with N = 512 (to_out, FeedForward layer 2 of stage 2): 160 x 128 tiles, two workgroups per CU
+      // (47.9 vs 58.3 us on layer 2, 21.0 vs 23.2 us on to_out; bitwise equal to the 128 x 128 kernel's output)
+      if (use_stream && use_dma && w.wt_kb >= 0 && one && !rs && res && act == 0 && out_mode == 0 && want_stats && fuse_ln && !want_gn &&
+          !dbg_flags && w.n == 512 && w.bias >= 0 && (int64_t)out_h * out_w >= stream_min_rows &&
+          stream_gemm_ok((int64_t)out_h * out_w, w.n, w.cin, 128)) {
+        StreamGemmParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.a = reinterpret_cast<const bf16_t*>(in); q.lda = in_ld; q.w = reinterpret_cast<const bf16_t*>(wt_dev + w.wt_kb);
+        q.M = out_h * out_w; q.N = w.n; q.K = w.cin; q.bias = p.bias;
+        q.res = reinterpret_cast<const bf16_t*>(res); q.res_ld = res_ld;
+        q.stat_out = statpart; q.stat_slots = w.n / 64;
+        q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
+        timed(cls, flops, bytes, [&] { launch_gemm_stream_n128<5, 3, 2>(q, cur_stream); });
+        last_stat_slots = q.stat_slots;
+        return true;
+      }
+      if (use_stream && use_dma && w.wt_kb >= 0 && w.n % 256 == 0 && one && rs && !res && out_mode == 0 && !want_stats && !want_gn && !dbg_flags &&
           (int64_t)out_h * out_w >= stream_min_rows && stream_gemm_ok((int64_t)out_h * out_w, w.n, w.cin)) {
         StreamGemmParams q;
         std::memset(&q, 0, sizeof(q));
@@ -1129,6 +1148,7 @@ class Engine : public EngineBase {
       }
     }
     timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream, gemm_cfg); });
+    last_stat_slots = conv_gemm_n_tiles(w.n);
     return made_stats;
   }
   void upsample2x(const T* in, int h, int w, int64_t in_ld, int c) {
@@ -1181,7 +1201,7 @@ class Engine : public EngineBase {
     capture(dbg_name + ".attn", attn_o, h, w, c, c, w);
     if (defer_out) return;
     const bool st = gemm("gemm_out", a.out, attn_o, h, w, c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld, 0, 0, 0, 0, true);
-    stat_tiles_ready = st ? conv_gemm_n_tiles(c) : 0;
+    stat_tiles_ready = st ? last_stat_slots : 0;
     capture(dbg_name, x, h, w, c, ld, w);
   }
   // The fused feed-forward kernel gives every workgroup 128 (C = 128) or 64 (C = 256) pixels: below one workgroup per CU the
@@ -1217,7 +1237,7 @@ class Engine : public EngineBase {
     const float2* rs = stream_stats(x, ld, c, m);
     gemm("gemm_ff1", f.w1, x, h, w, ld, 1, 0, 0, h, w, scratch, 4 * c, rs, 1, nullptr, 0);
     const bool st = gemm("gemm_ff2", f.w2, scratch, h, w, 4 * c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld, 0, 0, 0, 0, true);
-    stat_tiles_ready = st ? conv_gemm_n_tiles(c) : 0;
+    stat_tiles_ready = st ? last_stat_slots : 0;
     capture(dbg_name, x, h, w, c, ld, w);
   }
   void gn_local_stats(const T* x, int c, int64_t m, bool have_partials) {   // -> gn_acc[2c] (sum, sum sq) in fp64
@@ -1268,6 +1288,7 @@ class Engine : public EngineBase {
     p.pl = cfg.pad_activate ? cfg.pad_lon[0] : 0; p.pr = cfg.pad_activate ? cfg.pad_lon[1] : 0;
     p.halo = halo; p.cpad = cpad0; p.dst_planar = dst_planar; p.Hb = Hb;
     p.row0 = row0; p.src_row0 = src_row0; p.src_rows = src_rows; p.dst_row = dst_row;
+    p.mirror = cfg.pad_activate == 2;
     if (nrows <= 0) return;
     timed("pack_input", 0.0, (double)C_in * nrows * cfg.image_width * 4.0 + (double)nrows * Wp * cpad0 * sizeof(T), [&] {
       hipLaunchKernelGGL(pack_input_kernel<T>, dim3(cdiv(Wp, 64), nrows), dim3(256), 0, cur_stream, p);
@@ -1490,6 +1511,7 @@ class Engine : public EngineBase {
   }
 
   void band_enable(int rank, int n) override {
+    if (cfg.pad_activate == 2) throw ConfigError("lat-band mode supports padding mode 'earth' only (the band plan's pole rows)");
     if (!finalized) throw StateError("wx_band_enable: finalize the weights first");
     if (band_on) throw StateError("wx_band_enable: already enabled");
     if (n < 1 || rank < 0 || rank >= n) throw ConfigError("wx_band_enable: bad rank / nranks");

@@ -78,14 +78,15 @@ __device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt
 // s_waitcnt immediate (gfx9 encoding): vmcnt = n, expcnt / lgkmcnt untouched
 constexpr int wx_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
 
-template <int FM, int NST, bool LN, bool ACT, bool RES, bool STAT>
-__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const StreamGemmParams p) {
-  constexpr int BM = 32 * FM, BN = 256, KB = 64;   // KB: bytes of K per stage row (32 bf16 = one MFMA k step)
+// FN = weight fragments per wave: 8 -> 256-column tiles (two workgroups per CU), 4 -> 128-column tiles for the N = 512 layers
+// (to_out, FeedForward layer 2: twice the tiles, so that every CU still holds two workgroups; OCC of them with a 2-stage ring)
+template <int FM, int NST, bool LN, bool ACT, bool RES, bool STAT, int FN = 8, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void gemm_stream_kernel(const StreamGemmParams p) {
+  constexpr int BM = 32 * FM, BN = 32 * FN, KB = 64;   // KB: bytes of K per stage row (32 bf16 = one MFMA k step)
   constexpr int A_TOT = BM / 16;                   // DMA instructions per stage for the activation rows (16 rows each)
   constexpr int A_I = (A_TOT + 3) / 4;             // ... per wave (waves with index >= A_TOT % 4 issue one fewer when A_TOT % 4 != 0)
   constexpr int B_I = BN / 64;
   constexpr int STAGE = (BM + BN) * KB;
-  constexpr int FN = 8;                            // weight fragments per wave (128 channels)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_par = reinterpret_cast<float*>(smem + NST * STAGE);   // bias[256] | colsum[256]
 
@@ -105,8 +106,10 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const StreamGemmPar
   const int total = n_my * nk;
 
   // epilogue parameters of the N-tile: staged once (visible after the first ring barrier)
-  s_par[tid] = p.bias ? p.bias[n_blk + tid] : 0.f;
-  s_par[256 + tid] = LN ? p.colsum[n_blk + tid] : 0.f;
+  if (tid < BN) {
+    s_par[tid] = p.bias ? p.bias[n_blk + tid] : 0.f;
+    s_par[BN + tid] = LN ? p.colsum[n_blk + tid] : 0.f;
+  }
 
   // ---- DMA coordinates -----------------------------------------------------------------------------
   const int lrow = lane >> 2, lslot = lane & 3;
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const StreamGemmPar
   // activations (MFMA B operand): row wm*16*FM + b*16 + li, slot g ^ swz(li)
   // weights (MFMA A operand): MFMA row li of fragment a = weight row wn*128 + (a>>1)*32 + (li>>2)*8 + (a&1)*4 + (li&3)
   const int x_base = (wm * 16 * FM + li) * KB + ((g ^ (3 * ((li >> 3) & 1))) << 4);
-  const int w_base_l = BM * KB + (wn * 128 + (li >> 2) * 8 + (li & 3)) * KB + ((g ^ (3 * ((li >> 2) & 1))) << 4);
+  const int w_base_l = BM * KB + (wn * (16 * FN) + (li >> 2) * 8 + (li & 3)) * KB + ((g ^ (3 * ((li >> 2) & 1))) << 4);
 
   f32x4_t acc[FN][FM];
 #pragma unroll
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const StreamGemmPar
   };
   // (mean, rstd) of tile r's rows -> LDS slot r & 1, one row per thread.  Called in the prologue for the first tile and at the END
   // of epilogue r for tile r + 1 (its readers are >= nk ring barriers away; the other slot may still be read by slower waves)
-  float2* s_stat = reinterpret_cast<float2*>(s_par + 512);
+  float2* s_stat = reinterpret_cast<float2*>(s_par + 2 * BN);
   auto stage_stats = [&](int r) {
     if constexpr (LN) {
       if (tid < BM) {
@@ -226,14 +229,14 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const StreamGemmPar
     for (int b = 0; b < FM; ++b) s1[b] = s2[b] = 0.f;
 #pragma unroll
     for (int ap = 0; ap < FN / 2; ++ap) {
-      const int cl = wn * 128 + ap * 32 + g * 8;   // channel inside the N-tile
+      const int cl = wn * (16 * FN) + ap * 32 + g * 8;   // channel inside the N-tile
       float bs[8], cs[8];
       {
         const float4 t0 = *reinterpret_cast<const float4*>(s_par + cl), t1 = *reinterpret_cast<const float4*>(s_par + cl + 4);
         bs[0] = t0.x; bs[1] = t0.y; bs[2] = t0.z; bs[3] = t0.w; bs[4] = t1.x; bs[5] = t1.y; bs[6] = t1.z; bs[7] = t1.w;
       }
       if constexpr (LN) {
-        const float4 t0 = *reinterpret_cast<const float4*>(s_par + 256 + cl), t1 = *reinterpret_cast<const float4*>(s_par + 256 + cl + 4);
+        const float4 t0 = *reinterpret_cast<const float4*>(s_par + BN + cl), t1 = *reinterpret_cast<const float4*>(s_par + BN + cl + 4);
         cs[0] = t0.x; cs[1] = t0.y; cs[2] = t0.z; cs[3] = t0.w; cs[4] = t1.x; cs[5] = t1.y; cs[6] = t1.z; cs[7] = t1.w;
       }
       uint4 rv[FM];
@@ -400,10 +403,10 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const StreamGemmPar
 inline int stream_gemm_bm(int fm) { return 32 * fm; }
 
 // grid geometry: per XCD nt * S blocks (S M-tile slots), at most 64 (two workgroups on each of the 32 CUs)
-inline void stream_gemm_geometry(StreamGemmParams& p, int fm, int max_per_xcd = 64) {
+inline void stream_gemm_geometry(StreamGemmParams& p, int fm, int max_per_xcd = 64, int bn = 256) {
   const int bm = 32 * fm;
   p.mt = cdiv(p.M, bm);
-  p.nt = p.N / 256;
+  p.nt = p.N / bn;
   int s = max_per_xcd / p.nt;
   if (s < 1) s = 1;
   const int need = cdiv(p.mt, 8);
@@ -413,23 +416,23 @@ inline void stream_gemm_geometry(StreamGemmParams& p, int fm, int max_per_xcd = 
 
 inline int& stream_gemm_max_per_xcd() { static int v = 64; return v; }   // probe knob: 32 = one workgroup per CU
 
-template <int FM, int NST, bool LN, bool ACT, bool RES, bool STAT>
+template <int FM, int NST, bool LN, bool ACT, bool RES, bool STAT, int FN = 8, int OCC = 2>
 inline void launch_gemm_stream_v(StreamGemmParams p, hipStream_t stream) {
-  constexpr int LDS = NST * (32 * FM + 256) * 64 + 2048 + 2 * 32 * FM * 8;   // ring | bias, colsum | two slots of row statistics
-  auto kern = gemm_stream_kernel<FM, NST, LN, ACT, RES, STAT>;
+  constexpr int LDS = NST * (32 * FM + 32 * FN) * 64 + 2 * 32 * FN * 4 + 2 * 32 * FM * 8;   // ring | bias, colsum | two slots of row statistics
+  auto kern = gemm_stream_kernel<FM, NST, LN, ACT, RES, STAT, FN, OCC>;
   static uint64_t attr_done_mask = 0;
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_mark_device(attr_done_mask);
   }
-  stream_gemm_geometry(p, FM, stream_gemm_max_per_xcd());
+  stream_gemm_geometry(p, FM, stream_gemm_max_per_xcd() * OCC / 2, 32 * FN);
   const unsigned grid = 8u * p.nt * p.s_per_xcd;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, p);
   WX_HIP(hipGetLastError());
 }
 
 // shapes this kernel takes
-inline bool stream_gemm_ok(int64_t M, int N, int K) { return N % 256 == 0 && N <= 16384 && K % 32 == 0 && M >= 1; }
+inline bool stream_gemm_ok(int64_t M, int N, int K, int bn = 256) { return N % bn == 0 && N <= 16384 && K % 32 == 0 && M >= 1; }
 
 // variant: 0 = plain (bias), 1 = LN fold, 2 = LN fold + GELU, 3 = bias + residual + row partials
 template <int FM, int NST>
@@ -441,6 +444,11 @@ inline void launch_gemm_stream(const StreamGemmParams& p, int variant, hipStream
     case 3: launch_gemm_stream_v<FM, NST, false, false, true, true>(p, stream); break;
     default: throw std::runtime_error("gemm_stream: unknown epilogue variant");
   }
+}
+// the 128-column tiles of the residual layers (variant 3 only)
+template <int FM, int NST, int OCC>
+inline void launch_gemm_stream_n128(const StreamGemmParams& p, hipStream_t stream) {
+  launch_gemm_stream_v<FM, NST, false, false, true, true, 4, OCC>(p, stream);
 }
 
 }  // namespace wx

@@ -97,8 +97,10 @@ class WXConfig:
             raise ValueError("decoder attention_type is not supported by the engine")
         if len(self.dim) != 4 or len(self.depth) != 4:
             raise ValueError("dim/depth must have 4 stages")
-        if self.pad_activate and self.pad_mode != "earth":
-            raise ValueError("only padding mode 'earth' is supported by the engine")
+        if self.pad_activate and self.pad_mode not in ("earth", "mirror"):
+            raise ValueError("padding mode must be 'earth' or 'mirror' (credit/boundary_padding.py:16-22)")
+        if self.pad_activate and self.pad_mode == "mirror" and max(self.pad_lat) >= self.image_height:
+            raise ValueError("mirror padding: pad_lat must be smaller than the image height (reflect padding)")
         for s, (h, w) in enumerate(self.stage_hw):
             for kind, wsz in (("local", self.local_window_size[s]), ("global", self.global_window_size[s])):
                 if h % wsz or w % wsz:
@@ -294,7 +296,11 @@ def named_config(name: str) -> WXConfig:
     base = dict(frames=1, channels=4, surface_channels=4, input_only_channels=4, output_only_channels=8,
                 patch_width=1, patch_height=1, cross_embed_kernel_sizes=[[4, 8, 16, 32], [2, 4], [2, 4], [2, 4]],
                 cross_embed_strides=[2, 2, 2, 2], interp=True, use_spectral_norm=True)
-    if name == "T0":  # tiny: odd padded height (49 -> 24), asymmetric-free pads, all branches exercised
+    if name == "T0M":  # T0 with padding mode "mirror" (credit/boundary_padding.py:98-117): reflect latitudes, wrap longitudes
+        mc = dict(base, image_height=37, image_width=72, levels=3, output_only_channels=3,
+                  dim=[32, 64, 128, 256], depth=[1, 1, 2, 1], global_window_size=[4, 2, 2, 1], local_window_size=3,
+                  padding_conf=dict(activate=True, mode="mirror", pad_lat=[5, 7], pad_lon=[12, 12]))
+    elif name == "T0":  # tiny: odd padded height (49 -> 24), asymmetric-free pads, all branches exercised
         mc = dict(base, image_height=37, image_width=72, levels=3, output_only_channels=3,
                   dim=[32, 64, 128, 256], depth=[1, 1, 2, 1], global_window_size=[4, 2, 2, 1], local_window_size=3,
                   padding_conf=dict(activate=True, mode="earth", pad_lat=[6, 6], pad_lon=[12, 12]))

@@ -182,7 +182,7 @@ def make_c_config(cfg: WXConfig, precision: str = "bf16", max_batch: int = 1) ->
         for j, k in enumerate(ks):
             c.embed_kernels[i][j] = k
         c.embed_strides[i] = cfg.cross_embed_strides[i]
-    c.pad_activate = int(cfg.pad_activate)
+    c.pad_activate = (2 if getattr(cfg, "pad_mode", "earth") == "mirror" else 1) if cfg.pad_activate else 0
     c.pad_lat[0], c.pad_lat[1] = cfg.pad_lat
     c.pad_lon[0], c.pad_lon[1] = cfg.pad_lon
     c.interp = int(cfg.interp)

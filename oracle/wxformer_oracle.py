@@ -107,6 +107,18 @@ def earth_pad(x: Tensor, pad_lat, pad_lon) -> Tensor:
     return x[..., src_r, src_c]
 
 
+def mirror_pad(x: Tensor, pad_lat, pad_lon) -> Tensor:
+    """credit/boundary_padding.py:98-117 (mode "mirror"): circular pad in longitude, then reflect pad in latitude (the edge
+    row is not repeated); no pole roll.  x [..., H, W] -> [..., H+p0+p1, W+pl+pr]."""
+    h, w = x.shape[-2:]
+    p0, p1 = pad_lat
+    pl, pr = pad_lon
+    i = torch.arange(h + p0 + p1)
+    src_r = torch.where(i < p0, p0 - i, torch.where(i >= p0 + h, h - 2 - (i - p0 - h), i - p0))
+    src_c = (torch.arange(w + pl + pr) - pl) % w
+    return x[..., src_r.view(-1, 1), src_c.view(1, -1)]
+
+
 def earth_unpad(x: Tensor, pad_lat, pad_lon) -> Tensor:
     # credit/boundary_padding.py:74-96
     h, w = x.shape[-2:]
@@ -359,7 +371,7 @@ def forward(cfg, sd: Dict, x, dtype=torch.float32, capture: Optional[Dict] = Non
     if x.dim() == 4:
         x = x.unsqueeze(2)
     if cfg.pad_activate:
-        x = earth_pad(x, cfg.pad_lat, cfg.pad_lon)
+        x = (mirror_pad if getattr(cfg, "pad_mode", "earth") == "mirror" else earth_pad)(x, cfg.pad_lat, cfg.pad_lon)
     b, c, t, h, w = x.shape
     x = x.reshape(b, c * t, h, w)  # frames==1: squeeze(2); frames>1: channel-major then time (:604-609)
     if capture is not None:

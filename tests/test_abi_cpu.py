@@ -107,8 +107,12 @@ def test_config_validation_errors():
     assert up.state_spec()["up_block1.conv.weight_orig"] == (128, 256, 3, 3) and "up_block4.1.weight_orig" in up.state_spec()
     with pytest.raises(ValueError):  # the flag belongs to the legacy class only
         WXConfig.from_model_conf(dict(base, upsample_v_conv=True), arch="wxformer")
+    mir = WXConfig.from_model_conf(dict(base, padding_conf=dict(activate=True, mode="mirror", pad_lat=[6, 6], pad_lon=[12, 12])))
+    assert mir.pad_mode == "mirror" and E.make_c_config(mir, "bf16").pad_activate == 2 and E.make_c_config(WXConfig.from_model_conf(base)).pad_activate == 1
     with pytest.raises(ValueError):
-        WXConfig.from_model_conf(dict(base, padding_conf=dict(activate=True, mode="mirror", pad_lat=[6, 6], pad_lon=[12, 12])))
+        WXConfig.from_model_conf(dict(base, padding_conf=dict(activate=True, mode="zeros", pad_lat=[6, 6], pad_lon=[12, 12])))
+    with pytest.raises(ValueError):   # reflect padding needs pad < height
+        WXConfig.from_model_conf(dict(base, padding_conf=dict(activate=True, mode="mirror", pad_lat=[37, 6], pad_lon=[12, 12])))
     with pytest.raises(ValueError):
         WXConfig.from_model_conf(dict(base, patch_height=2, patch_width=2))
 
@@ -135,7 +139,7 @@ def test_synthetic_weights_are_deterministic_and_warm():
 @pytest.mark.reference
 def test_state_spec_equals_reference_state_dict():
     import make_goldens
-    for name in ("T0", "T1", "T0W", "T0U"):
+    for name in ("T0", "T1", "T0W", "T0U", "T0M"):
         cfg = named_config(name)
         m = make_goldens.reference_model(cfg)
         ref = {k: tuple(v.shape) for k, v in m.state_dict().items()}

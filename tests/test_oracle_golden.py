@@ -42,10 +42,24 @@ def test_earth_pad_asymmetric_181x360():
     np.testing.assert_allclose(pb.double().sum(dim=(0, 2, 3, 4)).numpy(), g["big_pad_sum"], rtol=1e-12)
 
 
+def test_mirror_pad_matches_reference():
+    """padding mode "mirror" (credit/boundary_padding.py:98-134): reflect in latitude, wrap in longitude."""
+    g = _load("earth_pad.npz")
+    x = torch.from_numpy(g["small_x"])
+    np.testing.assert_array_equal(O.mirror_pad(x, (3, 2), (4, 3)).numpy(), g["small_mirror"])
+    rng = np.random.Generator(np.random.Philox(key=[7, 7]))
+    rng.standard_normal((1, 2, 1, 7, 10), dtype=np.float32)
+    big = torch.from_numpy(rng.standard_normal((1, 3, 1, 181, 360), dtype=np.float32))
+    pm = O.mirror_pad(big, (12, 34), (56, 78))
+    np.testing.assert_array_equal(pm[0, :, 0, ::7, ::11].numpy(), g["big_mirror_strided"])
+    np.testing.assert_allclose(pm.double().sum(dim=(0, 2, 3, 4)).numpy(), g["big_mirror_sum"], rtol=1e-12)
+    np.testing.assert_array_equal(O.earth_unpad(pm, (12, 34), (56, 78)).numpy(), big.numpy())
+
+
 _SLOW = os.environ.get("WX_SLOW", "0") == "1"
 
 
-@pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W", "T0U", "RT",
+@pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W", "T0U", "T0M", "RT",
                                   pytest.param("C3", marks=pytest.mark.skipif(
                                       not _SLOW, reason="~1.5 min of CPU; set WX_SLOW=1"))])
 def test_forward_matches_reference_golden(name):

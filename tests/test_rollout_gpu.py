@@ -5,7 +5,11 @@
     the reference's own pieces (fp32 CPU), with the fp64 oracle's trajectory stored beside it.  The reference's fp32 arithmetic itself
     drifts from fp64 along the trajectory (`ref_vs_fp64_rel_l2[t]`), so the bar for step t is stated relative to that:
         fp32 engine:  rel-L2(engine, reference)[t] <= max(1e-4 * t, 4 * ref_vs_fp64_rel_l2[t])
-        bf16 engine:  rel-L2(engine, reference)[t] <= BF16_STEP1 * growth(t)   (bound stated below; reported in the test output)
+        bf16 engine:  rel-L2(engine, reference)[t] <= 2e-2 at EVERY step (the single-step bf16 bar, no growth allowance)
+    Measured (MI355X): fp32 2.1e-6 .. 2.4e-6 at all 24 steps (the reference itself sits 1.0e-6 from fp64); bf16 8.0e-3 at t = 1,
+    1.11e-2 at t = 2, then flat at 1.15e-2 .. 1.17e-2 -- with these name-keyed synthetic weights the model contracts perturbations,
+    so the per-step rounding error saturates instead of compounding.  Trained weights need not contract; the fixture documents the
+    engine, not the forecast model.
 """
 import os
 
@@ -86,8 +90,7 @@ def test_wx_rollout_argument_errors():
         eng.step(x0, frc, phys_out=torch.empty((1, cfg.base_output_channels, 3, 3), device="cuda"))
 
 
-BF16_STEP1 = 2e-2           # the single-step bf16 bar of tests/test_engine_gpu.py
-BF16_GROWTH = 1.25          # allowed per-step growth factor of the bf16 trajectory error (measured: see the printed table)
+BF16_BOUND = 2e-2           # the single-step bf16 bar of tests/test_engine_gpu.py, held at every step of the rollout
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -116,4 +119,4 @@ def test_24_step_rollout_on_the_1_degree_grid_vs_reference_trajectory(prec):
         if prec == "fp32":
             assert rel[t] <= max(1e-4 * (t + 1), 4.0 * floor[t]), f"fp32 step {t + 1}: {rel[t]:.3e} (floor {floor[t]:.3e})"
         else:
-            assert rel[t] <= BF16_STEP1 * BF16_GROWTH ** t, f"bf16 step {t + 1}: rel-L2 {rel[t]:.3e}"
+            assert rel[t] <= BF16_BOUND, f"bf16 step {t + 1}: rel-L2 {rel[t]:.3e}"

@@ -6,8 +6,10 @@
 #include <cstring>
 #include <random>
 #include <vector>
+#ifndef WX_ATTN_NOTRACE
 #define WX_GEMM_TRACE 1
 #define WX_ATTN_TRACE 1
+#endif
 #include "wx_attn.h"
 using namespace wx;
 static void* dalloc(size_t n) { void* p; WX_HIP(hipMalloc(&p, n)); return p; }
@@ -39,6 +41,9 @@ int main(int argc, char** argv) {
   WX_HIP(hipEventRecord(e1, st)); WX_HIP(hipStreamSynchronize(st));
   float ms; WX_HIP(hipEventElapsedTime(&ms, e0, e1));
   printf("H=%d W=%d C=%d wsz=%d kind=%d tasks=%zu nkf=%d: %.1f us\n", H, W, C, wsz, kind, tasks, nkf, ms * 1e3 / 20);
+#ifdef WX_ATTN_NOTRACE
+  return 0;
+#endif
   unsigned long long* tr = (unsigned long long*)dalloc(tasks * 64);
   WX_HIP(hipMemset(tr, 0, tasks * 64));
   p.trace = tr;

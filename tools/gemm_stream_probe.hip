@@ -140,6 +140,11 @@ int main(int argc, char** argv) {
     auto run_53 = [&] { launch_gemm_stream<5, 3>(q, s.variant, st); };
     auto run_52 = [&] { launch_gemm_stream<5, 2>(q, s.variant, st); };
     auto run_43 = [&] { launch_gemm_stream<4, 3>(q, s.variant, st); };
+    StreamGemmParams q4 = q;
+    q4.stat_slots = 2 * (N / 128);
+    auto run_n128_a = [&] { launch_gemm_stream_n128<5, 3, 2>(q4, st); };
+    auto run_n128_b = [&] { launch_gemm_stream_n128<5, 2, 4>(q4, st); };
+    auto run_n128_c = [&] { launch_gemm_stream_n128<4, 3, 3>(q4, st); };
 
     run_old();
     run_53();
@@ -265,6 +270,27 @@ int main(int argc, char** argv) {
       WX_HIP(hipFree(tr));
     }
 #endif
+    if (res && N % 128 == 0) {   // 128-column tiles for the residual layers: parity vs the 256-column kernel (same k order: bitwise), timing
+      double t_a = 1e30, t_b = 1e30, t_c = 1e30;
+      int bad128 = 0;
+      for (int v = 0; v < 3; ++v) {
+        WX_HIP(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, st));
+        if (v == 0) run_n128_a(); else if (v == 1) run_n128_b(); else run_n128_c();
+        WX_HIP(hipStreamSynchronize(st));
+        WX_HIP(hipMemcpy(h2.data(), y1, h2.size() * 2, hipMemcpyDeviceToHost));
+        unblock(h2);
+        if (std::memcmp(h1.data(), h2.data(), h1.size() * 2) != 0) ++bad128;
+      }
+      for (int round = 0; round < 3; ++round) {
+        t_a = std::min(t_a, time_us(st, 20, run_n128_a));
+        t_b = std::min(t_b, time_us(st, 20, run_n128_b));
+        t_c = std::min(t_c, time_us(st, 20, run_n128_c));
+      }
+      const double f2 = 2.0 * M * N * K * 1e-6;
+      printf("    128-col tiles: 160x128 nst3 occ2 %7.1f us %5.0f TF | 160x128 nst2 occ4 %7.1f us %5.0f TF | 128x128 nst3 occ3 %7.1f us %5.0f TF | mismatching variants %d\n",
+             t_a, f2 / t_a, t_b, f2 / t_b, t_c, f2 / t_c, bad128);
+      if (bad128) ++bad;
+    }
     const double fl = 2.0 * M * N * K * 1e-6;
     printf("%-20s M=%6d N=%5d K=%5d | old %7.1f us %5.0f TF | 160x256 nst3 %7.1f us %5.0f TF | nst2 %7.1f us %5.0f TF | 128x256 nst3 %7.1f us %5.0f TF\n",
            s.name, M, N, K, t_old, fl / t_old, t53, fl / t53, t52, fl / t52, t43, fl / t43);

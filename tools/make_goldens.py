@@ -44,7 +44,7 @@ def reference_model(cfg, post_conf=None):
         local_window_size=cfg.local_window_size[0], cross_embed_kernel_sizes=cfg.cross_embed_kernel_sizes,
         cross_embed_strides=cfg.cross_embed_strides, use_spectral_norm=cfg.use_spectral_norm, interp=cfg.interp,
         **({"upsample_v_conv": True} if getattr(cfg, "upsample_v_conv", False) else {}),
-        padding_conf={"activate": cfg.pad_activate, "mode": "earth", "pad_lat": list(cfg.pad_lat),
+        padding_conf={"activate": cfg.pad_activate, "mode": getattr(cfg, "pad_mode", "earth"), "pad_lat": list(cfg.pad_lat),
                       "pad_lon": list(cfg.pad_lon)},
         post_conf=post_conf or {"activate": False})
     sd = synth_state_dict(cfg)
@@ -130,8 +130,16 @@ def pad_golden():
     out["big_pad_strided"] = pb[0, :, 0, ::7, ::11].numpy()
     out["big_pad_sum"] = pb.double().sum(dim=(0, 2, 3, 4)).numpy()
     out["big_pad_shape"] = np.array(pb.shape)
+    # mode "mirror" (boundary_padding.py:98-134) on the same shapes
+    tm = TensorPadding(mode="mirror", pad_lat=[3, 2], pad_lon=[4, 3])
+    out["small_mirror"] = tm.pad(small).numpy()
+    tm2 = TensorPadding(mode="mirror", pad_lat=[12, 34], pad_lon=[56, 78])
+    pm = tm2.pad(big)
+    assert torch.equal(tm2.unpad(pm), big)
+    out["big_mirror_strided"] = pm[0, :, 0, ::7, ::11].numpy()
+    out["big_mirror_sum"] = pm.double().sum(dim=(0, 2, 3, 4)).numpy()
     np.savez_compressed(os.path.join(GOLD, "earth_pad.npz"), **out)
-    print("[golden] earth_pad:", tuple(pb.shape))
+    print("[golden] earth_pad + mirror:", tuple(pb.shape), tuple(pm.shape))
 
 
 def glue_conf(cfg, n_static=2, n_dyn=2):
@@ -542,7 +550,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,swin,rollC1,rollC3S,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
+    ap.add_argument("--only", default="pad,T0,T1,glue,swin,rollC1,rollC3S,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -573,7 +581,7 @@ def main():
             reconstruct_golden()
         elif item == "asm":
             assemble_golden()
-        elif item in ("T0", "T1", "T0W", "T0U"):
+        elif item in ("T0", "T1", "T0W", "T0U", "T0M"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "RT":   # the model of the reference's own tests/test_crossformer.py
             model_golden(item, 2, False)

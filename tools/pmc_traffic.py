@@ -14,7 +14,7 @@ from collections import defaultdict
 
 def family(name):
     name = name.replace("void ", "")
-    for key in ("conv_gemm_dma_kernel", "conv_gemm_kernel", "ff_fused_kernel", "window_attn_kernel", "embed_patch_kernel"):
+    for key in ("gemm_stream_kernel", "conv_gemm_dma_kernel", "conv_gemm_kernel", "ff_fused_kernel", "window_attn_kernel", "embed_patch_kernel"):
         if key in name:
             return "wx::" + key
     return name.split("(")[0][:60]
