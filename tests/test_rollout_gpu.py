@@ -94,13 +94,17 @@ BF16_BOUND = 2e-2           # the single-step bf16 bar of tests/test_engine_gpu.
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_24_step_rollout_on_the_1_degree_grid_vs_reference_trajectory(prec):
-    path = os.path.join(GOLD, "rollout_C1.npz")
+@pytest.mark.parametrize("name", ["C1", "C3S"])
+def test_full_length_rollout_vs_reference_trajectory(name, prec):
+    """C1: BASELINE config 2 (24 steps on the 1-degree grid).  C3S: 8 steps on the 0.25-degree grid (721 x 1440, the small-width
+    model of credit_smoke_test_v2_025deg.yml) -- reference trajectory only: torch's fp64 CPU convolution of the k = 32 CrossEmbed
+    branch needs 157 GB at that size, so the fp64 floor of that fixture is NaN and the fp32 gate is 1e-4 * t alone."""
+    path = os.path.join(GOLD, f"rollout_{name}.npz")
     if not os.path.isfile(path):
-        pytest.skip("tests/golden/rollout_C1.npz not generated yet (tools/make_goldens.py --only rollC1)")
+        pytest.skip(f"tests/golden/rollout_{name}.npz not generated (tools/make_goldens.py --only roll{name})")
     g = np.load(path)
     n, s = int(g["n_steps"]), int(g["stride"])
-    cfg, eng = make_engine("C1", prec, tracer=(g["tracer_inds"], g["tracer_thres"]))
+    cfg, eng = make_engine(name, prec, tracer=(g["tracer_inds"], g["tracer_thres"]))
     x0 = torch.from_numpy(synth_input(cfg)).cuda()
     frcs = [torch.from_numpy(synth_forcing(cfg, 2, t + 1)).cuda() for t in range(n)]
     ys, x = [], x0
@@ -111,12 +115,13 @@ def test_24_step_rollout_on_the_1_degree_grid_vs_reference_trajectory(prec):
     ref, o64, floor = g["y"].astype(np.float64), g["y64"].astype(np.float64), g["ref_vs_fp64_rel_l2"]
     rel = [float(np.linalg.norm(ys[t] - ref[t]) / np.linalg.norm(ref[t])) for t in range(n)]
     rel64 = [float(np.linalg.norm(ys[t] - o64[t]) / np.linalg.norm(o64[t])) for t in range(n)]
-    print(f"\\n{prec} engine, C1, {n}-step rollout: rel-L2 per step vs the reference trajectory | vs the fp64 oracle | reference vs fp64")
+    print(f"\n{prec} engine, {name}, {n}-step rollout: rel-L2 per step vs the reference trajectory | vs the fp64 oracle | reference vs fp64")
     for t in range(n):
         print(f"  t={t + 1:2d}  {rel[t]:.3e}  {rel64[t]:.3e}  {floor[t]:.3e}")
     assert all(np.isfinite(v) for v in rel)
     for t in range(n):
         if prec == "fp32":
-            assert rel[t] <= max(1e-4 * (t + 1), 4.0 * floor[t]), f"fp32 step {t + 1}: {rel[t]:.3e} (floor {floor[t]:.3e})"
+            bound = 1e-4 * (t + 1) if np.isnan(floor[t]) else max(1e-4 * (t + 1), 4.0 * floor[t])
+            assert rel[t] <= bound, f"fp32 step {t + 1}: {rel[t]:.3e} (bound {bound:.3e})"
         else:
             assert rel[t] <= BF16_BOUND, f"bf16 step {t + 1}: rel-L2 {rel[t]:.3e}"
