@@ -24,6 +24,13 @@ def credit_models():
     if REF not in sys.path:
         sys.path.insert(0, REF)
     import credit.models as cm
+    # wxengine.model picks its base class when it is first imported; an earlier test may have imported it before `credit` was
+    # importable (plain nn.Module then) -- re-import it now that the reference is on the path, as a maintainer's process would
+    import importlib
+    import wxengine.model as wm
+    from credit.models.base_model import BaseModel
+    if not issubclass(wm.WXFormerHIP, BaseModel):
+        importlib.reload(wm)
     return cm
 
 
