@@ -71,11 +71,21 @@ __device__ __forceinline__ void cosine_normalise(uint4 (&f)[NS], float mul) {
 // SPLIT = true : the workgroup's four waves share one task -- V^T is staged once by all 256 threads and the query
 //                blocks are dealt round-robin to the waves.  Same work, a quarter of the per-task latency: the
 //                stage-2/3 launches have only 3-6 tasks per SIMD and were bound by the length of one task.
+// Register budget.  Left alone, hipcc parks the accumulators in AGPRs and the 100-token bf16 kernel lands on 153 + 24
+// registers = 2 waves per SIMD.  The kernel is a chain of dependent softmax steps that only OTHER waves can hide, so
+// occupancy is what it is bound by (tools/attn_probe, stage-0 launch): 2 waves 151 us -> 3 waves (152 VGPRs, asked for
+// through __launch_bounds__) 121 us -> 4 waves 115 us.  128 registers are only reachable without spills when the V^T
+// fragments (32 registers) are re-read from the wave's LDS slice in every query block (VLDS below) instead of living in
+// registers.  The f32 kernels and window shapes with more key fragments would spill and keep the free budget.
 #ifndef WX_ATTN_MINW
-#define WX_ATTN_MINW 1   // tools/attn_probe: minimum waves per SIMD asked of the register allocator
+#define WX_ATTN_MINW 4
 #endif
+#ifndef WX_ATTN_VLDS
+#define WX_ATTN_VLDS 1
+#endif
+constexpr int attn_min_waves(int nkf, int dh, int elem) { return (elem == 2 && nkf <= 8 && dh <= 32) ? WX_ATTN_MINW : 1; }
 template <typename T, int NKF, bool SPLIT, bool BT, int DH = 32>
-__global__ __launch_bounds__(256, WX_ATTN_MINW) void window_attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void window_attn_kernel(const AttnParams p) {
   constexpr int TBN = 1024;  // LDS bias table: [0, (2w-1)^2) the offsets, the rest -1e30 (padded keys index there)
   constexpr int D = DH;      // head dimension: 32 (CrossFormer), up to 128 (FuXi's Swin stage)
   constexpr int NDF = D / 16;
@@ -210,19 +220,25 @@ __global__ __launch_bounds__(256, WX_ATTN_MINW) void window_attn_kernel(const At
   AT_TICK(at1);
 
   constexpr int NVF = (sizeof(T) == 2) ? NKB : NKF;
-  uint4 vf[NDF][NVF];
+  // V^T fragments: resident in registers, or (VLDS) re-read from the wave's LDS slice in every query block -- 16 ds_read_b64
+  // per block against ~350 instructions, and 32 registers fewer
+  constexpr bool VLDS = WX_ATTN_VLDS && sizeof(T) == 2 && NKF >= 7 && NKF <= 8 && DH == 32;
+  auto read_vf = [&](int df, int b, int opaque = 0) -> uint4 {
+    const T* row = vt + (df * 16 + li) * VT_COLS + opaque;
+    if constexpr (sizeof(T) == 2) {
+      const uint2 lo = *reinterpret_cast<const uint2*>(row + b * 32 + g * 4);
+      const uint2 hi = *reinterpret_cast<const uint2*>(row + b * 32 + 16 + g * 4);
+      return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+      return *reinterpret_cast<const uint4*>(row + b * 16 + g * 4);
+    }
+  };
+  uint4 vf[VLDS ? 1 : NDF][VLDS ? 1 : NVF];
+  if constexpr (!VLDS) {
 #pragma unroll
-  for (int df = 0; df < NDF; ++df) {
-    const T* row = vt + (df * 16 + li) * VT_COLS;
+    for (int df = 0; df < NDF; ++df) {
 #pragma unroll
-    for (int b = 0; b < NVF; ++b) {
-      if constexpr (sizeof(T) == 2) {
-        const uint2 lo = *reinterpret_cast<const uint2*>(row + b * 32 + g * 4);
-        const uint2 hi = *reinterpret_cast<const uint2*>(row + b * 32 + 16 + g * 4);
-        vf[df][b] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      } else {
-        vf[df][b] = *reinterpret_cast<const uint4*>(row + b * 16 + g * 4);
-      }
+      for (int b = 0; b < NVF; ++b) vf[df][b] = read_vf(df, b);
     }
   }
 
@@ -343,6 +359,8 @@ __global__ __launch_bounds__(256, WX_ATTN_MINW) void window_attn_kernel(const At
 #pragma unroll
     for (int df = 0; df < NDF; ++df) oacc[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if constexpr (sizeof(T) == 2) {
+      int vo = 0;
+      if constexpr (VLDS) asm volatile("" : "+v"(vo));   // keeps the LDS reads inside the query loop (LICM would re-create the 32 registers)
 #pragma unroll
       for (int b = 0; b < NKB; ++b) {
         float lo[4], hi[4];
@@ -357,7 +375,7 @@ __global__ __launch_bounds__(256, WX_ATTN_MINW) void window_attn_kernel(const At
         pf.z = pack_bf16x2(hi[0], hi[1]);
         pf.w = pack_bf16x2(hi[2], hi[3]);
 #pragma unroll
-        for (int df = 0; df < NDF; ++df) oacc[df] = mma_sub<T>(vf[df][b], pf, oacc[df]);
+        for (int df = 0; df < NDF; ++df) oacc[df] = mma_sub<T>(VLDS ? read_vf(df, b, vo) : vf[VLDS ? 0 : df][VLDS ? 0 : b], pf, oacc[df]);
       }
     } else {
 #pragma unroll

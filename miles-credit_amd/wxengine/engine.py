@@ -15,7 +15,8 @@ import numpy as np
 from .config import WXConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwxengine.so")
+# WX_LIBRARY: an alternate build of the SAME sources (A/B timing of compile-time switches); the source-hash check still applies
+LIB_PATH = os.environ.get("WX_LIBRARY") or os.path.join(_HERE, "libwxengine.so")
 
 WX_ABI_VERSION = 2
 ARCH = {"crossformer": 0, "wxformer": 1, "crossformer_upconv": 2}
