@@ -67,6 +67,14 @@ __device__ __forceinline__ void cosine_normalise(uint4 (&f)[NS], float mul) {
   }
 }
 
+// gfx950 LDS transpose read: the 16 lanes of a group each supply the address of 8 bytes of a row-major [4][16] block of 16-bit
+// elements (lane i: row i / 4, columns 4 * (i % 4) ..); lane i receives column i, rows 0..3.  Addresses must be 8-byte aligned.
+__device__ __forceinline__ uint2 lds_read_tr16(const void* lds_ptr) {
+  typedef short v4s16 __attribute__((ext_vector_type(4)));
+  const v4s16 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(lds_ptr));
+  return __builtin_bit_cast(uint2, r);
+}
+
 // SPLIT = false: one wave per (window tile, head), four independent tasks per workgroup.
 // SPLIT = true : the workgroup's four waves share one task -- V^T is staged once by all 256 threads and the query
 //                blocks are dealt round-robin to the waves.  Same work, a quarter of the per-task latency: the
@@ -84,7 +92,10 @@ __device__ __forceinline__ void cosine_normalise(uint4 (&f)[NS], float mul) {
 #define WX_ATTN_VLDS 1
 #endif
 constexpr int attn_min_waves(int nkf, int dh, int elem) { return (elem == 2 && nkf <= 8 && dh <= 32) ? WX_ATTN_MINW : 1; }
-template <typename T, int NKF, bool SPLIT, bool BT, int DH = 32>
+// SW: the Swin-mode features (kind 3 token map, seam mask, cosine attention, per-block q scaling).  A template switch, not a
+// run-time one: the mask test used to split the score loop into one basic block per key fragment, and hipcc schedules inside
+// basic blocks -- the WXFormer launches paid for a mode they never use (58 -> 70 us per 100-token launch, round-2 profile).
+template <typename T, int NKF, bool SPLIT, bool BT, int DH = 32, bool SW = false>
 __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void window_attn_kernel(const AttnParams p) {
   constexpr int TBN = 1024;  // LDS bias table: [0, (2w-1)^2) the offsets, the rest -1e30 (padded keys index there)
   constexpr int D = DH;      // head dimension: 32 (CrossFormer), up to 128 (FuXi's Swin stage)
@@ -93,8 +104,18 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int QK_SUBS = D * (int)sizeof(T) / 64;       // 16-byte pieces per lane for a Q/K fragment
   constexpr int NKB = (NKF + 1) / 2;                     // 32-key steps (bf16 PV)
-  constexpr int VT_COLS = (sizeof(T) == 2) ? (NKB * 32 + 8) : (NP + 4);
+  // bf16: V stays ROW-major in LDS -- NDF sub-images [NKB * 32 keys][16 channels] (32-byte rows) written with one 16-byte
+  // store per loaded piece -- and the PV operand is fetched with ds_read_b64_tr_b16, the gfx950 transpose read: a 16-lane
+  // group addresses one contiguous [4 keys][16 channels] block and each lane receives the 4 keys of its channel.  (The
+  // earlier image was V^T, built with 8 ds_write_b16 per piece: 56 LDS writes per task instead of 7.)  f32: V^T as before.
+#ifdef WX_ATTN_NOTR
+  constexpr bool VTR = false;
+#else
+  constexpr bool VTR = sizeof(T) == 2;
+#endif
+  constexpr int VT_COLS = VTR ? NKB * 32 : sizeof(T) == 2 ? NKB * 32 + 8 : (NP + 4);
   constexpr int VT_BYTES = D * VT_COLS * (int)sizeof(T);
+  constexpr int VSUB = NKB * 32 * 32;                    // bytes of one 16-channel sub-image
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -110,22 +131,27 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
   const int head = active ? (int)(task % p.heads) : 0;
   const int win0 = active ? (int)(task / p.heads) * p.pack : 0;
 
-  // token t of the tile -> pixel index, or -1 when its window lies beyond the last one (packed tiles only)
+  // token t of the tile -> pixel index, or -1 when its window lies beyond the last one (packed tiles only).
+  // t < 256 and the divisors are <= 256, so floor(t / d) == (t * ceil(2^16 / d)) >> 16 exactly: the per-token divisions by
+  // run-time values (14 of them per task, ~25 instructions each) become a multiply and a shift.
+  const unsigned mg_x = (65536u + (unsigned)wsx - 1u) / (unsigned)wsx, mg_n = (65536u + (unsigned)NW1 - 1u) / (unsigned)NW1;
+  const int wy0 = win0 / wins_x, wx0 = win0 - wy0 * wins_x;
   auto token_pixel = [&](int t) -> int64_t {
-    int w = win0, tl = t;
+    int wy = wy0, wx_ = wx0, tl = t;
     if (p.pack > 1) {
-      const int sub = t / NW1;
-      w += sub;
+      const int sub = (int)(((unsigned)t * mg_n) >> 16);
+      const int w = win0 + sub;
       tl = t - sub * NW1;
       if (w >= n_win) return -1;
+      wy = w / wins_x;
+      wx_ = w - wy * wins_x;
     }
-    const int wy = w / wins_x, wx_ = w - wy * wins_x;
-    const int ty = tl / wsx, tx = tl - ty * wsx;
+    const int ty = (int)(((unsigned)tl * mg_x) >> 16), tx = tl - ty * wsx;
     int py, px;
     if (p.kind == 0) {
       py = wy * p.wsz + ty;
       px = wx_ * wsx + tx;
-    } else if (p.kind == 3) {  // window of the rolled map: rolled (r, c) holds pixel ((r + shift_y) % H, (c + shift_x) % W)
+    } else if (SW && p.kind == 3) {  // window of the rolled map: rolled (r, c) holds pixel ((r + shift_y) % H, (c + shift_x) % W)
       py = wy * p.wsz + ty + p.shift_y;
       px = wx_ * wsx + tx + p.shift_x;
       py -= py >= p.H ? p.H : 0;
@@ -154,7 +180,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
   float* s_tb = reinterpret_cast<float*>(smem + (SPLIT ? 1 : 4) * VT_BYTES);
   int* s_bk = reinterpret_cast<int*>(s_tb + TBN);   // [NP] byte offset 4*(ty*(2w-1)+tx) of token t, or -2048 when padded
   int* s_row = BT ? s_bk + NP : reinterpret_cast<int*>(s_tb);   // [NP] window row ty of token t (kind 3: the shift mask's regions)
-  if (p.kind == 3 && threadIdx.x < NP) s_row[threadIdx.x] = (int)threadIdx.x / wsx;
+  if (SW && p.kind == 3 && threadIdx.x < NP) s_row[threadIdx.x] = (int)threadIdx.x / wsx;
   if constexpr (BT) {
     const int side = 2 * p.wsz - 1;
     for (int i = threadIdx.x; i < TBN; i += 256) s_tb[i] = i < side * side ? p.tb[i] : -1.0e30f;
@@ -198,7 +224,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
         kf[j][s] = *reinterpret_cast<const uint4*>(qkv + kp * p.ld_qkv + p.C + head * D + (s * 64 + g * 16) / (int)sizeof(T));
     }
   }
-  if (p.logit_scale) {
+  if (SW && p.logit_scale) {
 #pragma unroll
     for (int j = 0; j < NKF; ++j) cosine_normalise<T, QK_SUBS>(kf[j], 1.0f);
   }
@@ -209,9 +235,13 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
       const int idx = it * STEP + (SPLIT ? (int)threadIdx.x : lane);
       const int t = idx % COLS_FILL, piece = idx / COLS_FILL;
       if (idx < COLS_FILL * PIECES) {
-        const T* e = reinterpret_cast<const T*>(&vv[it]);
+        if constexpr (VTR) {
+          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(vt) + (piece >> 1) * VSUB + t * 32 + (piece & 1) * 16) = vv[it];
+        } else {
+          const T* e = reinterpret_cast<const T*>(&vv[it]);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) vt[(piece * VEC + i) * VT_COLS + t] = e[i];
+          for (int i = 0; i < VEC; ++i) vt[(piece * VEC + i) * VT_COLS + t] = e[i];
+        }
       }
     }
   }
@@ -224,12 +254,19 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
   // per block against ~350 instructions, and 32 registers fewer
   constexpr bool VLDS = WX_ATTN_VLDS && sizeof(T) == 2 && NKF >= 7 && NKF <= 8 && DH == 32;
   auto read_vf = [&](int df, int b, int opaque = 0) -> uint4 {
-    const T* row = vt + (df * 16 + li) * VT_COLS + opaque;
-    if constexpr (sizeof(T) == 2) {
-      const uint2 lo = *reinterpret_cast<const uint2*>(row + b * 32 + g * 4);
-      const uint2 hi = *reinterpret_cast<const uint2*>(row + b * 32 + 16 + g * 4);
+    if constexpr (VTR) {
+      // lane l of a 16-lane group points at its own 8 bytes of the group's [4 keys][16 channels] block: keys b*32 + g*4 + {0..3}
+      // (lo) and + 16 (hi) -- the key order the score accumulators hold -- so the block of group g starts lane*8 bytes in
+      const char* base = reinterpret_cast<const char*>(vt) + opaque + lane * 8 + df * VSUB + b * 1024;
+      const uint2 lo = lds_read_tr16(base), hi = lds_read_tr16(base + 512);
       return make_uint4(lo.x, lo.y, hi.x, hi.y);
     } else {
+      const T* row = vt + (df * 16 + li) * VT_COLS + opaque;
+      if constexpr (sizeof(T) == 2) {   // WX_ATTN_NOTR builds: the V^T image
+        const uint2 lo = *reinterpret_cast<const uint2*>(row + b * 32 + g * 4);
+        const uint2 hi = *reinterpret_cast<const uint2*>(row + b * 32 + 16 + g * 4);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
       return *reinterpret_cast<const uint4*>(row + b * 16 + g * 4);
     }
   };
@@ -273,8 +310,8 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
 #pragma unroll
     for (int s = 0; s < QK_SUBS; ++s) qf[s] = qnext[s];
     load_q(qb + QSTEP, qnext);
-    if (p.logit_scale) cosine_normalise<T, QK_SUBS>(qf, p.logit_scale[head]);
-    else if (sizeof(T) == 2 && p.q_scale != 0.f) {
+    if (SW && p.logit_scale) cosine_normalise<T, QK_SUBS>(qf, p.logit_scale[head]);
+    else if (SW && sizeof(T) == 2 && p.q_scale != 0.f) {
 #pragma unroll
       for (int s = 0; s < QK_SUBS; ++s) {
         float v[VEC];
@@ -291,7 +328,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
     const float* brow = p.bias + (int64_t)head * p.bias_head_stride + (int64_t)query * NP + g * 4;  // query < NP always
     // kind 3: region (0 / 1) of this lane's query under the shift mask; window row of the tile's window
     const int reg_lim = p.H - p.shift_y - (win0 / wins_x) * p.wsz;   // token row ty is in region 1 iff ty >= reg_lim
-    const bool swin_mask = p.kind == 3 && p.shift_y > 0;
+    const bool swin_mask = SW && p.kind == 3 && p.shift_y > 0;
     const int reg_q = swin_mask ? (int)(s_row[query < NP ? query : 0] >= reg_lim) : 0;
     float4 bt[BT ? NKF : 1];
     if constexpr (BT) {
@@ -333,7 +370,22 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
         sv[j][2] = a[2] * p.scale + bb.z;
         sv[j][3] = a[3] * p.scale + bb.w;
       }
-      mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(sv[j][0], sv[j][1])), __builtin_fmaxf(sv[j][2], sv[j][3]));   // v_max3_f32 pairs
+      // two v_max3_f32; written as asm because fmaxf() makes hipcc canonicalise every input first (a v_max_f32 x, x, x each)
+      if constexpr (sizeof(T) != 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(sv[j][0], sv[j][1])), __builtin_fmaxf(sv[j][2], sv[j][3]));
+    }
+    if constexpr (sizeof(T) == 2) {
+      // Row maximum with v_max3_f32 (14 instructions for 28 scores).  fmaxf() on values that come straight out of an MFMA
+      // makes hipcc canonicalise each one first (28 extra v_max_f32 x, x, x), so this is inline asm -- and the hazard
+      // recogniser does not see asm operands: an asm VALU read of a register an MFMA is still writing returns stale data
+      // (found as a run-to-run difference at 721 x 1440).  Hence: nothing moves across the barrier, and the first asm
+      // statement waits out the longest MFMA write-back (19 wait states) itself.
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][0]), "v"(sv[j][1]));
+        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][2]), "v"(sv[j][3]));
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -352,7 +404,8 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
     }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
+    // bf16 output: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division; the fp32 mode keeps the exact quotient
+    const float inv = sizeof(T) == 2 ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;
     AT_TICK(q2);
 
     f32x4_t oacc[NDF];
@@ -411,12 +464,17 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
 #endif
 }
 
-template <typename T, int NKF, bool SPLIT, bool BT = false, int DH = 32>
+template <typename T, int NKF, bool SPLIT, bool BT = false, int DH = 32, bool SW = false>
 inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
+  if (!SW && (p.kind == 3 || p.logit_scale || p.q_scale != 0.f)) throw std::runtime_error("window attention: Swin-mode parameters on the WXFormer kernel");
   constexpr int NKB = (NKF + 1) / 2;
-  constexpr int VT_COLS = (sizeof(T) == 2) ? (NKB * 32 + 8) : (NKF * 16 + 4);
+#ifdef WX_ATTN_NOTR
+  constexpr int VT_COLS = (sizeof(T) == 2) ? NKB * 32 + 8 : (NKF * 16 + 4);
+#else
+  constexpr int VT_COLS = (sizeof(T) == 2) ? NKB * 32 : (NKF * 16 + 4);
+#endif
   constexpr int LDS = (SPLIT ? 1 : 4) * DH * VT_COLS * (int)sizeof(T) + (BT ? 1024 * 4 + NKF * 16 * 4 : 0) + NKF * 16 * 4;
-  auto kern = window_attn_kernel<T, NKF, SPLIT, BT, DH>;
+  auto kern = window_attn_kernel<T, NKF, SPLIT, BT, DH, SW>;
   static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -487,11 +545,11 @@ template <typename T, int DH>
 inline void launch_window_attn_dh(const AttnParams& p, hipStream_t stream) {
   const int wsx = p.wsz_x > 0 ? p.wsz_x : p.wsz;
   switch (attn_nkf_tokens(p.wsz * wsx * p.pack)) {
-    case 1: launch_window_attn_n<T, 1, false, false, DH>(p, stream); break;
-    case 2: launch_window_attn_n<T, 2, false, false, DH>(p, stream); break;
-    case 4: launch_window_attn_n<T, 4, false, false, DH>(p, stream); break;
-    case 7: launch_window_attn_n<T, 7, false, false, DH>(p, stream); break;
-    case 8: launch_window_attn_n<T, 8, false, false, DH>(p, stream); break;
+    case 1: launch_window_attn_n<T, 1, false, false, DH, true>(p, stream); break;
+    case 2: launch_window_attn_n<T, 2, false, false, DH, true>(p, stream); break;
+    case 4: launch_window_attn_n<T, 4, false, false, DH, true>(p, stream); break;
+    case 7: launch_window_attn_n<T, 7, false, false, DH, true>(p, stream); break;
+    case 8: launch_window_attn_n<T, 8, false, false, DH, true>(p, stream); break;
     default: throw std::runtime_error("window attention (general head dim): at most 128 tokens per window");
   }
 }

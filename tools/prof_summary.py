@@ -17,11 +17,13 @@ def short(name):
     return name[:90]
 
 
-def kernel_stats(path):
+def kernel_stats(path, by_grid=False):
     rows = defaultdict(lambda: [0, 0.0])
     with open(path) as f:
         for r in csv.DictReader(f):
             n = short(r.get("Kernel_Name") or r.get("Name") or "?")
+            if by_grid:   # one row per launch shape: the same kernel serves several stages
+                n = f"{n[:78]} g={r.get('Grid_Size') or r.get('Grid_Size_X', '?')}"
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
             rows[n][0] += 1
             rows[n][1] += dur
@@ -50,6 +52,6 @@ def counter_stats(path):
 if __name__ == "__main__":
     root = sys.argv[1]
     for p in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
-        kernel_stats(p)
+        kernel_stats(p, by_grid="--by-grid" in sys.argv)
     for p in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
         counter_stats(p)
