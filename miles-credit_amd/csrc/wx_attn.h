@@ -75,6 +75,19 @@ __device__ __forceinline__ uint2 lds_read_tr16(const void* lds_ptr) {
   return __builtin_bit_cast(uint2, r);
 }
 
+// 16-byte accesses through a native vector type: a plain uint4 (struct) copy from a pointer becomes a memcpy that keeps the
+// destination array in scratch memory
+typedef unsigned attn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 attn_ld16(const void* p) {
+  const attn_u32x4 v = *reinterpret_cast<const attn_u32x4*>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void attn_st16(void* p, const uint4& u) {
+  *reinterpret_cast<attn_u32x4*>(p) = attn_u32x4{u.x, u.y, u.z, u.w};
+}
+// workgroup barrier that waits for this wave's LDS traffic only (__syncthreads() would also drain the global loads in flight)
+__device__ __forceinline__ void attn_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // SPLIT = false: one wave per (window tile, head), four independent tasks per workgroup.
 // SPLIT = true : the workgroup's four waves share one task -- V^T is staged once by all 256 threads and the query
 //                blocks are dealt round-robin to the waves.  Same work, a quarter of the per-task latency: the
@@ -90,6 +103,9 @@ __device__ __forceinline__ uint2 lds_read_tr16(const void* lds_ptr) {
 #endif
 #ifndef WX_ATTN_VLDS
 #define WX_ATTN_VLDS 1
+#endif
+#ifndef WX_ATTN_MFMA_SOFTMAX
+#define WX_ATTN_MFMA_SOFTMAX 1   // bf16: max subtraction and row sum on the matrix pipe (see the query loop)
 #endif
 constexpr int attn_min_waves(int nkf, int dh, int elem) { return (elem == 2 && nkf <= 8 && dh <= 32) ? WX_ATTN_MINW : 1; }
 // SW: the Swin-mode features (kind 3 token map, seam mask, cosine attention, per-block q scaling).  A template switch, not a
@@ -125,46 +141,61 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
   const int N = NW1 * p.pack;           // tokens per tile
   const int wins_x = p.W / wsx, wins_y = p.H / p.wsz;
   const int n_win = wins_x * wins_y;
-  const int64_t task = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;
-  const int64_t n_tasks = (int64_t)((n_win + p.pack - 1) / p.pack) * p.heads;
-  const bool active = task < n_tasks;
-  const int head = active ? (int)(task % p.heads) : 0;
-  const int win0 = active ? (int)(task / p.heads) * p.pack : 0;
+  const int n_tasks = ((n_win + p.pack - 1) / p.pack) * p.heads;   // < 2^31 (launcher check)
+  const int task_raw = SPLIT ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  // the waves of the last workgroup that have no task repeat the last one and store nothing: no early exit, no
+  // "active" test in front of every load
+  const bool active = task_raw < n_tasks;
+  const int task = active ? task_raw : n_tasks - 1;
+  const int head = task % p.heads;
+  const int win0 = (task / p.heads) * p.pack;
 
-  // token t of the tile -> pixel index, or -1 when its window lies beyond the last one (packed tiles only).
+  // Token t of the tile -> pixel.  ALWAYS a real pixel: padded tokens (t >= N) alias the tile's last token and windows
+  // beyond the last one (packed tiles) alias the tile's first window.  That is safe because a padded key carries a -1e30
+  // bias -- its probability is exactly 0 whatever K / V row it loaded -- and a padded query row is never stored
+  // (token_ok), so no load of the prologue needs a branch or a zero fill.
   // t < 256 and the divisors are <= 256, so floor(t / d) == (t * ceil(2^16 / d)) >> 16 exactly: the per-token divisions by
-  // run-time values (14 of them per task, ~25 instructions each) become a multiply and a shift.
+  // run-time values become a multiply and a shift.  The three WXFormer layouts are linear in (window row ty, token tl,
+  // window wy, wx): pixel = ty * CT + tl * CL + wy * BY + wx * BX (tx = tl - ty * wsx substituted).
   const unsigned mg_x = (65536u + (unsigned)wsx - 1u) / (unsigned)wsx, mg_n = (65536u + (unsigned)NW1 - 1u) / (unsigned)NW1;
   const int wy0 = win0 / wins_x, wx0 = win0 - wy0 * wins_x;
-  auto token_pixel = [&](int t) -> int64_t {
-    int wy = wy0, wx_ = wx0, tl = t;
-    if (p.pack > 1) {
-      const int sub = (int)(((unsigned)t * mg_n) >> 16);
-      const int w = win0 + sub;
-      tl = t - sub * NW1;
-      if (w >= n_win) return -1;
-      wy = w / wins_x;
-      wx_ = w - wy * wins_x;
+  int CT, CL, BY, BX;
+  if (p.kind == 0) { CT = p.W - wsx; CL = 1; BY = p.wsz * p.W; BX = wsx; }                                  // short windows
+  else if (p.kind == 2) { CT = p.W - wsx * wins_x; CL = wins_x; BY = p.wsz * p.W; BX = 1; }                 // wx_band.h long layout
+  else { CT = wins_y * p.W - wsx * wins_x; CL = wins_x; BY = p.W; BX = 1; }                                 // long (dilated) windows
+  const float r_wins_x = 1.0f / (float)wins_x;
+  auto token_pixel = [&](int t) -> int {
+    int tl = min(t, N - 1);
+    int wy = wy0, wx_ = wx0;
+    if (NKF == 1 && p.pack > 1) {   // packed tiles hold at most 16 tokens (attn_pack)
+      const int sub = (int)(((unsigned)tl * mg_n) >> 16);
+      int w = win0 + sub;
+      tl -= sub * NW1;
+      w = w < n_win ? w : win0;
+      int q = (int)((float)w * r_wins_x);           // w < 2^23: the float quotient is off by at most one
+      const int r = w - q * wins_x;
+      q += (int)(r >= wins_x) - (int)(r < 0);
+      wy = q;
+      wx_ = w - q * wins_x;
     }
-    const int ty = (int)(((unsigned)tl * mg_x) >> 16), tx = tl - ty * wsx;
-    int py, px;
-    if (p.kind == 0) {
-      py = wy * p.wsz + ty;
-      px = wx_ * wsx + tx;
-    } else if (SW && p.kind == 3) {  // window of the rolled map: rolled (r, c) holds pixel ((r + shift_y) % H, (c + shift_x) % W)
-      py = wy * p.wsz + ty + p.shift_y;
-      px = wx_ * wsx + tx + p.shift_x;
+    const int ty = (int)(((unsigned)tl * mg_x) >> 16);
+    if (SW && p.kind == 3) {  // window of the rolled map: rolled (r, c) holds pixel ((r + shift_y) % H, (c + shift_x) % W)
+      int py = wy * p.wsz + ty + p.shift_y;
+      int px = wx_ * wsx + (tl - ty * wsx) + p.shift_x;
       py -= py >= p.H ? p.H : 0;
       px -= px >= p.W ? p.W : 0;
-    } else if (p.kind == 2) {  // wx_band.h long layout: phase-major rows, columns still dilated
-      py = wy * p.wsz + ty;
-      px = tx * wins_x + wx_;
-    } else {
-      py = ty * wins_y + wy;
-      px = tx * wins_x + wx_;
+      return py * p.W + px;
     }
-    return (int64_t)py * p.W + px;
+    return ty * CT + tl * CL + wy * BY + wx_ * BX;
   };
+  auto token_ok = [&](int t) -> bool {
+    if (t >= N || !active) return false;
+    if (NKF == 1 && p.pack > 1) return win0 + (int)(((unsigned)t * mg_n) >> 16) < n_win;
+    return true;
+  };
+  // byte offset of a pixel's q|k|v row: 24-bit multiplies (pixels < 2^24, row bytes < 2^24, tensor < 4 GB: checked at launch)
+  const unsigned row_bytes = (unsigned)p.ld_qkv * (unsigned)sizeof(T);
+  auto row_off = [&](int pixel) -> unsigned { return __umul24((unsigned)pixel, row_bytes); };
 
 #ifdef WX_ATTN_TRACE
 #define AT_TICK(v) const unsigned long long v = trace_tick()
@@ -175,60 +206,66 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
 #define AT_ACC(a, x, y)
 #endif
   AT_TICK(at0);
-  const T* __restrict__ qkv = reinterpret_cast<const T*>(p.qkv);
+  const char* __restrict__ qkv_b = reinterpret_cast<const char*>(p.qkv) + (size_t)head * D * sizeof(T);   // this head's q columns
+  const size_t k_col = (size_t)p.C * sizeof(T), v_col = 2 * k_col;
   T* vt = reinterpret_cast<T*>(smem + (SPLIT ? 0 : wave) * VT_BYTES);
   float* s_tb = reinterpret_cast<float*>(smem + (SPLIT ? 1 : 4) * VT_BYTES);
   int* s_bk = reinterpret_cast<int*>(s_tb + TBN);   // [NP] byte offset 4*(ty*(2w-1)+tx) of token t, or -2048 when padded
   int* s_row = BT ? s_bk + NP : reinterpret_cast<int*>(s_tb);   // [NP] window row ty of token t (kind 3: the shift mask's regions)
-  if (SW && p.kind == 3 && threadIdx.x < NP) s_row[threadIdx.x] = (int)threadIdx.x / wsx;
+  // position-bias generating table: requested FIRST, so that waiting for it (vmcnt is in-order) leaves the K / V loads in flight
+  float tbv[BT ? TBN / 256 : 1];
   if constexpr (BT) {
-    const int side = 2 * p.wsz - 1;
-    for (int i = threadIdx.x; i < TBN; i += 256) s_tb[i] = i < side * side ? p.tb[i] : -1.0e30f;
-    if (threadIdx.x < NP) {
-      const int t = threadIdx.x, ty = t / p.wsz, tx = t - ty * p.wsz;
-      s_bk[t] = t < N ? 4 * (ty * side + tx) : -2048;
-    }
+    const int side2 = (2 * p.wsz - 1) * (2 * p.wsz - 1);
+#pragma unroll
+    for (int i = 0; i < TBN / 256; ++i) tbv[i] = p.tb[min((int)threadIdx.x + i * 256, side2 - 1)];
   }
 
-  // ---- V rows -> registers; K fragments are requested BEFORE the V^T scatter waits on them --------------------
+  // ---- V rows -> registers; K fragments requested before anything waits -------------------------------------------
   constexpr int PIECES = D / VEC;  // 16-byte pieces per token row
   constexpr int COLS_FILL = (sizeof(T) == 2) ? NKB * 32 : NP;
-  // all loads of the tile first, THEN the LDS scatter: a rolled loop waited for each 16-byte load before issuing
-  // the next one -- 8 serial L2 round trips, a third of a task's lifetime (tools/attn_probe)
   constexpr int STEP = SPLIT ? 256 : 64;
   constexpr int ITER = (COLS_FILL * PIECES + STEP - 1) / STEP;
   uint4 vv[ITER];
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
     const int idx = it * STEP + (SPLIT ? (int)threadIdx.x : lane);
-    const int t = idx % COLS_FILL, piece = idx / COLS_FILL;
-    vv[it] = make_uint4(0u, 0u, 0u, 0u);
-    const int64_t tp = (active && idx < COLS_FILL * PIECES && t < N) ? token_pixel(t) : -1;
-    if (tp >= 0) vv[it] = *reinterpret_cast<const uint4*>(qkv + tp * p.ld_qkv + 2 * p.C + head * D + piece * VEC);
+    const int t = idx % COLS_FILL, piece = min(idx / COLS_FILL, PIECES - 1);
+    vv[it] = attn_ld16(qkv_b + v_col + row_off(token_pixel(t)) + piece * 16);
   }
-  // pixel of token j*16 + li (key rows of fragment j == query rows of query block j): computed once, the window
-  // decomposition costs two integer divisions per token
+  // pixel of token j*16 + li (key rows of fragment j == query rows of query block j)
   int tokpix[NKF];
 #pragma unroll
-  for (int j = 0; j < NKF; ++j) tokpix[j] = (active && j * 16 + li < N) ? (int)token_pixel(j * 16 + li) : -1;
+  for (int j = 0; j < NKF; ++j) tokpix[j] = token_pixel(j * 16 + li);
 
-  // ---- K fragments (A operand of S^T) and V^T fragments (A operand of O^T) ------------------
+  // ---- K fragments (A operand of S^T) ------------------------------------------------------------------------------
   uint4 kf[NKF][QK_SUBS];
 #pragma unroll
   for (int j = 0; j < NKF; ++j) {
+    const unsigned ko = row_off(tokpix[j]);
 #pragma unroll
-    for (int s = 0; s < QK_SUBS; ++s) {
-      kf[j][s] = make_uint4(0u, 0u, 0u, 0u);
-      const int64_t kp = tokpix[j];
-      if (kp >= 0)
-        kf[j][s] = *reinterpret_cast<const uint4*>(qkv + kp * p.ld_qkv + p.C + head * D + (s * 64 + g * 16) / (int)sizeof(T));
+    for (int s = 0; s < QK_SUBS; ++s) kf[j][s] = attn_ld16(qkv_b + k_col + ko + s * 64 + g * 16);
+  }
+  // ---- per-workgroup tables, then the only workgroup barrier (LDS counter only: the loads above stay in flight) ------
+  if (SW && p.kind == 3 && threadIdx.x < NP) s_row[threadIdx.x] = (int)threadIdx.x / wsx;
+  if constexpr (BT) {
+    const int side = 2 * p.wsz - 1;
+#pragma unroll
+    for (int i = 0; i < TBN / 256; ++i) {
+      const int e = (int)threadIdx.x + i * 256;
+      s_tb[e] = e < side * side ? tbv[i] : -1.0e30f;
+    }
+    if (threadIdx.x < NP) {
+      const int t = threadIdx.x;
+      const int ty = (int)(((unsigned)t * ((65536u + (unsigned)p.wsz - 1u) / (unsigned)p.wsz)) >> 16), tx = t - ty * p.wsz;
+      s_bk[t] = t < N ? 4 * (ty * side + tx) : -2048;
     }
   }
+  if constexpr (!SPLIT) attn_lds_barrier();
   if (SW && p.logit_scale) {
 #pragma unroll
     for (int j = 0; j < NKF; ++j) cosine_normalise<T, QK_SUBS>(kf[j], 1.0f);
   }
-  // ---- V^T into this wave's LDS slice (zero-filled beyond N) -------------------------------
+  // ---- V into this wave's LDS slice: wave-private, LDS operations of one wave complete in order -> no barrier ---------
   {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
@@ -236,7 +273,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
       const int t = idx % COLS_FILL, piece = idx / COLS_FILL;
       if (idx < COLS_FILL * PIECES) {
         if constexpr (VTR) {
-          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(vt) + (piece >> 1) * VSUB + t * 32 + (piece & 1) * 16) = vv[it];
+          attn_st16(reinterpret_cast<char*>(vt) + (piece >> 1) * VSUB + t * 32 + (piece & 1) * 16, vv[it]);
         } else {
           const T* e = reinterpret_cast<const T*>(&vv[it]);
 #pragma unroll
@@ -245,8 +282,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
       }
     }
   }
-  __syncthreads();
-  if (!active) return;
+  if constexpr (SPLIT) __syncthreads();   // the four waves share one V image
   AT_TICK(at1);
 
   constexpr int NVF = (sizeof(T) == 2) ? NKB : NKF;
@@ -284,17 +320,16 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
   AT_TICK(at2);
   // query fragments are fetched one block ahead: the load of block qb+1 flies during block qb's MFMAs and softmax
   auto tok_of = [&](int qb_) {
-    int qp = -1;
+    int qp = 0;
 #pragma unroll
     for (int j = 0; j < NKF; ++j) qp = (j == qb_) ? tokpix[j] : qp;  // constant indices only (no scratch)
     return qp;
   };
   auto load_q = [&](int qb_, uint4* dst) {
-    const int qp = qb_ < nqb ? tok_of(qb_) : -1;
+    if (qb_ < nqb) {   // uniform
+      const unsigned qo = row_off(tok_of(qb_));
 #pragma unroll
-    for (int s = 0; s < QK_SUBS; ++s) {
-      dst[s] = make_uint4(0u, 0u, 0u, 0u);
-      if (qp >= 0) dst[s] = *reinterpret_cast<const uint4*>(qkv + (int64_t)qp * p.ld_qkv + head * D + (s * 64 + g * 16) / (int)sizeof(T));
+      for (int s = 0; s < QK_SUBS; ++s) dst[s] = attn_ld16(qkv_b + qo + s * 64 + g * 16);
     }
   };
   constexpr int QSTEP = SPLIT ? 4 : 1;
@@ -303,9 +338,8 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
   for (int qb = SPLIT ? wave : 0; qb < nqb; qb += QSTEP) {
     AT_TICK(q0);
     const int query = qb * 16 + li;
-    const int64_t qpix_ = tok_of(qb);
-    const bool qok = qpix_ >= 0;
-    const int64_t qpix = qok ? qpix_ : 0;
+    const int qpix = tok_of(qb);
+    const bool qok = token_ok(query);
     uint4 qf[QK_SUBS];
 #pragma unroll
     for (int s = 0; s < QK_SUBS; ++s) qf[s] = qnext[s];
@@ -391,24 +425,39 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     AT_TICK(q1);
     float sum = 0.f;
+    if constexpr (sizeof(T) == 2 && WX_ATTN_MFMA_SOFTMAX) {
+      // bf16 engine: the matrix pipe idles during the softmax, the VALU does not -- so two of its jobs move over.
+      // (1) s - m is one more MFMA per fragment: A = a column of ones (k = 0), B = a row holding -m~ (k = 0), accumulator =
+      //     the scores.  m~ = bf16(m) is as good as m: any per-query constant cancels in the normalisation, it only has to
+      //     keep 2^(s - m~) in range.  (2) the row sum is the PV product with an all-ones A operand (below).
+      const unsigned mneg = pack_bf16x2(-mx, 0.f) & 0xffffu;
+      const uint4 a_one = make_uint4(g == 0 ? 0x3f80u : 0u, 0u, 0u, 0u), b_m = make_uint4(g == 0 ? mneg : 0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int j = 0; j < NKF; ++j) {
+      for (int j = 0; j < NKF; ++j) {
+        f32x4_t a = {sv[j][0], sv[j][1], sv[j][2], sv[j][3]};
+        a = mma_sub<T>(a_one, b_m, a);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // bf16 mode: probabilities are rounded to bf16 for the PV MFMA anyway -> one v_exp_f32 (2^x) instead of
-        // libm's ~12-instruction expf; fp32 mode keeps the exact path
-        if constexpr (sizeof(T) == 2) sv[j][r] = __builtin_amdgcn_exp2f(sv[j][r] - mx);  // log2(e) folded into scale / bias
-        else sv[j][r] = expf(sv[j][r] - mx);
-        sum += sv[j][r];
+        for (int r = 0; r < 4; ++r) sv[j][r] = __builtin_amdgcn_exp2f(a[r]);
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // bf16 mode: probabilities are rounded to bf16 for the PV MFMA anyway -> one v_exp_f32 (2^x) instead of
+          // libm's ~12-instruction expf; fp32 mode keeps the exact path
+          if constexpr (sizeof(T) == 2) sv[j][r] = __builtin_amdgcn_exp2f(sv[j][r] - mx);  // log2(e) folded into scale / bias
+          else sv[j][r] = expf(sv[j][r] - mx);
+          sum += sv[j][r];
+        }
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
     }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    // bf16 output: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division; the fp32 mode keeps the exact quotient
-    const float inv = sizeof(T) == 2 ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;
     AT_TICK(q2);
 
     f32x4_t oacc[NDF];
+    f32x4_t osum = {0.f, 0.f, 0.f, 0.f};   // every row: the sum over keys of the bf16-rounded probabilities of query li
 #pragma unroll
     for (int df = 0; df < NDF; ++df) oacc[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if constexpr (sizeof(T) == 2) {
@@ -429,7 +478,9 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
         pf.w = pack_bf16x2(hi[2], hi[3]);
 #pragma unroll
         for (int df = 0; df < NDF; ++df) oacc[df] = mma_sub<T>(VLDS ? read_vf(df, b, vo) : vf[VLDS ? 0 : df][VLDS ? 0 : b], pf, oacc[df]);
+        if constexpr (WX_ATTN_MFMA_SOFTMAX) osum = mma_sub<T>(make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u), pf, osum);
       }
+      if constexpr (WX_ATTN_MFMA_SOFTMAX) sum = osum[0];
     } else {
 #pragma unroll
       for (int j = 0; j < NKF; ++j) {
@@ -444,13 +495,15 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
       }
     }
     AT_TICK(q3);
+    // bf16 output: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division; the fp32 mode keeps the exact quotient
+    const float inv = sizeof(T) == 2 ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;
     if (qok) {
 #pragma unroll
       for (int df = 0; df < NDF; ++df) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = oacc[df][r] * inv;
-        store4<T>(out + qpix * p.ld_out + head * D + df * 16 + g * 4, v);
+        store4<T>(out + (size_t)__umul24((unsigned)qpix, (unsigned)p.ld_out) + head * D + df * 16 + g * 4, v);
       }
     }
     AT_TICK(q4);
@@ -466,6 +519,9 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void 
 
 template <typename T, int NKF, bool SPLIT, bool BT = false, int DH = 32, bool SW = false>
 inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
+  if ((int64_t)p.H * p.W >= (1 << 24) || (int64_t)p.ld_qkv * (int64_t)sizeof(T) >= (1 << 24) || p.ld_out >= (1 << 24) ||
+      (int64_t)p.H * p.W * p.ld_qkv * (int64_t)sizeof(T) >= (int64_t(1) << 32))
+    throw std::runtime_error("window attention: map too large for 24-bit pixel / 32-bit byte addressing");
   if (!SW && (p.kind == 3 || p.logit_scale || p.q_scale != 0.f)) throw std::runtime_error("window attention: Swin-mode parameters on the WXFormer kernel");
   constexpr int NKB = (NKF + 1) / 2;
 #ifdef WX_ATTN_NOTR
