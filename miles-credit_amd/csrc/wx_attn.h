@@ -107,12 +107,14 @@ __device__ __forceinline__ void attn_lds_barrier() { asm volatile("s_waitcnt lgk
 #ifndef WX_ATTN_MFMA_SOFTMAX
 #define WX_ATTN_MFMA_SOFTMAX 1   // bf16: max subtraction and row sum on the matrix pipe (see the query loop)
 #endif
-constexpr int attn_min_waves(int nkf, int dh, int elem) { return (elem == 2 && nkf <= 8 && dh <= 32) ? WX_ATTN_MINW : 1; }
+constexpr int attn_min_waves(int nkf, int dh, int elem, bool sw) {
+  return (elem == 2 && nkf <= 8 && dh <= 32) ? (sw && nkf >= 7 ? 3 : WX_ATTN_MINW) : 1;   // the Swin-mode extras spill at 128 registers
+}
 // SW: the Swin-mode features (kind 3 token map, seam mask, cosine attention, per-block q scaling).  A template switch, not a
 // run-time one: the mask test used to split the score loop into one basic block per key fragment, and hipcc schedules inside
 // basic blocks -- the WXFormer launches paid for a mode they never use (58 -> 70 us per 100-token launch, round-2 profile).
 template <typename T, int NKF, bool SPLIT, bool BT, int DH = 32, bool SW = false>
-__global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)))) void window_attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) void window_attn_kernel(const AttnParams p) {
   constexpr int TBN = 1024;  // LDS bias table: [0, (2w-1)^2) the offsets, the rest -1e30 (padded keys index there)
   constexpr int D = DH;      // head dimension: 32 (CrossFormer), up to 128 (FuXi's Swin stage)
   constexpr int NDF = D / 16;
