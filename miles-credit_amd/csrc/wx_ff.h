@@ -279,8 +279,10 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
         v[f * 4 + 2] = f32x2_t{rs * (h[1][f][0] - mu * c1.x) + d1.x, rs * (h[1][f][1] - mu * c1.y) + d1.y};
         v[f * 4 + 3] = f32x2_t{rs * (h[1][f][2] - mu * c1.z) + d1.z, rs * (h[1][f][3] - mu * c1.w) + d1.w};
       }
+#ifndef WX_FF_NOGELU   // tools/ff_probe ablation: without the activation the C = 128 block runs 13 % faster, the C = 256 block 11 %
 #pragma unroll
       for (int i = 0; i < PXF * 4; i += GP) gelu_fast_pairs<GP>(v + i);  // GP pairs in lock-step (ILP vs registers)
+#endif
 #pragma unroll
       for (int f = 0; f < PXF; ++f)
         hb[f] = make_uint4(pack_bf16x2(v[f * 4].x, v[f * 4].y), pack_bf16x2(v[f * 4 + 1].x, v[f * 4 + 1].y),

@@ -270,6 +270,34 @@ int main(int argc, char** argv) {
       WX_HIP(hipFree(tr));
     }
 #endif
+    if (res && N % 64 == 0) {   // 64-column tiles (more, smaller workgroups per CU for the short residual layers): bitwise vs the 256-column kernel
+      StreamGemmParams q2 = q;
+      q2.stat_slots = 2 * (N / 64);
+      auto r64_a = [&] { launch_gemm_stream_v<5, 3, false, false, true, true, 2, 3>(q2, st); };
+      auto r64_b = [&] { launch_gemm_stream_v<5, 3, false, false, true, true, 2, 4>(q2, st); };
+      auto r64_c = [&] { launch_gemm_stream_v<4, 3, false, false, true, true, 2, 4>(q2, st); };
+      auto r64_d = [&] { launch_gemm_stream_v<3, 3, false, false, true, true, 4, 4>(q4, st); };
+      double t[4] = {1e30, 1e30, 1e30, 1e30};
+      int bad64 = 0;
+      for (int v = 0; v < 4; ++v) {
+        WX_HIP(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, st));
+        if (v == 0) r64_a(); else if (v == 1) r64_b(); else if (v == 2) r64_c(); else r64_d();
+        WX_HIP(hipStreamSynchronize(st));
+        WX_HIP(hipMemcpy(h2.data(), y1, h2.size() * 2, hipMemcpyDeviceToHost));
+        unblock(h2);
+        if (std::memcmp(h1.data(), h2.data(), h1.size() * 2) != 0) ++bad64;
+      }
+      for (int round = 0; round < 3; ++round) {
+        t[0] = std::min(t[0], time_us(st, 20, r64_a));
+        t[1] = std::min(t[1], time_us(st, 20, r64_b));
+        t[2] = std::min(t[2], time_us(st, 20, r64_c));
+        t[3] = std::min(t[3], time_us(st, 20, r64_d));
+      }
+      const double f2 = 2.0 * M * N * K * 1e-6;
+      printf("    64-col tiles: 160x64 occ3 %7.1f us %5.0f TF | 160x64 occ4 %7.1f us %5.0f TF | 128x64 occ4 %7.1f us %5.0f TF | 96x128 occ4 %7.1f us %5.0f TF | mismatching variants %d\n",
+             t[0], f2 / t[0], t[1], f2 / t[1], t[2], f2 / t[2], t[3], f2 / t[3], bad64);
+      if (bad64) ++bad;
+    }
     if (res && N % 128 == 0) {   // 128-column tiles for the residual layers: parity vs the 256-column kernel (same k order: bitwise), timing
       double t_a = 1e30, t_b = 1e30, t_c = 1e30;
       int bad128 = 0;
