@@ -810,7 +810,6 @@ class Engine : public EngineBase {
   int stat_tiles_ready = 0;     // > 0: `statpart` holds partials of the current stream contents (that many per row)
   bool use_patch = true, planar_xin = true;
   double* gn_acc = nullptr;
-  float *gn_scale = nullptr, *gn_shift = nullptr;
   float *d_mean = nullptr, *d_std = nullptr, *d_lo = nullptr, *d_hi = nullptr;
   bool have_denorm = false, have_tracer = false;
   int tracer_denorm = 0, n_prog = -1, n_static = 0, n_dyn = 0;
@@ -869,8 +868,6 @@ class Engine : public EngineBase {
     if (const char* e = getenv("WX_NO_PLANAR")) planar_xin = !(e[0] == '1');
     const int cmax = cfg.dim[3];
     gn_acc = (double*)dalloc(2 * cmax * sizeof(double));
-    gn_scale = (float*)dalloc(cmax * sizeof(float));
-    gn_shift = (float*)dalloc(cmax * sizeof(float));
     d_mean = (float*)dalloc(C_out * sizeof(float));
     d_std = (float*)dalloc(C_out * sizeof(float));
     d_lo = (float*)dalloc(C_out * sizeof(float));
@@ -963,8 +960,10 @@ class Engine : public EngineBase {
     n_prog = np; n_static = ns; n_dyn = nd;   // n_dyn = channels of the forcing tensor
   }
   // the channels of x_next that do not come from y: fixed groups from x, dynamic-forcing groups from frc (planes of `plane` floats)
-  void copy_layout_groups(const float* x, const float* frc, float* x_next, int64_t plane, hipStream_t s) {
+  // with_static = false: x_next already holds the fixed planes (the rollout's ping-pong buffers keep them from two steps earlier)
+  void copy_layout_groups(const float* x, const float* frc, float* x_next, int64_t plane, hipStream_t s, bool with_static = true) {
     for (const LGroup& g : lgroups) {
+      if (g.kind == 2 && !with_static) continue;
       if (g.kind == 2)
         WX_HIP(hipMemcpyAsync(x_next + g.x0 * plane, x + g.x0 * plane, g.n * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
       else if (g.kind == 1)
@@ -1271,13 +1270,11 @@ class Engine : public EngineBase {
   void gn_finalize_apply(const T* x, int c, int64_t m, int64_t m_count, int64_t g_off, int64_t b_off, const T* res, int64_t res_ld, T* out,
                          int64_t out_ld) {
     constexpr int VEC = 16 / (int)sizeof(T);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(c, 128)), dim3(128), 0, cur_stream, gn_acc, f_dev + g_off, f_dev + b_off, c,
-                       cfg.dim[0], (double)m_count, 1e-5f, gn_scale, gn_shift);
-    WX_HIP(hipGetLastError());
     const int64_t total = m * (c / VEC);
-    const int ablocks = (int)std::min<int64_t>(4096, (total + 255) / 256);
+    const int ablocks = (int)std::min<int64_t>(2048, (total + 255) / 256);   // one resident round: every workgroup derives the affine once
     timed("gn_apply", 0.0, (double)m * c * sizeof(T) * (res ? 3.0 : 2.0), [&] {
-      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(ablocks), dim3(256), 0, cur_stream, x, (int64_t)c, c, m, gn_scale, gn_shift, res, res_ld, out, out_ld);
+      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(ablocks), dim3(256), 2 * c * sizeof(float), cur_stream, x, (int64_t)c, c, m, gn_acc, f_dev + g_off,
+                         f_dev + b_off, cfg.dim[0], (double)m_count, 1e-5f, res, res_ld, out, out_ld);
       WX_HIP(hipGetLastError());
     });
   }
@@ -2086,11 +2083,11 @@ class Engine : public EngineBase {
   // removes nothing and adds its replay overhead plus the forcing staging copy.
   int graph_mode = getenv("WX_GRAPH") ? atoi(getenv("WX_GRAPH")) : 0;
   bool want_graph() const { return graph_mode == 1 && !prof_on && !dbg_on && !band_on && !post; }
-  void step_body(const float* x, const float* frc, float* y_phys, float* x_next, hipStream_t s) {
+  void step_body(const float* x, const float* frc, float* y_phys, float* x_next, hipStream_t s, bool with_static = true) {
     cur_stream = s;
     core(x);
     finish_item(x, nullptr, y_phys, x_next);
-    if (x_next) copy_layout_groups(x, frc, x_next, (int64_t)cfg.image_height * cfg.image_width, s);
+    if (x_next) copy_layout_groups(x, frc, x_next, (int64_t)cfg.image_height * cfg.image_width, s, with_static);
   }
   void rollout(const float* x0, const float* const* frc, int n, float* const* y_phys, float* x_final, hipStream_t s) override {
     check_ready();
@@ -2120,7 +2117,8 @@ class Engine : public EngineBase {
         const bool next = t < n - 1 || x_final;
         float* xn = next ? roll_x[t & 1] : nullptr;
         if (xn == x) throw ConfigError("wx_rollout: x0 aliases an internal state buffer");
-        step_body(x, frc ? frc[t] : nullptr, y_phys ? y_phys[t] : nullptr, xn, s);
+        // the fixed (static) planes never change during a rollout: each ping-pong buffer receives them once per call
+        step_body(x, frc ? frc[t] : nullptr, y_phys ? y_phys[t] : nullptr, xn, s, /*with_static=*/t < 2);
         if (xn) x = xn;
       }
       if (x_final) WX_HIP(hipMemcpyAsync(x_final, roll_x[(n - 1) & 1], x_bytes, hipMemcpyDeviceToDevice, s));
