@@ -49,6 +49,9 @@ struct EmbedPatchParams {
   int row0;            // first output row of this launch (the launcher may split the map into two launches)
 };
 
+#ifndef WX_EMBED_VREUSE
+#define WX_EMBED_VREUSE 1   // 0: the one-fragment-per-MFMA tap loop (A/B builds)
+#endif
 // NW waves share one patch: NW = 8 (512 threads, 2 waves per SIMD, 4 fragments each) lets one wave's LDS/L1
 // latency hide under its partner's MFMAs; NW = 4 (8 fragments each) halves the weight-fragment L1 traffic.
 template <typename T, int NW, int TH>
@@ -113,61 +116,155 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
     const uint4* w32 = wt32 + (int64_t)ch * (32 * 8) * 64 + lane;
     const uint4* w16 = f16 ? wt16 + (int64_t)ch * (16 * 4) * 64 + lane : nullptr;
     const uint4* w8 = f8 ? wt8 + (int64_t)ch * (8 * 2 * 2) * 64 + lane : nullptr;
-    uint4 r32[8];
+    if constexpr (RPW == 2 && WX_EMBED_VREUSE) {
+      // VERTICAL REUSE.  Output row r taps patch row 2r + ky, so patch row pr (relative to the wave's first output row) is tap
+      // ky = pr of the wave's row 0 AND tap ky = pr - 2 of its row 1: one fragment read feeds both rows with two different
+      // weight rows.  Patch rows are walked by parity (pr, pr + 2, ...), so the weight row of row 0 in one step is the weight
+      // row of row 1 in the next -- two register sets that swap roles (the loop is unrolled by two), each refilled with the
+      // row two steps ahead right after its last use.  LDS reads per MFMA: 1 KB -> 0.5 KB (the kernel was LDS-read-bound).
+      auto step = [&](auto v0_c, auto v1_c, int pr, uint4* cur, uint4* prev, uint4* hcur, uint4* hprev, uint4 (*ecur)[2], uint4 (*eprev)[2]) {
+        constexpr bool V0 = decltype(v0_c)::value, V1 = decltype(v1_c)::value;   // row 0 has tap pr / row 1 has tap pr - 2
+        const int ky0 = pr, ky1 = pr - 2;
+        const bool in16_0 = V0 && f16 && ky0 >= 8 && ky0 < 24, in16_1 = V1 && f16 && ky1 >= 8 && ky1 < 24;
+        const bool in8_0 = V0 && f8 && ky0 >= 12 && ky0 < 20, in8_1 = V1 && f8 && ky1 >= 12 && ky1 < 20;
+        if (in16_0) {
+          const uint4* q = w16 + (int64_t)(ky0 - 8) * 4 * 64;
 #pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4) r32[k4] = w32[k4 * 64];
-    const int ky_end = (p.dbg & 32) ? 1 : KS;
-    for (int ky = 0; ky < ky_end; ++ky) {
-      uint4 n32[8];
-      const uint4* wn = w32 + (int64_t)((p.dbg & 64) ? 0 : (ky + 1 < KS ? ky + 1 : ky)) * 8 * 64;  // dbg 64: timing experiment, same weights every row (L1-hot)
-#pragma unroll
-      for (int k4 = 0; k4 < 8; ++k4) n32[k4] = wn[k4 * 64];
-      const bool in16 = f16 && ky >= 8 && ky < 24;
-      const bool in8 = f8 && ky >= 12 && ky < 20;
-      uint4 r16[4], r8[2][2];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) r16[j] = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) r8[j][0] = r8[j][1] = make_uint4(0u, 0u, 0u, 0u);
-      if (in16) {
-        const uint4* q = w16 + (int64_t)(ky - 8) * 4 * 64;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r16[j] = q[j * 64];
-      }
-      if (in8) {
-        const uint4* q = w8 + (int64_t)(ky - 12) * 4 * 64;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          r8[j][0] = q[(j * 2 + 0) * 64];
-          r8[j][1] = q[(j * 2 + 1) * 64];
+          for (int j = 0; j < 4; ++j) hcur[j] = q[j * 64];
         }
-      }
-      const char* prow = smem + ky * PW * 16;
+        if (in8_0) {
+          const uint4* q = w8 + (int64_t)(ky0 - 12) * 4 * 64;
 #pragma unroll
-      for (int k4 = 0; k4 < 8; ++k4) {
-        uint4 xf[NF];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) xf[f] = *reinterpret_cast<const uint4*>(prow + fbase[f] + k4 * 64);
-#pragma unroll
-        for (int f = 0; f < NF; ++f) a32[f] = mma_sub<T>(r32[k4], xf[f], a32[f]);
-        if (k4 >= 2 && k4 < 6) {
-          if (in16) {
-#pragma unroll
-            for (int f = 0; f < NF; ++f) a16[f] = mma_sub<T>(r16[k4 - 2 < 0 ? 0 : (k4 - 2 > 3 ? 3 : k4 - 2)], xf[f], a16[f]);
+          for (int j = 0; j < 2; ++j) {
+            ecur[j][0] = q[(j * 2 + 0) * 64];
+            ecur[j][1] = q[(j * 2 + 1) * 64];
           }
         }
-        if (k4 >= 3 && k4 < 5) {
-          if (in8) {
+        const char* prow = smem + pr * PW * 16;
+        const bool refill = pr + 2 < KS;
+        const uint4* wnext = w32 + (int64_t)(refill ? pr + 2 : KS - 1) * 8 * 64;   // no row two steps on: a harmless in-range reload
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-              a8[0][f] = mma_sub<T>(r8[k4 == 3 ? 0 : 1][0], xf[f], a8[0][f]);
-              a8[1][f] = mma_sub<T>(r8[k4 == 3 ? 0 : 1][1], xf[f], a8[1][f]);
+        for (int k4 = 0; k4 < 8; ++k4) {
+          const uint4 x0 = *reinterpret_cast<const uint4*>(prow + fbase[0] + k4 * 64);
+          const uint4 x1 = *reinterpret_cast<const uint4*>(prow + fbase[1] + k4 * 64);
+          if constexpr (V0) {
+            a32[0] = mma_sub<T>(cur[k4], x0, a32[0]);
+            a32[1] = mma_sub<T>(cur[k4], x1, a32[1]);
+          }
+          if constexpr (V1) {
+            a32[2] = mma_sub<T>(prev[k4], x0, a32[2]);
+            a32[3] = mma_sub<T>(prev[k4], x1, a32[3]);
+          }
+          prev[k4] = wnext[k4 * 64];   // this set becomes row 0's weight row of the next step
+          if (k4 >= 2 && k4 < 6) {
+            const int j = k4 - 2 < 0 ? 0 : (k4 - 2 > 3 ? 3 : k4 - 2);
+            if (in16_0) {
+              a16[0] = mma_sub<T>(hcur[j], x0, a16[0]);
+              a16[1] = mma_sub<T>(hcur[j], x1, a16[1]);
+            }
+            if (in16_1) {
+              a16[2] = mma_sub<T>(hprev[j], x0, a16[2]);
+              a16[3] = mma_sub<T>(hprev[j], x1, a16[3]);
+            }
+          }
+          if (k4 >= 3 && k4 < 5) {
+            const int j = k4 == 3 ? 0 : 1;
+            if (in8_0) {
+              a8[0][0] = mma_sub<T>(ecur[j][0], x0, a8[0][0]);
+              a8[0][1] = mma_sub<T>(ecur[j][0], x1, a8[0][1]);
+              a8[1][0] = mma_sub<T>(ecur[j][1], x0, a8[1][0]);
+              a8[1][1] = mma_sub<T>(ecur[j][1], x1, a8[1][1]);
+            }
+            if (in8_1) {
+              a8[0][2] = mma_sub<T>(eprev[j][0], x0, a8[0][2]);
+              a8[0][3] = mma_sub<T>(eprev[j][0], x1, a8[0][3]);
+              a8[1][2] = mma_sub<T>(eprev[j][1], x0, a8[1][2]);
+              a8[1][3] = mma_sub<T>(eprev[j][1], x1, a8[1][3]);
             }
           }
         }
-      }
+      };
+      using TT = std::true_type;
+      using FF_ = std::false_type;
+#pragma unroll 1
+      for (int par = 0; par < 2; ++par) {
+        uint4 wa[8], wb[8], ha[4], hb[4], ea[2][2], eb[2][2];
 #pragma unroll
-      for (int k4 = 0; k4 < 8; ++k4) r32[k4] = n32[k4];
+        for (int k4 = 0; k4 < 8; ++k4) {
+          wa[k4] = w32[(int64_t)(par * 8 + k4) * 64];
+          wb[k4] = wa[k4];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ha[j] = hb[j] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ea[j][0] = ea[j][1] = eb[j][0] = eb[j][1] = make_uint4(0u, 0u, 0u, 0u);
+        // pr = par: row 0 only;  pr = par + 2 .. par + 30: both rows;  pr = par + 32: row 1 only (17 steps per parity)
+        step(TT{}, FF_{}, par, wa, wb, ha, hb, ea, eb);
+#pragma unroll 1
+        for (int pr = par + 2; pr < par + KS; pr += 4) {
+          step(TT{}, TT{}, pr, wb, wa, hb, ha, eb, ea);
+          if (pr + 2 < par + KS) step(TT{}, TT{}, pr + 2, wa, wb, ha, hb, ea, eb);
+        }
+        // KS / 2 - 1 = 15 middle steps (odd): the last middle step ran with (cur, prev) = (wb, wa), so row 1's tap 30 + par sits in wb
+        step(FF_{}, TT{}, par + KS, wa, wb, ha, hb, ea, eb);
+      }
+    } else {
+      uint4 r32[8];
+  #pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) r32[k4] = w32[k4 * 64];
+      const int ky_end = (p.dbg & 32) ? 1 : KS;
+      for (int ky = 0; ky < ky_end; ++ky) {
+        uint4 n32[8];
+        const uint4* wn = w32 + (int64_t)((p.dbg & 64) ? 0 : (ky + 1 < KS ? ky + 1 : ky)) * 8 * 64;  // dbg 64: timing experiment, same weights every row (L1-hot)
+  #pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) n32[k4] = wn[k4 * 64];
+        const bool in16 = f16 && ky >= 8 && ky < 24;
+        const bool in8 = f8 && ky >= 12 && ky < 20;
+        uint4 r16[4], r8[2][2];
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) r16[j] = make_uint4(0u, 0u, 0u, 0u);
+  #pragma unroll
+        for (int j = 0; j < 2; ++j) r8[j][0] = r8[j][1] = make_uint4(0u, 0u, 0u, 0u);
+        if (in16) {
+          const uint4* q = w16 + (int64_t)(ky - 8) * 4 * 64;
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) r16[j] = q[j * 64];
+        }
+        if (in8) {
+          const uint4* q = w8 + (int64_t)(ky - 12) * 4 * 64;
+  #pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            r8[j][0] = q[(j * 2 + 0) * 64];
+            r8[j][1] = q[(j * 2 + 1) * 64];
+          }
+        }
+        const char* prow = smem + ky * PW * 16;
+  #pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+          uint4 xf[NF];
+  #pragma unroll
+          for (int f = 0; f < NF; ++f) xf[f] = *reinterpret_cast<const uint4*>(prow + fbase[f] + k4 * 64);
+  #pragma unroll
+          for (int f = 0; f < NF; ++f) a32[f] = mma_sub<T>(r32[k4], xf[f], a32[f]);
+          if (k4 >= 2 && k4 < 6) {
+            if (in16) {
+  #pragma unroll
+              for (int f = 0; f < NF; ++f) a16[f] = mma_sub<T>(r16[k4 - 2 < 0 ? 0 : (k4 - 2 > 3 ? 3 : k4 - 2)], xf[f], a16[f]);
+            }
+          }
+          if (k4 >= 3 && k4 < 5) {
+            if (in8) {
+  #pragma unroll
+              for (int f = 0; f < NF; ++f) {
+                a8[0][f] = mma_sub<T>(r8[k4 == 3 ? 0 : 1][0], xf[f], a8[0][f]);
+                a8[1][f] = mma_sub<T>(r8[k4 == 3 ? 0 : 1][1], xf[f], a8[1][f]);
+              }
+            }
+          }
+        }
+  #pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) r32[k4] = n32[k4];
+      }
     }
     __syncthreads();  // everyone is done with the patch before the next chunk overwrites it
   }
