@@ -49,6 +49,9 @@ struct EmbedPatchParams {
   int row0;            // first output row of this launch (the launcher may split the map into two launches)
 };
 
+#ifndef WX_EMBED_TAIL_NW
+#define WX_EMBED_TAIL_NW 8   // waves per workgroup of the half-height tail tiles (4: two rows per wave with vertical reuse, two workgroups per CU -- measured equal)
+#endif
 #ifndef WX_EMBED_VREUSE
 #define WX_EMBED_VREUSE 1   // 0: the one-fragment-per-MFMA tap loop (A/B builds)
 #endif
@@ -338,7 +341,7 @@ inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page,
   const int rem = p.out_h - 16 * r1;
   if (!(p.dbg & 8192) && full_rounds >= 1 && r1 < tile_rows && rem > 0 && cdiv(rem, 8) * tiles_x <= n_cu) {
     launch_embed_patch_part<T, 8, 16>(p, 0, 16 * r1, zero_page, stream);
-    launch_embed_patch_part<T, 8, 8>(p, 16 * r1, rem, zero_page, stream);
+    launch_embed_patch_part<T, WX_EMBED_TAIL_NW, 8>(p, 16 * r1, rem, zero_page, stream);
   } else {
     launch_embed_patch_part<T, 8, 16>(p, 0, p.out_h, zero_page, stream);
   }
