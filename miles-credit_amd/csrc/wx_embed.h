@@ -47,6 +47,10 @@ struct EmbedPatchParams {
   int n32, n16, n8;    // real channels per branch (multiples of 4; <= 16, 16, 32)
   int dbg;
   int row0;            // first output row of this launch (the launcher may split the map into two launches)
+  // chunk split (small maps, launch_embed_patch): blockIdx.y takes the channel chunks [y * chunk_per, (y + 1) * chunk_per) and
+  // leaves its raw fp32 sums in partial[y][pixel][64] (k32 | k16 | k8 channels); embed_finish_kernel adds them in order
+  float* partial;
+  int chunk_per;
 };
 
 #ifndef WX_EMBED_TAIL_NW
@@ -100,9 +104,11 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
     a8[1][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int ch = 0; ch < chunks; ++ch) {
+  const int ch_lo = p.partial ? (int)blockIdx.y * p.chunk_per : 0;
+  const int ch_hi = p.partial ? min(chunks, ch_lo + p.chunk_per) : chunks;
+  for (int ch = ch_lo; ch < ch_hi; ++ch) {
     // ---- stage the patch for this channel chunk (LDS-DMA, one pixel per lane) --------------------
-    if (!(p.dbg & 16) || ch == 0)
+    if (!(p.dbg & 16) || ch == ch_lo)
       for (int it = 0; it < NPIX_PAD / NT; ++it) {
         const int idx = it * NT + wave * 64 + lane;
         const int py = idx / PW, px = idx - py * PW;
@@ -272,6 +278,20 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
     __syncthreads();  // everyone is done with the patch before the next chunk overwrites it
   }
 
+  if (p.partial) {   // raw sums of this chunk range: [pixel][64] floats, lane (li, g) holds channels 4g..4g+3 of each 16-channel group
+    float* part = p.partial + (int64_t)blockIdx.y * p.out_h * p.out_w * 64;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int oy = oy0 + RPW * wave + (f >> 1), ox = ox0 + (f & 1) * 16 + li;
+      if (oy >= p.out_h || ox >= p.out_w) continue;
+      float* q = part + ((int64_t)oy * p.out_w + ox) * 64 + g * 4;
+      *reinterpret_cast<float4*>(q) = make_float4(a32[f][0], a32[f][1], a32[f][2], a32[f][3]);
+      *reinterpret_cast<float4*>(q + 16) = make_float4(a16[f][0], a16[f][1], a16[f][2], a16[f][3]);
+      *reinterpret_cast<float4*>(q + 32) = make_float4(a8[0][f][0], a8[0][f][1], a8[0][f][2], a8[0][f][3]);
+      *reinterpret_cast<float4*>(q + 48) = make_float4(a8[1][f][0], a8[1][f][1], a8[1][f][2], a8[1][f][3]);
+    }
+    return;
+  }
   // ---- epilogue: + bias, 4 consecutive channels per lane ---------------------------------------------
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 b32 = *reinterpret_cast<const float4*>(p.bias32 + g * 4);
@@ -307,6 +327,29 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
   }
 }
 
+// chunk-split finish: out = bf16(sum_y partial[y] + bias), one thread per (pixel, 4 channels); fixed summation order
+template <typename T>
+__global__ __launch_bounds__(256) void embed_finish_kernel(const EmbedPatchParams p, int n_split) {
+  const int64_t npix = (int64_t)p.out_h * p.out_w;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npix * 16) return;
+  const int64_t pix = idx >> 4;
+  const int q = (int)(idx & 15) * 4;     // channel 0..60 of the 64-wide partial row
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int y = 0; y < n_split; ++y) {
+    const float4 v = *reinterpret_cast<const float4*>(p.partial + ((int64_t)y * npix + pix) * 64 + q);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const int grp = q >> 4, c = q & 15;    // grp 0: k32, 1: k16, 2 / 3: k8 channels 0..15 / 16..31
+  const float* bias = grp == 0 ? p.bias32 : grp == 1 ? p.bias16 : p.bias8;
+  void* outp = grp == 0 ? p.out32 : grp == 1 ? p.out16 : p.out8;
+  const int n = grp == 0 ? p.n32 : grp == 1 ? p.n16 : p.n8;
+  const int cc = grp == 3 ? 16 + c : c;
+  if (!bias || !outp || cc >= n) return;
+  float v[4] = {acc.x + bias[cc], acc.y + bias[cc + 1], acc.z + bias[cc + 2], acc.w + bias[cc + 3]};
+  store4<T>(reinterpret_cast<T*>(outp) + pix * p.out_ld + cc, v);
+}
+
 template <typename T, int NW, int TH>
 inline void launch_embed_patch_part(EmbedPatchParams p, int row0, int rows, const void* zero_page, hipStream_t stream) {
   constexpr int PH = 2 * TH + 30, PW = 2 * 32 + 30;
@@ -320,22 +363,33 @@ inline void launch_embed_patch_part(EmbedPatchParams p, int row0, int rows, cons
   }
   p.row0 = row0;
   const int blocks = cdiv(rows, TH) * cdiv(p.out_w, 32);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
+  const int n_split = p.partial ? cdiv(p.cpad / (16 / (int)sizeof(T)), p.chunk_per) : 1;
+  hipLaunchKernelGGL(kern, dim3(blocks, n_split), dim3(NT), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
   WX_HIP(hipGetLastError());
+  if (p.partial) {
+    const int64_t work = (int64_t)p.out_h * p.out_w * 16;
+    hipLaunchKernelGGL(embed_finish_kernel<T>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, stream, p, n_split);
+    WX_HIP(hipGetLastError());
+  }
 }
 // One workgroup (8 waves, 93 KB of LDS) per CU: a 16-row launch of the C3 map is 625 tiles = 2.44 rounds of 256 CUs, the
 // third round 44 % full.  The tail rows are therefore done by a second launch of half-height tiles that fits ONE round
 // (C3: 500 tiles of 16 rows + 250 tiles of 8 rows = 2 + ~0.6 rounds instead of 3).
+// small maps (fewer 16-row tiles than half the CUs): 4-row tiles, and the caller may add the chunk split
+inline bool embed_patch_small_map(int out_h, int out_w, int dbg, int n_cu = 256) {
+  return !(dbg & 8192) && !(dbg & 256) && cdiv(out_h, 16) * cdiv(out_w, 32) < n_cu / 2;
+}
 template <typename T>
 inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream, int n_cu = 256) {
-  if (p.dbg & 256) { launch_embed_patch_part<T, 4, 16>(p, 0, p.out_h, zero_page, stream); return; }  // A/B switch
+  if (p.dbg & 256) { EmbedPatchParams q = p; q.partial = nullptr; launch_embed_patch_part<T, 4, 16>(q, 0, p.out_h, zero_page, stream); return; }  // A/B switch
   const int tiles_x = cdiv(p.out_w, 32), tile_rows = cdiv(p.out_h, 16);
   if (!(p.dbg & 8192) && tile_rows * tiles_x < n_cu / 2) {
     // small maps (1 degree: 120 x 192 outputs = 48 tiles of 16 rows on 256 CUs): 4-row tiles of 4 waves, two workgroups per
     // CU -- four times the workgroups for 2.4x the patch traffic
-    launch_embed_patch_part<T, 4, 4>(p, 0, p.out_h, zero_page, stream);
+    launch_embed_patch_part<T, 4, 4>(p, 0, p.out_h, zero_page, stream);   // p.partial set by the caller: chunk split on top
     return;
   }
+  if (p.partial) { EmbedPatchParams q = p; q.partial = nullptr; launch_embed_patch<T>(q, zero_page, stream, n_cu); return; }
   const int full_rounds = (tile_rows * tiles_x) / n_cu;
   const int r1 = (full_rounds * n_cu) / tiles_x;            // tile rows that fill whole rounds
   const int rem = p.out_h - 16 * r1;

@@ -793,6 +793,10 @@ class Engine : public EngineBase {
   float2* rowstat = nullptr;
   char* zero_page = nullptr;
   bool use_dma = true;
+  bool embed_split = !getenv("WX_NO_EMBED_SPLIT");
+  int embed_split_ways = getenv("WX_EMBED_SPLIT") ? std::max(2, atoi(getenv("WX_EMBED_SPLIT"))) : 4;
+  float* embed_partial = nullptr;
+  size_t embed_partial_bytes = 0;
   bool use_stream = !(getenv("WX_NO_STREAM") && getenv("WX_NO_STREAM")[0] == '1');   // persistent large-tile GEMM (wx_gemm_stream.h) for the LN-folded 1x1 layers of the deep stages
   int stream_min_rows = 4096;
   char* stream_sink = nullptr;
@@ -1330,6 +1334,19 @@ class Engine : public EngineBase {
             if (kj == 8) { ep.wt8 = wt_dev + pw.wt; ep.bias8 = f_dev + pw.bias; ep.out8 = x + off; ep.n8 = pw.n; }
           }
           off += st.embed[j].n;
+        }
+        // small maps (1-degree grid, lat-band ranks): the serial walk over the channel chunks bounds the launch -> split it four
+        // ways over blockIdx.y, fp32 partial sums, fixed-order finish kernel
+        const int chunks0 = cpad0 / (16 / (int)sizeof(T));
+        if (embed_split && embed_patch_small_map(sh[0], sw[0], dbg_flags) && chunks0 >= 8) {
+          const int n_split = embed_split_ways;
+          const size_t need = (size_t)n_split * sh[0] * sw[0] * 64 * sizeof(float);
+          if (need > embed_partial_bytes) {
+            embed_partial = (float*)dalloc(need);   // grows at most a few times (batch / band geometry); dalloc's list frees the older ones at destroy
+            embed_partial_bytes = need;
+          }
+          ep.partial = embed_partial;
+          ep.chunk_per = cdiv(chunks0, n_split);
         }
         timed("embed_patch", fl, (double)(in_h * Wp) * cpad0 * sizeof(T) + (double)sh[0] * sw[0] * 64 * sizeof(T), [&] {
           launch_embed_patch<T>(ep, zero_page, cur_stream);
