@@ -159,6 +159,15 @@ def main():
             "all_kernels_ms_per_step": round(tot_ms / nprof, 3),
             "by_class_ms_per_step": {r["name"]: round(r["ms"] / nprof, 3) for r in sorted(rows, key=lambda r: -r["ms"])},
         }
+        # second bound the north star names: window attention against HBM (algorithmic q|k|v + out bytes over the class's
+        # event time -- an event pair adds ~3 us to each ~45 us launch, so this UNDER-states the kernel: profiles/ has rocprofv3's)
+        att = [r for r in rows if r["name"] == "window_attn"]
+        if att and att[0]["ms"] > 0:
+            a_gbs = att[0]["bytes"] / (att[0]["ms"] * 1e-3) / 1e9
+            roofline["attention"] = {"bound": "hbm", "kernel": "wx::window_attn_kernel (all launches)", "achieved": round(a_gbs, 1),
+                                     "peak": 8000.0, "unit": "GB/s", "frac": round(a_gbs / 8000.0, 4),
+                                     "launches_per_step": att[0]["launches"] // nprof,
+                                     "avg_launch_us": round(1e3 * att[0]["ms"] / max(att[0]["launches"], 1), 2)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
