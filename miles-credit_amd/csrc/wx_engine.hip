@@ -793,6 +793,9 @@ class Engine : public EngineBase {
   float2* rowstat = nullptr;
   char* zero_page = nullptr;
   bool use_dma = true;
+  bool split_k = !getenv("WX_NO_SPLIT_K");
+  float* splitk_buf = nullptr;
+  size_t splitk_bytes = 0;
   bool embed_split = !getenv("WX_NO_EMBED_SPLIT");
   int embed_split_ways = getenv("WX_EMBED_SPLIT") ? std::max(2, atoi(getenv("WX_EMBED_SPLIT"))) : 4;
   float* embed_partial = nullptr;
@@ -1155,6 +1158,21 @@ class Engine : public EngineBase {
       }
     }
     if (blk_hidden) throw StateError("k-blocked hidden tensor requested but the GEMM fell back to the row-major kernel");
+    // split-K for plain deep-K launches that cannot fill the chip (stage-3 CrossEmbed k = 4: 160 tiles walking K = 8192; every
+    // CrossEmbed GEMM of the 1-degree grid): 128 x 128 tiles x S K-ranges, fp32 partial sums, fixed-order finish kernel
+    if (split_k && use_dma && !rs && !res && act == 0 && out_mode == 0 && !p.stat_out && !p.gn_out && w.n % 128 == 0 &&
+        (w.cin * (int)sizeof(T)) % 128 == 0 && conv_gemm_is_dma<T>(p, zero_page)) {
+      const int64_t tiles = (int64_t)cdiv((int64_t)out_h * out_w, 128) * (w.n / 128);
+      const int nk = w.kh * w.kw * (w.cin * (int)sizeof(T) / 128);
+      int S = (int)std::min<int64_t>(8, 512 / std::max<int64_t>(tiles, 1));
+      S = std::min(S, nk / 16);   // at least 16 K steps per range
+      if (tiles <= 200 && S >= 2) {
+        const size_t need = (size_t)S * out_h * out_w * w.n * sizeof(float);
+        if (need > splitk_bytes) { splitk_buf = (float*)dalloc(need); splitk_bytes = need; }
+        p.partial = splitk_buf;
+        p.k_splits = S;
+      }
+    }
     timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream, gemm_cfg); });
     last_stat_slots = conv_gemm_n_tiles(w.n);
     return made_stats;

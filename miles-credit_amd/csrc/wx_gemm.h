@@ -51,6 +51,10 @@ struct ConvGemmParams {
   int py, px;          // mode 2
   int dbg;             // perf-experiment switches (0 in production): 1 skip global stores, 2 skip act, 4 skip K loop, 8 skip residual
   unsigned long long* trace;  // tools/gemm_probe only: [blocks][8] phase timestamps (s_memtime) + HW_ID; nullptr in production
+  // split-K (conv_gemm_dma only; plain launches: no rowstat / act / res / statistics outputs, out_mode 0): blockIdx.y takes the
+  // K steps [nk*y/S, nk*(y+1)/S) and stores its raw fp32 sums to partial[y][M][n]; conv_gemm_finish_kernel adds them in order
+  float* partial;
+  int k_splits;
 };
 #ifdef WX_GEMM_TRACE
 __device__ __forceinline__ void trace_stamp(const ConvGemmParams& p, int slot) {
@@ -471,7 +475,14 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
   unsigned long long tr_work = 0, tr_dma = 0, tr_bar = 0;
 #endif
+  // split-K: this block's share of the nk steps (the whole range without a split)
+  const int ks_lo = p.partial ? (int)(((int64_t)nk * blockIdx.y) / p.k_splits) : 0;
+  const int ks_hi = p.partial ? (int)(((int64_t)nk * (blockIdx.y + 1)) / p.k_splits) : nk;
   int ky = 0, kx = 0, cc = 0;
+  if (!ONE && ks_lo > 0) {   // position of step ks_lo in the (tap, chunk) walk of `issue`
+    if (TAPIN) { cc = ks_lo / (p.kh * p.kw); const int tap = ks_lo - cc * (p.kh * p.kw); ky = tap / p.kw; kx = tap - ky * p.kw; }
+    else { const int tap = ks_lo / cchunks; cc = ks_lo - tap * cchunks; ky = tap / p.kw; kx = tap - ky * p.kw; }
+  }
   // TAPIN (compile time: a run-time switch here cost 12 B of scratch inside the K loop and 30-80 % per launch)
   // measured: ConvT-k4 (8 chunks) 0.41 -> 0.31 ms with taps inner; CrossEmbed k=4 on 2 chunks 0.11 -> 0.15 ms, so narrow
   // inputs keep the chunk-inner order
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   // writes) then overlaps their flight instead of delaying their issue by an L2 round trip
 #pragma unroll
   for (int j = 0; j < NST - 1; ++j)
-    if (j < nk) issue((unsigned)(j * STAGE), j);
+    if (ks_lo + j < ks_hi) issue((unsigned)(j * STAGE), ks_lo + j);
   if (wave == 0) {
     const int idx = lane & 31;
     const float* srcf = lane < 32 ? p.bias : (p.rowstat ? p.colsum : nullptr);
@@ -547,17 +558,17 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   }
   dma_wait_all();
   __syncthreads();
-  const int nk_run = (p.dbg & 4) ? 0 : nk;
+  const int nk_run = (p.dbg & 4) ? ks_lo : ks_hi;
   trace_stamp(p, 1);
   int cur_i = 0, nxt_i = NST - 1;  // ring indices of the stage being computed / being filled
-  for (int ks = 0; ks < nk_run; ++ks) {
+  for (int ks = ks_lo; ks < nk_run; ++ks) {
     const char* cur = smem + cur_i * STAGE;
     WX_TICK(tk0);
 #ifdef WX_GEMM_TRACE
-    if (ks + NST - 1 < nk && !(p.dbg & 1024)) issue((unsigned)(nxt_i * STAGE), ks + NST - 1);
+    if (ks + NST - 1 < ks_hi && !(p.dbg & 1024)) issue((unsigned)(nxt_i * STAGE), ks + NST - 1);
     if (p.dbg & 2048) cur = smem;  // ds_reads always from stage 0 (still executed)
 #else
-    if (ks + NST - 1 < nk) issue((unsigned)(nxt_i * STAGE), ks + NST - 1);
+    if (ks + NST - 1 < ks_hi) issue((unsigned)(nxt_i * STAGE), ks + NST - 1);
 #endif
 #pragma unroll
     for (int s = 0; s < SUBS; ++s) {
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
     }
     // step ks+1 must have landed; with 3 stages step ks+2 (just issued) may stay in flight
     WX_TICK(tk1);
-    if (NST == 3 && ks + 2 < nk) dma_wait_allow<PER_STEP>(); else dma_wait_all();
+    if (NST == 3 && ks + 2 < ks_hi) dma_wait_allow<PER_STEP>(); else dma_wait_all();
     WX_TICK(tk2);
     __syncthreads();  // ... for every wave, and everyone is done reading `cur`
     WX_TICK(tk3);
@@ -600,6 +611,17 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
     p.trace[(size_t)blockIdx.x * 16 + 10] = tr_bar;
   }
 #endif
+  if (p.partial) {   // split-K: raw sums, 4 consecutive channels of one pixel per lane and fragment
+    float* part = p.partial + (int64_t)blockIdx.y * M * p.n;
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        const int n = n_blk + wn * WN + a * 16 + g * 4, m = m_blk + wm * WMR + b * 16 + li;
+        if (m < M && n < p.n) *reinterpret_cast<float4*>(part + (int64_t)m * p.n + n) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+      }
+    return;
+  }
   // ---- epilogue ---------------------------------------------------------------------------------
   // Straight-line and batched on purpose: the tile is short-K (8-16 steps for the transformer GEMMs), so the
   // epilogue is a third of a workgroup's lifetime; every per-element branch / dependent load here was measured
@@ -821,6 +843,22 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   }
 }
 
+// split-K finish: out[m][n] = T(sum_y partial[y][m][n] + bias[n]); fixed order, 4 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void conv_gemm_finish_kernel(const ConvGemmParams p) {
+  const int M = p.out_h * p.out_w, nq = p.n / 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * nq) return;
+  const int m = (int)(idx / nq), n = (int)(idx - (int64_t)m * nq) * 4;
+  float4 acc = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int y = 0; y < p.k_splits; ++y) {
+    const float4 v = *reinterpret_cast<const float4*>(p.partial + ((int64_t)y * M + m) * p.n + n);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  float v[4] = {acc.x, acc.y, acc.z, acc.w};
+  store4<T>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.out_ld + n, v);
+}
+
 template <typename T, int BM, int BN, int KB, bool ONE, int NST, bool TAPIN = false>
 inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
   constexpr int STAGES = NST * (BM + BN) * KB;
@@ -834,8 +872,13 @@ inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_pag
   }
   const int M = p.out_h * p.out_w;
   const int64_t blocks = (int64_t)cdiv(M, BM) * cdiv(p.n, BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BM * 2), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, p.partial ? p.k_splits : 1), dim3(BM * 2), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
   WX_HIP(hipGetLastError());
+  if (p.partial) {
+    const int64_t work = (int64_t)M * (p.n / 4);
+    hipLaunchKernelGGL(conv_gemm_finish_kernel<T>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, stream, p);
+    WX_HIP(hipGetLastError());
+  }
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KB>
