@@ -793,6 +793,8 @@ class Engine : public EngineBase {
   float2* rowstat = nullptr;
   char* zero_page = nullptr;
   bool use_dma = true;
+  bool merge_parity = !getenv("WX_NO_MERGE_PARITY");
+  const ConvW* gemm_par = nullptr;   // set around a gemm() call: the four parity weight sets of a ConvTranspose k4
   bool split_k = !getenv("WX_NO_SPLIT_K");
   float* splitk_buf = nullptr;
   size_t splitk_bytes = 0;
@@ -1106,6 +1108,22 @@ class Engine : public EngineBase {
     p.act = act; p.res = res; p.res_ld = res_ld; p.out = out; p.out_ld = out_ld;
     p.out_mode = out_mode; p.cout = cout; p.py = py; p.px = px; p.dbg = dbg_flags;
     const double m = (double)out_h * out_w;
+    if (gemm_par) {   // the four parity convs of a ConvTranspose k4 s2 p1 (out_mode 2): one launch when the fast path takes it
+      const ConvW* gp = gemm_par;
+      gemm_par = nullptr;
+      if (merge_parity && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr) && !dbg_flags && w.n <= 64) {
+        p.n_par = 4;
+        for (int q = 0; q < 4; ++q) p.wt_par[q] = wt_dev + gp[q].wt;
+        const double fl4 = 4.0 * 2.0 * m * w.n * w.kh * w.kw * w.cin_true;
+        const double by4 = (4.0 * m * w.n + (double)in_h * in_w * w.cin_true + 4.0 * w.n * w.kh * w.kw * w.cin) * sizeof(T);
+        timed(cls, fl4, by4, [&] { launch_conv_gemm<T>(p, zero_page, cur_stream, gemm_cfg); });
+        return false;
+      }
+      for (int q = 0; q < 4; ++q)
+        gemm(cls, gp[q], in, in_h, in_w, in_ld, stride, pad_y - (q >> 1), pad_x - (q & 1), out_h, out_w, out, out_ld, rs, act, res, res_ld, out_mode,
+             cout, q >> 1, q & 1, want_stats, want_gn);
+      return false;
+    }
     const double flops = 2.0 * m * w.n * w.kh * w.kw * w.cin_true;
     const double bytes = (m * w.n * (res ? 2.0 : 1.0) + (double)in_h * in_w * w.cin_true + (double)w.n * w.kh * w.kw * w.cin) * sizeof(T);
     bool made_stats = false;
@@ -1458,11 +1476,8 @@ class Engine : public EngineBase {
       upsample2x(cat[0], sh[0], sw[0], 2 * cfg.dim[0], 2 * cfg.dim[0]);
       gemm("gemm_conv3", up4c, upbuf, Hd, Wd, 2 * cfg.dim[0], 1, 1, 1, Hd, Wd, dec, ld_dec, nullptr, 0, nullptr, 0);
     } else {
-      for (int q = 0; q < 4; ++q) {
-        const int py = q >> 1, px = q & 1;
-        gemm("gemm_convT4", up4[q], cat[0], sh[0], sw[0], 2 * cfg.dim[0], 1, 1 - py, 1 - px, sh[0], sw[0], dec, ld_dec, nullptr, 0,
-             nullptr, 0, 2, 0, py, px);
-      }
+      gemm_par = up4;   // pads (1 - py, 1 - px), output pixel (2 oy + py, 2 ox + px): gemm() runs the four parities (merged when it can)
+      gemm("gemm_convT4", up4[0], cat[0], sh[0], sw[0], 2 * cfg.dim[0], 1, 1, 1, sh[0], sw[0], dec, ld_dec, nullptr, 0, nullptr, 0, 2, 0, 0, 0);
     }
     capture("up_block4", dec, Hd, Wd, C_out, ld_dec, Wd);
   }
@@ -1921,11 +1936,9 @@ class Engine : public EngineBase {
         gemm("gemm_conv3", fin4, bps4, 2 * rows + 2, Wd, cpad4, 1, 0, 1, 2 * rows, Wd, bdec + (int64_t)Wd * ld_dec, ld_dec, nullptr, 0, nullptr, 0);
         return;
       }
-      for (int q = 0; q < 4; ++q) {
-        const int py = q >> 1, px = q & 1;
-        gemm("gemm_convT4", up4[q], bcat[0], rows + 2, sw[0], 2 * cfg.dim[0], 1, -py, 1 - px, rows, sw[0], bdec + (int64_t)Wd * ld_dec, ld_dec,
-             nullptr, 0, nullptr, 0, 2, 0, py, px);
-      }
+      gemm_par = up4;
+      gemm("gemm_convT4", up4[0], bcat[0], rows + 2, sw[0], 2 * cfg.dim[0], 1, 0, 1, rows, sw[0], bdec + (int64_t)Wd * ld_dec, ld_dec,
+           nullptr, 0, nullptr, 0, 2, 0, 0, 0);
     }, "halo_dec");
     band_op([this, r] { band_tail(2 * bplan.g.ps[0][r] - 1, post != nullptr); });
     if (post) {   // a12 under sharding: local integrals, every rank's sums to everyone, added in rank order, local correction

@@ -55,6 +55,11 @@ struct ConvGemmParams {
   // K steps [nk*y/S, nk*(y+1)/S) and stores its raw fp32 sums to partial[y][M][n]; conv_gemm_finish_kernel adds them in order
   float* partial;
   int k_splits;
+  // merged parity convs (out_mode 2, conv_gemm_dma only): n_par = 4 -> one launch does the four output parities of a ConvTranspose
+  // k4 s2 p1; N-tile index = parity q (py = q >> 1, px = q & 1), weights wt_par[q], padding (1 - py, 1 - px) + (pad_y, pad_x) base.
+  // Consecutive workgroups take the four parities of one M-tile, so the input rows come out of L2 three times out of four.
+  int n_par;
+  const void* wt_par[4];
 };
 #ifdef WX_GEMM_TRACE
 __device__ __forceinline__ void trace_stamp(const ConvGemmParams& p, int slot) {
@@ -408,21 +413,30 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   const int li = lane & 15, g = lane >> 4;
 
   const int M = p.out_h * p.out_w;
-  const int n_tiles = (p.n + BN - 1) / BN;
+  const int n_tiles = p.n_par == 4 ? 4 : (p.n + BN - 1) / BN;
   int logical;  // XCD-aware remap (bijective for any grid size)
   {
     const int nblk = gridDim.x, b = blockIdx.x;
     const int xcd = b & 7, idx = b >> 3, q = nblk >> 3, r = nblk & 7;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_n = logical % n_tiles, tile_m = logical / n_tiles;
+  int tile_n = logical % n_tiles;
+  const int tile_m = logical / n_tiles;
+  int par_y = p.py, par_x = p.px, pad_y = p.pad_y, pad_x = p.pad_x;
+  const void* wt_base = p.wt;
+  if (p.n_par == 4) {   // n_tiles == 4: the N-tile index is the parity, every parity has ONE real N-tile (n <= BN)
+    par_y = tile_n >> 1; par_x = tile_n & 1;
+    pad_y = p.pad_y - par_y; pad_x = p.pad_x - par_x;
+    wt_base = p.wt_par[tile_n];
+    tile_n = 0;
+  }
   const int m_blk = tile_m * BM, n_blk = tile_n * BN;
 
   const int cchunks = p.cin / BKE;
   const int nk = p.kh * p.kw * cchunks;
   const int64_t ktot = (int64_t)p.kh * p.kw * p.cin;
   const char* __restrict__ in = reinterpret_cast<const char*>(p.in);
-  const char* __restrict__ wt = reinterpret_cast<const char*>(p.wt);
+  const char* __restrict__ wt = reinterpret_cast<const char*>(wt_base);
 
   // ---- per-lane DMA coordinates ---------------------------------------------------------------
   const int lrow = lane / PPR, lslot = lane % PPR;
@@ -435,8 +449,8 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
     const int m = m_blk + row;
     a_ok[i] = m < M;
     const int oy = m / p.out_w, ox = m - oy * p.out_w;
-    a_iy0[i] = oy * p.stride - p.pad_y;
-    a_ix0[i] = ox * p.stride - p.pad_x;
+    a_iy0[i] = oy * p.stride - pad_y;
+    a_ix0[i] = ox * p.stride - pad_x;
     a_piece[i] = (lslot ^ stage_swz<KB>(row)) * 16;  // source piece (bytes) feeding this lane's LDS slot
   }
   const char* b_src[B_I];
@@ -797,7 +811,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
             ch = n0 - q * p.cout;
             pix = (int64_t)(2 * oy + (q >> 1)) * (2 * p.out_w) + 2 * ox + (q & 1);
           } else {
-            pix = (int64_t)(2 * oy + p.py) * (2 * p.out_w) + 2 * ox + p.px;
+            pix = (int64_t)(2 * oy + par_y) * (2 * p.out_w) + 2 * ox + par_x;
             ch = n0;
           }
         }
@@ -871,7 +885,7 @@ inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_pag
     attr_mark_device(attr_done_mask);
   }
   const int M = p.out_h * p.out_w;
-  const int64_t blocks = (int64_t)cdiv(M, BM) * cdiv(p.n, BN);
+  const int64_t blocks = (int64_t)cdiv(M, BM) * (p.n_par == 4 ? 4 : cdiv(p.n, BN));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, p.partial ? p.k_splits : 1), dim3(BM * 2), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
   WX_HIP(hipGetLastError());
   if (p.partial) {
