@@ -93,12 +93,12 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
     for (int i = 0; i < DMA_I; ++i) lds_dma16_s(wsrc + (int64_t)ch * CB + i * 4096, dst[i] + stage_off);
   };
   issue(0, 0u);
+  float* s_b2 = s_par + 2 * p.hidden + 6 * C;   // [C] b2 | [C] bo at the very end of the parameter block (offset 2*hidden + 6C whether or not POST is built)
+#ifndef WX_FF_NOPARAM   // tools/ff_probe ablation: what the per-workgroup parameter staging costs
   for (int i = tid; i < p.hidden; i += 256) {
     s_par[i] = p.cs1[i];
     s_par[p.hidden + i] = p.b1[i];
   }
-  // [C] b2 | [C] bo at the very end of the parameter block (offset 2*hidden + 6C whether or not POST is built)
-  float* s_b2 = s_par + 2 * p.hidden + 6 * C;
   for (int i = tid; i < C; i += 256) {
     s_b2[i] = p.b2[i];
     s_b2[C + i] = PRE ? p.bo[i] : 0.f;
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
       s_par[2 * p.hidden + 3 * C + i] = p.bq[i];
     }
   }
+#endif
 
   // ---- x fragments (B operand of GEMM1, residual of the epilogue) ---------------------------------
   uint4 xb[KS][PXF];
