@@ -166,6 +166,19 @@ __device__ inline void gelu4(float* v) {  // exact (erff) for the fp32 engine, t
   }
 }
 
+// Store widening for MFMA accumulator layouts (lane (li, g) holds 4 consecutive channels 4g.. of a 16-channel fragment of pixel li):
+// two fragments A, B = A + 1 give each lane two 8-byte pieces 32 bytes apart.  v_permlane16_swap exchanges the odd 16-lane rows of
+// its first operand with the even rows of its second, after which EVEN rows (g = 0, 2) hold [own A | neighbour g+1's A] = channels
+// 16A + 4g .. +8 and ODD rows (g = 1, 3) hold [neighbour g-1's B | own B] = channels 16B + 4(g-1) .. +8: ONE 16-byte store per lane
+// instead of two 8-byte ones (same bytes; the fused kernels' store phases were store-ISSUE-bound, tools/ff_probe).  Needs every
+// lane of the wave active.  Inline asm: the s_nop covers the VALU-write -> permlane-read wait states.
+__device__ __forceinline__ uint4 pair_rows16(uint2 a, uint2 b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 0" : "+v"(a.x), "+v"(b.x), "+v"(a.y), "+v"(b.y));
+  return make_uint4(a.x, a.y, b.x, b.y);
+}
+// channel offset of that 16-byte piece relative to fragment A's first channel
+__device__ __forceinline__ int pair_rows16_channel(int g) { return 16 * (g & 1) + 4 * (g & ~1); }
+
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // "this kernel's launch attributes are set" flags: hipFuncSetAttribute applies to the CURRENT device only, so a process that

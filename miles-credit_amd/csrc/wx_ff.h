@@ -59,6 +59,9 @@ inline int ff_perm(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 
 // physical 16-byte slot of logical slot g in row o of a W2 chunk (64-byte rows)
 inline int ff_w2_slot(int o, int g) { return (g + 2 * ((o & 15) >> 2)) & 3; }
 
+#ifndef WX_FF_TAIL_PIPE
+#define WX_FF_TAIL_PIPE 1   // software-pipelined to_qkv tail (0: the plain read -> multiply -> epilogue -> barrier order)
+#endif
 template <int C, int PXF, int OCC, int GP, bool PRE, bool POST>
 __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, const char* __restrict__ zero_page) {
   constexpr int KS = C / 32;          // GEMM1 k steps
@@ -328,8 +331,9 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   for (int f = 0; f < PXF; ++f) {
     const int px = px0b + f * 16 + li2;
     const bool ok = px < p.M;
-    bf16_t* orow = p.out + (int64_t)(ok ? px : 0) * p.out_ld + 4 * g2;
+    bf16_t* orow = p.out + (int64_t)(ok ? px : 0) * p.out_ld + pair_rows16_channel(g2);
     float s1 = 0.f, s2 = 0.f;
+    uint2 o_even = make_uint2(0u, 0u);
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       const float4 bb = *reinterpret_cast<const float4*>(s_b2 + m * 16 + 4 * g2);
@@ -348,7 +352,12 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
         s1 += (q0 + q1) + (q2 + q3);
         s2 += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
       }
-      if (ok) *reinterpret_cast<uint2*>(orow + m * 16) = o;
+      if (m & 1) {   // fragments (m - 1, m) -> one 16-byte store per lane (pair_rows16)
+        const uint4 w = pair_rows16(o_even, o);
+        if (ok) *reinterpret_cast<uint4*>(orow + (m - 1) * 16) = w;
+      } else {
+        o_even = o;
+      }
       if constexpr (POST) {  // the rounded output row becomes the next block's input, same register layout
         if (m & 1) { xb[m / 2][f].z = o.x; xb[m / 2][f].w = o.y; } else { xb[m / 2][f].x = o.x; xb[m / 2][f].y = o.y; }
       }
@@ -362,6 +371,86 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   if constexpr (POST) {
     // ---- next attention: LayerNorm(x_out) folded into to_qkv (crossformer.py:268-270), 64 output rows per ring block ----
     row_statistics();
+#if WX_FF_TAIL_PIPE
+    // Software-pipelined tail.  A block's fragments are read from LDS BEFORE the previous block's LayerNorm-fold epilogue and its stores,
+    // so the LDS round trip hides under that arithmetic (in the chunk loop the GELU plays this part; here the plain order
+    // read -> multiply -> epilogue -> barrier left each block 40 % longer than a feed-forward chunk with its GELU).  The barrier that
+    // frees block i's ring slot therefore sits between its MFMAs and its epilogue, and block i + 2 is requested right after it.
+    constexpr int MLB = 16 / KS, NB = 4 / MLB;   // fragment batches of 16 reads (64 VGPRs); NB batches per 64-row block
+    auto read_batch = [&](const char* blk, int m0, uint4 (&a)[MLB][KS]) {
+#pragma unroll
+      for (int ml = 0; ml < MLB; ++ml)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          a[ml][ks] = *reinterpret_cast<const uint4*>(blk + w1_off + (m0 + ml) * 16 * 2 * C + (((ks * 4 + g) ^ li) * 16));
+    };
+    uint4 a_cur[MLB][KS];
+    if (NPOST > 1) issue(NPRE + nch + 1, (unsigned)CB);   // block 1 -> slot 1 (the last chunk's slot: free since the loop's final barrier)
+    read_batch(smem, 0, a_cur);
+    asm volatile("" ::: "memory");
+#pragma unroll 1
+    for (int i = 0; i < NPOST; ++i) {  // nch is even: ring parity of block i is i & 1
+      const char* cur = smem + (i & 1) * CB;
+      f32x4_t qa[4][PXF];
+#pragma unroll
+      for (int ml = 0; ml < 4; ++ml)
+#pragma unroll
+        for (int f = 0; f < PXF; ++f) qa[ml][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        uint4 a_nxt[MLB][KS];
+        if (nb + 1 < NB) { read_batch(cur, (nb + 1) * MLB, a_nxt); asm volatile("" ::: "memory"); }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int ml = 0; ml < MLB; ++ml)
+#pragma unroll
+            for (int f = 0; f < PXF; ++f) {
+#if defined(WX_FF_TAIL_ABL) && (WX_FF_TAIL_ABL & 4)
+              qa[nb * MLB + ml][f][0] += __builtin_bit_cast(float, a_cur[ml][ks].x ^ xb[ks][f].y);   // ablation: no MFMA
+#else
+              qa[nb * MLB + ml][f] = mma_sub<bf16_t>(a_cur[ml][ks], xb[ks][f], qa[nb * MLB + ml][f]);
+#endif
+            }
+        if (nb + 1 < NB) {
+#pragma unroll
+          for (int ml = 0; ml < MLB; ++ml)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a_cur[ml][ks] = a_nxt[ml][ks];
+        }
+      }
+      dma_wait_all();     // block i + 1 has landed (and the stores of epilogue i - 1, a whole block old, are acknowledged)
+      __syncthreads();    // ... for every wave, and everyone has read block i
+      if (i + 1 < NPOST) { read_batch(smem + ((i + 1) & 1) * CB, 0, a_cur); asm volatile("" ::: "memory"); }
+      if (i + 2 < NPOST) issue(NPRE + nch + i + 2, (unsigned)((i & 1) * CB));
+      uint2 o_even[PXF];
+#pragma unroll
+      for (int ml = 0; ml < 4; ++ml) {
+        const int n0 = i * 64 + ml * 16 + 4 * g2;
+        const float4 cs = *reinterpret_cast<const float4*>(s_par + 2 * p.hidden + n0);
+        const float4 bb = *reinterpret_cast<const float4*>(s_par + 2 * p.hidden + 3 * C + n0);
+#pragma unroll
+        for (int f = 0; f < PXF; ++f) {
+          const int px = px0b + f * 16 + li2;
+          const float mu = mean[f], rs = rstd[f];
+          uint2 o;
+          o.x = pack_bf16x2(rs * (qa[ml][f][0] - mu * cs.x) + bb.x, rs * (qa[ml][f][1] - mu * cs.y) + bb.y);
+          o.y = pack_bf16x2(rs * (qa[ml][f][2] - mu * cs.z) + bb.z, rs * (qa[ml][f][3] - mu * cs.w) + bb.w);
+          if (ml & 1) {   // fragments (ml - 1, ml) -> one 16-byte store per lane: the 245 MB of q|k|v per stage-0 launch used to leave in 8-byte pieces
+            const uint4 w = pair_rows16(o_even[f], o);
+#if defined(WX_FF_TAIL_ABL) && (WX_FF_TAIL_ABL & 1)
+            asm volatile("" ::"v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w));   // ablation: no stores
+#else
+            if (px < p.M) *reinterpret_cast<uint4*>(p.qkv + (int64_t)px * p.ld_qkv + i * 64 + (ml - 1) * 16 + pair_rows16_channel(g2)) = w;
+#endif
+          } else {
+            o_even[f] = o;
+          }
+        }
+      }
+    }
+  }
+#else
 #pragma unroll 1
     for (int i = 0; i < NPOST; ++i) {  // nch is even: ring parity of block i is i & 1
       const char* cur = smem + (i & 1) * CB;
@@ -407,6 +496,7 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
       __syncthreads();
     }
   }
+#endif
 #ifdef WX_FF_TRACE
   if (p.trace && (threadIdx.x & 63) == 0) {
     unsigned long long* t = p.trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
