@@ -499,7 +499,18 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
     AT_TICK(q3);
     // bf16 output: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division; the fp32 mode keeps the exact quotient
     const float inv = sizeof(T) == 2 ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum;
-    if (qok) {
+    if constexpr (sizeof(T) == 2 && NDF % 2 == 0) {
+      // the two 8-byte pieces a lane holds per fragment pair become one 16-byte store (pair_rows16: every lane takes part, the
+      // predicate only guards the store; lanes l and l ^ 16 belong to the same query, so they agree on it)
+      T* orow = out + (size_t)__umul24((unsigned)qpix, (unsigned)p.ld_out) + head * D + pair_rows16_channel(g);
+#pragma unroll
+      for (int df = 0; df < NDF; df += 2) {
+        const uint2 lo = make_uint2(pack_bf16x2(oacc[df][0] * inv, oacc[df][1] * inv), pack_bf16x2(oacc[df][2] * inv, oacc[df][3] * inv));
+        const uint2 hi = make_uint2(pack_bf16x2(oacc[df + 1][0] * inv, oacc[df + 1][1] * inv), pack_bf16x2(oacc[df + 1][2] * inv, oacc[df + 1][3] * inv));
+        const uint4 w = pair_rows16(lo, hi);
+        if (qok) attn_st16(orow + df * 16, w);
+      }
+    } else if (qok) {
 #pragma unroll
       for (int df = 0; df < NDF; ++df) {
         float v[4];
