@@ -276,8 +276,6 @@ int wx_band_plan_messages(wx_band_plan p, int xid, int rank, wx_band_msg* sends,
 /* which: 0..3 = first row of the short layout at that stage, 4..7 = first PHASE of the long layout, 8 = input/output rows;
  * starts[nranks+1] */
 int wx_band_plan_partition(wx_band_plan p, int which, int32_t* starts);
-/* legacy name kept for callers that probe for sharding support: nranks == 1 is a no-op, anything else points at wx_band_* */
-int wx_set_comm(wx_handle h, void* nccl_comm, int rank, int nranks);
 
 /* ---- introspection for parity tests and the roofline report ----------------
  * wx_debug_read: copy an intermediate activation of the LAST forward (batch item 0) to host as
@@ -285,7 +283,9 @@ int wx_set_comm(wx_handle h, void* nccl_comm, int rank, int nranks);
  *   "layers.S.1.layers.D.J", "up_block1".."up_block4".  Only valid after
  *   wx_set_debug(h, 1) and a forward.
  * wx_profile: when enabled, every kernel launch is bracketed by HIP events on the launch stream;
- *   wx_profile_read returns per-kernel-class totals since the last wx_profile_reset.
+ *   wx_profile_read returns per-kernel-class totals since the last wx_profile_reset.  enable: 1 per class ("gemm_ff1"),
+ *   2 per class and stage ("gemm_ff1.s2"), 3 additionally tags launches that took a non-default kernel family
+ *   ("gemm_ff1.s2@stream": the persistent GEMM) -- what the parity tests use to prove which kernel they exercised.
  */
 int wx_set_debug(wx_handle h, int enable);
 int wx_debug_read(wx_handle h, const char* name, float* host_out, int64_t capacity, int64_t shape[3]);

@@ -150,6 +150,8 @@ class Engine : public EngineBase {
     if (device < 0) return;   // host-only instance (wx_band_plan_create): nothing was allocated
     (void)hipSetDevice(device);
     if (b_comm) (void)RcclApi::get().CommDestroy(b_comm);
+    roll_invalidate();
+    if (roll_stream) { (void)hipStreamDestroy(roll_stream); (void)hipEventDestroy(roll_ev_in); (void)hipEventDestroy(roll_ev_out); }
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
@@ -175,6 +177,8 @@ class Engine : public EngineBase {
       throw ConfigError("pad_lat=[p,0] hits a slicing quirk of the reference (boundary_padding.py:66); unsupported");
     if (cfg.pad_activate && (cfg.pad_lat[0] > cfg.image_height || cfg.pad_lat[1] > cfg.image_height))
       throw ConfigError("pad_lat larger than the image");
+    if (cfg.pad_activate == 2 && (cfg.pad_lat[0] >= cfg.image_height || cfg.pad_lat[1] >= cfg.image_height))
+      throw ConfigError("padding mode mirror: pad_lat must be smaller than the image height (reflection without the edge row)");
     int h = Hp, w = Wp;
     for (int s = 0; s < 4; ++s) {
       const int st = cfg.embed_strides[s];
@@ -897,6 +901,7 @@ class Engine : public EngineBase {
   void set_denorm(const float* mean, const float* stdv, int n) override {
     if (n != C_out) throw ShapeError("wx_set_denorm: n must equal the number of output channels");
     WX_HIP(hipSetDevice(device));
+    roll_invalidate();
     alloc_small();
     WX_HIP(hipMemcpy(d_mean, mean, n * sizeof(float), hipMemcpyHostToDevice));
     WX_HIP(hipMemcpy(d_std, stdv, n * sizeof(float), hipMemcpyHostToDevice));
@@ -904,6 +909,7 @@ class Engine : public EngineBase {
   }
   void set_tracer(const int32_t* inds, const float* thres, const float* thres_max, int n, int denorm) override {
     WX_HIP(hipSetDevice(device));
+    roll_invalidate();
     alloc_small();
     if (n == 0) { have_tracer = false; return; }
     std::vector<float> lo(C_out, -3.4e38f), hi(C_out, 3.4e38f);
@@ -933,6 +939,7 @@ class Engine : public EngineBase {
   void set_layout_groups(int n, const int32_t* kind, const int32_t* x_start, const int32_t* src_start, const int32_t* count) override {
     if (!acts_ready) throw StateError("call wx_finalize_weights before wx_set_layout");
     WX_HIP(hipSetDevice(device));
+    roll_invalidate();
     if (n < 0 || (n > 0 && (!kind || !x_start || !src_start || !count))) throw ConfigError("wx_set_layout_groups: null argument");
     const int cx = C_in / cfg.frames;
     std::vector<int> owner(cx, -1), xmap(C_out, -1);
@@ -984,7 +991,8 @@ class Engine : public EngineBase {
   }
 
   // ------------------------------------------------------------------ profiling + debug
-  bool prof_on = false, detail_on = false;
+  bool prof_on = false, detail_on = false, family_on = false;
+  const char* cur_family = nullptr;   // kernel family of the launch being timed (profile mode 3 appends "@family")
   struct Pending { std::string name; double flops, bytes; int ev; };
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   std::vector<Pending> pending;
@@ -992,7 +1000,7 @@ class Engine : public EngineBase {
   hipStream_t cur_stream = nullptr;
   int cur_stage = -1;   // appended to kernel-class names while profiling ("gemm_ff1.s2")
 
-  void profile(int on) override { prof_on = on != 0; detail_on = on > 1; }
+  void profile(int on) override { prof_on = on != 0; detail_on = on > 1; family_on = on > 2; }
   void profile_reset() override { drain(); stats.clear(); }
   void drain() {
     if (pending.empty()) return;
@@ -1021,7 +1029,7 @@ class Engine : public EngineBase {
   }
   template <typename F>
   void timed(const char* name, double flops, double bytes, F&& fn) {
-    if (!prof_on) { fn(); return; }
+    if (!prof_on) { cur_family = nullptr; fn(); return; }
     const int idx = (int)pending.size();
     while ((int)ev_pool.size() <= idx) {
       hipEvent_t a, b;
@@ -1033,6 +1041,8 @@ class Engine : public EngineBase {
     WX_HIP(hipEventRecord(ev_pool[idx].second, cur_stream));
     std::string nm(name);
     if (detail_on && cur_stage >= 0) nm += ".s" + std::to_string(cur_stage);
+    if (family_on && cur_family) nm += std::string("@") + cur_family;
+    cur_family = nullptr;
     pending.push_back({nm, flops, bytes, idx});
   }
 
@@ -1042,6 +1052,7 @@ class Engine : public EngineBase {
     if (band_on) throw StateError("wx_attach_postblock: attach the post block before wx_band_enable");
     if (p && (p->h_full != Ho || p->w != Wo || p->cout != C_out || p->cin * p->fr != C_in || p->fr != cfg.frames))
       throw ConfigError("wx_attach_postblock: post block geometry does not match the model");
+    roll_invalidate();
     post = p;
   }
   // forward tail + optional post block + (y_phys, x_next) of one batch item
@@ -1152,6 +1163,7 @@ class Engine : public EngineBase {
         q.stat_out = statpart; q.stat_slots = w.n / 64;
         q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
         q.a_blk = blk_hidden ? 1 : 0; q.a_rows = q.M;
+        cur_family = "stream";
         timed(cls, flops, bytes, [&] { launch_gemm_stream_n128<5, 3, 2>(q, cur_stream); });
         last_stat_slots = q.stat_slots;
         return true;
@@ -1168,6 +1180,7 @@ class Engine : public EngineBase {
         // tile per epilogue (tools/gemm_stream_probe, MI355X): with GELU the 160-row tile on a 2-stage ring (256 VGPRs, 2 x 54 KB of
         // LDS) wins -- 54.6 / 46.8 us on the stage-2 / stage-3 FeedForward shapes against 56.4 / 58.5 -- without it the 128-row tile
         // on 3 stages does (39.8 vs 46.4 us on to_qkv)
+        cur_family = "stream";
         timed(cls, flops, bytes, [&] {
           if (act == 1) launch_gemm_stream<5, 2>(q, 2, cur_stream);
           else launch_gemm_stream<4, 3>(q, 1, cur_stream);
@@ -2125,6 +2138,15 @@ class Engine : public EngineBase {
   hipEvent_t roll_ev_in = nullptr, roll_ev_out = nullptr;
   std::map<std::tuple<int, const void*, int>, hipGraphExec_t> roll_graphs;
   bool roll_warm = false;
+  int roll_frc_ndyn = 0;   // forcing planes roll_frc was sized for
+  // captured step graphs bake in the de-normalisation / tracer arguments, the layout-group copies and the post-block decision:
+  // every setter that changes one of them drops the graphs (after the replays in flight on roll_stream have finished)
+  void roll_invalidate() {
+    if (roll_graphs.empty()) return;
+    if (roll_stream) (void)hipStreamSynchronize(roll_stream);
+    for (auto& kv : roll_graphs) (void)hipGraphExecDestroy(kv.second);
+    roll_graphs.clear();
+  }
   // WX_GRAPH=1 replays each step from a captured hipGraph.  OFF by default, on measurement (MI355X, 1-degree model, 48 steps): eager
   // 557.7 steps/s (1.79 ms/step, ~170 launches), graph replay 484.8 (2.06 ms): on this stack the cost between two dependent kernels is
   // the device-side dispatch boundary (~1.5 us, MI355X_MICROARCH.md "boundary": eager == hipGraph), not host launch time, so a graph
@@ -2156,7 +2178,11 @@ class Engine : public EngineBase {
     if (!roll_x[0]) {
       roll_x[0] = (float*)dalloc(x_bytes);
       roll_x[1] = (float*)dalloc(x_bytes);
-      if (n_dyn > 0) roll_frc = (float*)dalloc((size_t)n_dyn * plane * sizeof(float));
+    }
+    if (n_dyn > roll_frc_ndyn) {   // a later layout may carry more forcing planes than the first call's
+      roll_invalidate();           // (the captured copies point at the old buffer)
+      roll_frc = (float*)dalloc((size_t)n_dyn * plane * sizeof(float));
+      roll_frc_ndyn = n_dyn;
     }
     const bool graph = want_graph() && roll_warm;
     if (!graph) {
@@ -2204,10 +2230,7 @@ class Engine : public EngineBase {
         WX_HIP(hipStreamEndCapture(roll_stream, &g));
         WX_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         WX_HIP(hipGraphDestroy(g));
-        if (roll_graphs.size() >= 64) {   // callers that hand out a fresh y_phys pointer every step: do not grow without bound
-          for (auto& kv : roll_graphs) (void)hipGraphExecDestroy(kv.second);
-          roll_graphs.clear();
-        }
+        if (roll_graphs.size() >= 64) roll_invalidate();   // callers that hand out a fresh y_phys pointer every step: bounded; waits for replays in flight
         it = roll_graphs.emplace(key, ge).first;
       }
       WX_HIP(hipGraphLaunch(it->second, roll_stream));
@@ -2288,13 +2311,6 @@ int wx_step(wx_handle h, const float* x_dev, const float* frc_dev, float* y_dev,
 int wx_rollout(wx_handle h, const float* x0_dev, const float* const* frc_dev, int n_steps, float* const* y_phys_dev, float* x_final_dev,
                void* stream) {
   return guarded([&] { WX_NEED(h); h->impl->rollout(x0_dev, frc_dev, n_steps, y_phys_dev, x_final_dev, (hipStream_t)stream); });
-}
-int wx_set_comm(wx_handle h, void* nccl_comm, int rank, int nranks) {
-  return guarded([&] {
-    WX_NEED(h);
-    (void)nccl_comm; (void)rank;
-    if (nranks != 1) throw wx::ConfigError("wx_set_comm: lat-band sharding is driven through wx_band_enable / wx_band_begin / wx_band_resume");
-  });
 }
 int wx_band_enable(wx_handle h, int rank, int nranks) { return guarded([&] { WX_NEED(h); h->impl->band_enable(rank, nranks); }); }
 int wx_band_info(wx_handle h, int* own_row0, int* own_rows, int64_t* send_bytes, int64_t* recv_bytes, int* n_exchanges) {

@@ -68,7 +68,6 @@ _PROTOTYPES = {
     "wx_forward": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     "wx_step": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "wx_rollout": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p], C.c_int),
-    "wx_set_comm": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int], C.c_int),
     "wx_band_enable": ([C.c_void_p, C.c_int, C.c_int], C.c_int),
     "wx_band_info": ([C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)], C.c_int),
     "wx_band_set_staging": ([C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64], C.c_int),
@@ -272,7 +271,8 @@ class WXEngine:
         rows = [(code.get(k, k), int(x0), int(0 if s0 is None else s0), int(n)) for k, x0, s0, n in groups]
         arr = [np.ascontiguousarray([r[i] for r in rows], dtype=np.int32) for i in range(4)]
         _check(self.lib.wx_set_layout_groups(self._h, len(rows), *[a.ctypes.data_as(C.POINTER(C.c_int32)) for a in arr]))
-        self._n_dyn = sum(r[3] for r in rows if r[0] == 1)
+        # the C side sizes the forcing tensor as max(src_start + count) over the forcing groups (wx_engine.hip, set_layout_groups)
+        self._n_dyn = max([r[2] + r[3] for r in rows if r[0] == 1], default=0)
 
     # ---- hot path -------------------------------------------------------------------
     @staticmethod

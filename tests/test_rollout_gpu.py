@@ -94,11 +94,13 @@ BF16_BOUND = 2e-2           # the single-step bf16 bar of tests/test_engine_gpu.
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", ["C1", "C3S"])
+@pytest.mark.parametrize("name", ["C1", "C3S", "C3"])
 def test_full_length_rollout_vs_reference_trajectory(name, prec):
     """C1: BASELINE config 2 (24 steps on the 1-degree grid).  C3S: 8 steps on the 0.25-degree grid (721 x 1440, the small-width
     model of credit_smoke_test_v2_025deg.yml) -- reference trajectory only: torch's fp64 CPU convolution of the k = 32 CrossEmbed
-    branch needs 157 GB at that size, so the fp64 floor of that fixture is NaN and the fp32 gate is 1e-4 * t alone."""
+    branch needs 157 GB at that size, so the fp64 floor of that fixture is NaN and the fp32 gate is 1e-4 * t alone.  C3: the HEADLINE
+    workload itself -- 6 steps of the full-width 124 M-parameter model of wxformer_era5_025deg_6hr.yml (BASELINE config 3), reference
+    fp32 trajectory (about 40 s of CPU per step to generate)."""
     path = os.path.join(GOLD, f"rollout_{name}.npz")
     if not os.path.isfile(path):
         pytest.skip(f"tests/golden/rollout_{name}.npz not generated (tools/make_goldens.py --only roll{name})")

@@ -65,3 +65,58 @@ def test_merged_parity_convs_bit_identical(prec):
     merged = _engine("C1", prec, {})
     separate = _engine("C1", prec, {"WX_NO_MERGE_PARITY": "1"})
     assert torch.equal(_forward(merged, x), _forward(separate, x))
+
+
+@pytest.mark.parametrize("name", ["T5", "C1"])
+def test_persistent_gemm_forced_on_small_maps(name):
+    """`gemm_stream_kernel` (wx_gemm_stream.h) only takes C >= 512 layers with >= 4096 rows by itself, i.e. only the 0.25-degree model.
+    WX_STREAM_MIN_ROWS=0 forces it onto small maps: T5 (C = 512 on 200 rows, C = 1024 on 50 rows: ragged against the 128- and 160-row
+    tiles, a sink-row tile, LN fold / LN fold + GELU into the k-blocked hidden / residual + row partials from the k-blocked hidden) and C1's
+    stage 3 (C = 512 on 360 rows).  Checked (a) against the same engine on the 128 x 128 kernel (`WX_NO_STREAM=1`): every GEMM output is the
+    same K walk -> the block outputs agree to the bf16 rounding of a differently ordered LayerNorm partial sum at most, (b) per block against
+    the fp64-free CPU oracle with the suite's bf16 gate, (c) run-to-run bit-identical (race screen)."""
+    from oracle import wxformer_oracle as O
+    cfg = named_config(name)
+    sd = synth_state_dict(cfg)
+    xin = synth_input(cfg)
+    x = torch.from_numpy(xin).cuda()
+    stream = _engine(name, "bf16", {"WX_STREAM_MIN_ROWS": "0"})
+    plain = _engine(name, "bf16", {"WX_NO_STREAM": "1"})
+    cap = {}
+    y_ref = O.forward(cfg, sd, xin, capture=cap)
+    stream.set_debug(True)
+    y_s = stream.forward(x).clone()
+    got_s = {k: stream.debug_read(k) for k in cap}
+    stream.set_debug(False)
+    plain.set_debug(True)
+    y_p = plain.forward(x).clone()
+    got_p = {k: plain.debug_read(k) for k in cap}
+    plain.set_debug(False)
+    assert torch.equal(y_s, stream.forward(x)), "persistent GEMM: two runs differ (race)"
+    for eng, want in ((stream, True), (plain, False)):   # prove which kernel family each engine ran
+        eng.profile(3)
+        eng.profile_reset()
+        eng.forward(x)
+        torch.cuda.synchronize()
+        tagged = [r["name"] for r in eng.profile_read() if r["name"].endswith("@stream")]
+        eng.profile(0)
+        assert bool(tagged) == want, tagged
+        if want:
+            assert {t.split(".")[0] for t in tagged} >= {"gemm_qkv", "gemm_out", "gemm_ff1", "gemm_ff2"}, tagged
+    deep = [k for k in cap if k.startswith("layers.2.1.") or k.startswith("layers.3.1.")]
+    assert len(deep) >= 6, deep
+    n_diff = 0
+    for k in deep:
+        ref = cap[k][0].numpy().astype(np.float64)
+        a, b = got_s[k].astype(np.float64), got_p[k].astype(np.float64)
+        l2_ref = np.linalg.norm(a - ref) / np.linalg.norm(ref)
+        l2_pl = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+        assert l2_ref <= 2e-2, f"{name} {k}: persistent GEMM vs oracle rel-L2 {l2_ref:.3e}"
+        assert l2_pl <= 4e-3, f"{name} {k}: persistent vs 128x128 kernel rel-L2 {l2_pl:.3e}"
+        n_diff += int(not np.array_equal(a, b))
+    l2 = float(torch.linalg.norm((y_s - y_p).double()) / torch.linalg.norm(y_p.double()))
+    assert l2 <= 1e-2, f"{name}: forward, persistent vs 128x128 kernel rel-L2 {l2:.3e}"
+    yr = y_ref.numpy().astype(np.float64)
+    l2o = np.linalg.norm(y_s.cpu().numpy().astype(np.float64) - yr) / np.linalg.norm(yr)
+    assert l2o <= 2e-2, f"{name}: forward vs oracle rel-L2 {l2o:.3e}"
+    print(f"[stream parity] {name}: {len(deep)} deep-stage captures, {n_diff} differ bitwise from the 128x128 path; y vs plain {l2:.2e}, vs oracle {l2o:.2e}")

@@ -553,7 +553,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,swin,rollC1,rollC3S,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
+    ap.add_argument("--only", default="pad,T0,T1,glue,swin,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -568,6 +568,8 @@ def main():
             long_rollout_golden("C1", 24, 20)
         elif item == "rollC3S":     # 8 steps on the 0.25-degree grid (small-width model)
             long_rollout_golden("C3S", 8, 40, with_fp64=False)
+        elif item == "rollC3":      # BASELINE config 3 itself: 6 steps of the FULL-width 124 M-parameter model on the 0.25-degree grid
+            long_rollout_golden("C3", 6, 40, with_fp64=False)
         elif item == "layout":
             layout_golden()
         elif item == "fixers":
