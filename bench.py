@@ -258,6 +258,48 @@ def main():
                    "finite_outputs": bool(torch.isfinite(yp1).all().item()), "note": "best of 3 x 24-step wx_rollout calls after 5 warm-up steps"}
         del e1
 
+    config5 = None
+    if rank == 0 and world == 1 and args.config == "C3" and args.precision == "bf16" and not args.no_config2:
+        # BASELINE config 5 (second architecture): the FuXi-6h 0.25-degree U-Transformer's Swin stage at its real shape
+        # (fuxi_6h_single_step.yml: 640 x 1280 / patch 4 / down 2 -> 80 x 160 tokens padded to 84 x 161, dim 1024, 8 heads, 7 x 7
+        # windows, depth 16) through wx_swin_* with random weights.  Throughput only: FuXi's stage is timm's class, parity unpinned.
+        from wxengine.swin import SwinStage
+        g = torch.Generator().manual_seed(5)
+        dim5, heads5, depth5, feat5 = 1024, 8, 16, (84, 161)
+        sd5 = {}
+        for i in range(depth5):
+            pfx = f"blocks.{i}."
+            for k, shp, sc in (("attn.qkv.weight", (3 * dim5, dim5), dim5 ** -0.5), ("attn.qkv.bias", (3 * dim5,), 0.1),
+                               ("attn.proj.weight", (dim5, dim5), dim5 ** -0.5), ("attn.proj.bias", (dim5,), 0.1),
+                               ("attn.meta_mlp.fc1.weight", (64, 2), 0.7), ("attn.meta_mlp.fc1.bias", (64,), 0.1),
+                               ("attn.meta_mlp.fc2.weight", (heads5, 64), 0.15), ("attn.meta_mlp.fc2.bias", (heads5,), 0.1),
+                               ("mlp.fc1.weight", (4 * dim5, dim5), dim5 ** -0.5), ("mlp.fc1.bias", (4 * dim5,), 0.1),
+                               ("mlp.fc2.weight", (dim5, 4 * dim5), (4 * dim5) ** -0.5), ("mlp.fc2.bias", (dim5,), 0.1)):
+                sd5[pfx + k] = torch.randn(*shp, generator=g) * sc
+            sd5[pfx + "attn.logit_scale"] = torch.log(10 * torch.ones(heads5))
+            for n in ("norm1", "norm2"):
+                sd5[pfx + n + ".weight"] = 0.3 + torch.randn(dim5, generator=g) * 0.05
+                sd5[pfx + n + ".bias"] = torch.randn(dim5, generator=g) * 0.02
+        st5 = SwinStage(dim=dim5, depth=depth5, num_heads=heads5, feat_size=feat5, window_size=7, precision="bf16", device=local_rank)
+        st5.load_state_dict(sd5)
+        x5 = torch.randn(feat5[0], feat5[1], dim5, generator=g).to(torch.bfloat16).to(dev)
+        y5 = torch.empty_like(x5)
+        for _ in range(2):
+            st5(x5, out=y5)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n5 = 10
+        for _ in range(n5):
+            st5(x5, out=y5)
+        torch.cuda.synchronize()
+        e5 = (time.perf_counter() - t1) / n5
+        config5 = {"metric": "FuXi-6h 0.25deg U-Transformer Swin stage passes/sec (84x161 tokens, dim 1024, depth 16; stage only)",
+                   "value": round(1.0 / e5, 2), "unit": "stage-passes/sec", "ms_per_pass": round(1e3 * e5, 3), "dtype": "bf16",
+                   "tflops": round(st5.flops / e5 / 1e12, 1), "finite_outputs": bool(torch.isfinite(y5.float()).all().item()),
+                   "note": "engine's Swin V2 (Cr) stage (pinned to credit/models/swin.py) at FuXi's shape; FuXi's own stage is timm's "
+                           "class: parity unpinned (SURVEY 8(c)); embedding / down / up blocks not included"}
+        del st5
+
     if rank == 0:
         total_steps = args.steps * world
         out = {
@@ -270,7 +312,7 @@ def main():
                        "parallelism": f"replicas over init times x{world} (no data-path collective)",
                        "loop": "one wx_step call per step" if args.per_step_calls else "wx_rollout (the K steps in one C-ABI call)",
                        "total_steps": total_steps, "params": cfg.num_params(), "finite_outputs": finite},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "fp32": fp32, "config2": config2,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "fp32": fp32, "config2": config2, "config5": config5,
         }
         print(json.dumps(out), flush=True)
     grp.close()

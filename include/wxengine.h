@@ -166,6 +166,34 @@ int wx_winattn_create(const wx_winattn_desc* desc, const float* bias_host, int n
 int wx_winattn_apply(wx_winattn_handle w, const void* qkv_dev, void* out_dev, void* stream);
 int wx_winattn_destroy(wx_winattn_handle w);
 
+/* ---- a stage of Swin V2 (Cr) transformer blocks (BASELINE config 5) -----------------------------------
+ * credit/models/swin.py:484-502 `SwinTransformerV2CrBlock.forward` (res-post-norm: x += norm1(proj(attention(qkv(x)))), then
+ * x += norm2(fc2(GELU(fc1(x))))) repeated `depth` times as credit/models/swin.py:560-668 `SwinTransformerV2CrStage` builds it
+ * (downscale = False): even blocks unshifted, odd blocks shifted by (shift_y, shift_x) = window // 2.  FuXi's U-Transformer
+ * (credit/models/fuxi.py:250-260) runs such a stage -- through timm's class, which is not vendored: parity of THAT class is
+ * unpinned, the V2-Cr block above is pinned to the reference's own forward (tests/test_swin.py).
+ *   x_in / x_out  [H * W][C] token-major (the reference's BHWC with B = 1), bf16 or float32 per `precision`; may alias
+ *   wx_swin_load(block, name, ...): name in {"attn.qkv.weight" [3C][C], "attn.qkv.bias", "attn.proj.weight" [C][C], "attn.proj.bias",
+ *     "attn.bias_table" [heads][N][N] (the OUTPUT of swin.py:283-297 for this block's meta MLP), "attn.logit_scale" [heads]
+ *     (exp(clamp(.., max = log 100)), swin.py:307), "norm1.weight", "norm1.bias", "mlp.fc1.weight" [hidden][C], "mlp.fc1.bias",
+ *     "mlp.fc2.weight" [C][hidden], "mlp.fc2.bias", "norm2.weight", "norm2.bias"}: float32 host data, `count` elements */
+typedef struct wx_swin_desc {
+  int32_t precision;           /* WX_PREC_FP32 / WX_PREC_BF16 */
+  int32_t H, W, C, heads;
+  int32_t wsz_y, wsz_x;
+  int32_t depth, hidden;       /* hidden = int(C * mlp_ratio) */
+  int32_t shift_y, shift_x;    /* of the odd blocks */
+  float mask_value;            /* -100 (swin.py:425) */
+  float ln_eps;                /* 1e-5 (nn.LayerNorm default) */
+} wx_swin_desc;
+typedef struct wx_swin* wx_swin_handle;
+int wx_swin_create(const wx_swin_desc* desc, int device, wx_swin_handle* out);
+int wx_swin_load(wx_swin_handle s, int block, const char* name, const float* host_data, int64_t count);
+int wx_swin_finalize(wx_swin_handle s);
+int wx_swin_apply(wx_swin_handle s, const void* x_in_dev, void* x_out_dev, void* stream);
+int wx_swin_flops(wx_swin_handle s, double* flops);   /* algorithmic FLOPs of one wx_swin_apply (2*MAC of the Linear layers + attention) */
+int wx_swin_destroy(wx_swin_handle s);
+
 /* ---- conservation fixers (PostBlock) -------------------------------------------
  * A wx_post is the device-side counterpart of credit/postblock/gen1.py::PostBlock for pressure-level grids: an ordered
  * list of TracerFixer (:111-167), GlobalMassFixer (:170-391), GlobalWaterFixer (:394-569) and GlobalEnergyFixer

@@ -26,6 +26,7 @@
 #include <rccl/rccl.h>   // types and prototypes only: the library is bound with dlopen when a communicator is requested
 #include "wx_gemm.h"
 #include "wx_gemm_stream.h"
+#include "wx_swin.h"
 #include "wx_post.h"
 #include "wx_pre.h"
 
@@ -2601,6 +2602,52 @@ int wx_winattn_apply(wx_winattn_handle w, const void* qkv_dev, void* out_dev, vo
     else wx::launch_window_attn_any<float>(p, d.head_dim, (hipStream_t)stream);
   });
 }
+
+// ---- a stage of Swin V2 (Cr) blocks (BASELINE config 5: the FuXi U-Transformer's stage) -----------------
+struct wx_swin {
+  std::unique_ptr<wx::SwinStageBase> impl;
+};
+int wx_swin_create(const wx_swin_desc* d, int device, wx_swin_handle* out) {
+  return guarded([&] {
+    if (!d || !out) throw wx::ConfigError("null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw wx::HipError("no HIP device visible: wxengine has no CPU fallback");
+    if (d->precision != WX_PREC_FP32 && d->precision != WX_PREC_BF16) throw wx::ConfigError("swin: unknown precision");
+    if (d->depth < 1 || d->H < 1 || d->W < 1 || d->heads < 1 || d->wsz_y < 1 || d->wsz_x < 1) throw wx::ConfigError("swin: bad geometry");
+    wx::SwinDesc sd{d->H, d->W, d->C, d->heads, d->wsz_y, d->wsz_x, d->depth, d->hidden, d->shift_y, d->shift_x, d->mask_value, d->ln_eps};
+    auto w = std::make_unique<wx_swin>();
+    try {
+      if (d->precision == WX_PREC_BF16) w->impl = std::make_unique<wx::SwinStage<wx::bf16_t>>(sd, device);
+      else w->impl = std::make_unique<wx::SwinStage<float>>(sd, device);
+    } catch (const std::runtime_error& e) {
+      throw wx::ConfigError(e.what());
+    }
+    *out = w.release();
+  });
+}
+int wx_swin_load(wx_swin_handle w, int block, const char* name, const float* host, int64_t count) {
+  return guarded([&] {
+    if (!w || !name || !host) throw wx::ConfigError("swin: null argument");
+    try { w->impl->load(block, name, host, count); } catch (const wx::HipError&) { throw; } catch (const std::runtime_error& e) { throw wx::ShapeError(e.what()); }
+  });
+}
+int wx_swin_finalize(wx_swin_handle w) {
+  return guarded([&] {
+    if (!w) throw wx::StateError("null swin handle");
+    try { w->impl->finalize(); } catch (const std::runtime_error& e) { throw wx::StateError(e.what()); }
+  });
+}
+int wx_swin_apply(wx_swin_handle w, const void* x_in_dev, void* x_out_dev, void* stream) {
+  return guarded([&] {
+    if (!w) throw wx::StateError("null swin handle");
+    if (!x_in_dev || !x_out_dev) throw wx::ConfigError("swin: null tensor pointer");
+    try { w->impl->apply(x_in_dev, x_out_dev, (hipStream_t)stream); } catch (const wx::HipError&) { throw; } catch (const std::runtime_error& e) { throw wx::StateError(e.what()); }
+  });
+}
+int wx_swin_flops(wx_swin_handle w, double* flops) {
+  return guarded([&] { if (!w || !flops) throw wx::ConfigError("swin: null argument"); *flops = w->impl->flops(); });
+}
+int wx_swin_destroy(wx_swin_handle w) { return guarded([&] { delete w; }); }
 
 const char* wx_last_error(void) { return wx::g_last_error.c_str(); }
 #ifndef WX_SOURCE_HASH

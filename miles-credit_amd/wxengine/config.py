@@ -308,10 +308,10 @@ def named_config(name: str) -> WXConfig:
         mc = dict(base, image_height=61, image_width=120, levels=5, output_only_channels=2,
                   dim=[32, 64, 128, 256], depth=[2, 1, 2, 1], global_window_size=[5, 5, 2, 1], local_window_size=5,
                   padding_conf=dict(activate=True, mode="earth", pad_lat=[11, 9], pad_lon=[24, 16]))
-    elif name == "T5":  # T1 geometry with the WIDTHS of the 0.25-degree model's deep stages (C = 512 / 1024): every launch shape of
+    elif name == "T5":  # T1 geometry with the WIDTHS of the 0.25-degree model (C = 128 / 256 / 512 / 1024): every launch shape of
         # C3's stages 2-3 (persistent GEMM, k-blocked hidden, 4-token packed windows, v-only long attention) on 200 / 50 rows
         mc = dict(base, image_height=61, image_width=120, levels=5, output_only_channels=2,
-                  dim=[32, 64, 512, 1024], depth=[1, 1, 2, 1], global_window_size=[5, 5, 2, 1], local_window_size=5,
+                  dim=[128, 256, 512, 1024], depth=[1, 1, 2, 1], global_window_size=[5, 5, 2, 1], local_window_size=5,
                   padding_conf=dict(activate=True, mode="earth", pad_lat=[11, 9], pad_lon=[24, 16]))
     elif name == "C1":  # credit_smoke_test_v2.yml:119-160
         mc = dict(base, image_height=181, image_width=360, levels=18,

@@ -115,6 +115,12 @@ _PROTOTYPES = {
     "wx_winattn_create": ([C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     "wx_winattn_apply": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "wx_winattn_destroy": ([C.c_void_p], C.c_int),
+    "wx_swin_create": ([C.c_void_p, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    "wx_swin_load": ([C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_float), C.c_int64], C.c_int),
+    "wx_swin_finalize": ([C.c_void_p], C.c_int),
+    "wx_swin_apply": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "wx_swin_flops": ([C.c_void_p, C.POINTER(C.c_double)], C.c_int),
+    "wx_swin_destroy": ([C.c_void_p], C.c_int),
     "wx_last_error": ([], C.c_char_p),
     "wx_version": ([], C.c_char_p),
 }

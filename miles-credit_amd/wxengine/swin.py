@@ -102,3 +102,96 @@ class WindowAttention:
             _check(self.lib.wx_winattn_apply(self._h, C.c_void_p(qkv.data_ptr()), C.c_void_p(out.data_ptr()),
                                              C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         return out
+
+
+class wx_swin_desc(C.Structure):
+    _fields_ = [("precision", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32),
+                ("wsz_y", C.c_int32), ("wsz_x", C.c_int32), ("depth", C.c_int32), ("hidden", C.c_int32), ("shift_y", C.c_int32),
+                ("shift_x", C.c_int32), ("mask_value", C.c_float), ("ln_eps", C.c_float)]
+
+
+class SwinStage:
+    """`depth` Swin V2 (Cr) blocks on a token-major map resident in HBM (C ABI `wx_swin_*`): the host-side mirror of
+    credit/models/swin.py::SwinTransformerV2CrStage (:560-668, downscale = False) made of SwinTransformerV2CrBlock (:330-502).
+    Same constructor vocabulary (`dim`, `num_heads`, `feat_size`, `window_size`, `mlp_ratio`), same state-dict keys
+    (`blocks.{i}.attn.qkv.weight`, `blocks.{i}.attn.meta_mlp.fc1.weight`, `blocks.{i}.attn.logit_scale`, `blocks.{i}.norm1.weight`,
+    `blocks.{i}.mlp.fc1.weight`, ...): a reference checkpoint's stage loads unchanged; the meta MLP of every block is evaluated
+    once, on the host, into that block's [heads, N, N] bias table.  Even blocks are unshifted, odd blocks shifted by window // 2
+    (a window as large as the map is not shifted, swin.py:407-409).  No CPU fallback."""
+
+    _DIRECT = ("attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm1.weight", "norm1.bias",
+               "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias", "norm2.weight", "norm2.bias")
+
+    def __init__(self, dim: int, depth: int, num_heads: int, feat_size: Tuple[int, int], window_size, mlp_ratio: float = 4.0,
+                 precision: str = "bf16", device: Optional[int] = None):
+        import torch
+        if not torch.cuda.is_available():
+            raise WXEngineError("no GPU visible: the Swin stage has no CPU fallback")
+        self.lib = load_library()
+        ws = (int(window_size), int(window_size)) if np.isscalar(window_size) else (int(window_size[0]), int(window_size[1]))
+        # swin.py:405-409 `_calc_window_shift`: a window is clipped to the map, and a clipped axis is not shifted
+        self.window = tuple(f if f <= w else w for f, w in zip(feat_size, ws))
+        self.shift = tuple(0 if f <= w else w // 2 for f, w in zip(feat_size, self.window))
+        self.dim, self.depth, self.heads, self.feat = int(dim), int(depth), int(num_heads), (int(feat_size[0]), int(feat_size[1]))
+        self.hidden = int(dim * mlp_ratio)
+        self.precision = precision
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        d = wx_swin_desc(PREC[precision], self.feat[0], self.feat[1], self.dim, self.heads, self.window[0], self.window[1], self.depth,
+                         self.hidden, self.shift[0], self.shift[1], -100.0, 1e-5)
+        self._h = C.c_void_p()
+        self.lib.wx_swin_create.argtypes = [C.POINTER(wx_swin_desc), C.c_int, C.POINTER(C.c_void_p)]
+        _check(self.lib.wx_swin_create(C.byref(d), self.device, C.byref(self._h)))
+        self._loaded = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self.lib.wx_swin_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _put(self, block: int, name: str, arr) -> None:
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32))
+        _check(self.lib.wx_swin_load(self._h, block, name.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size))
+
+    def load_state_dict(self, sd, prefix: str = "blocks.") -> None:
+        """sd: {key: array-like} with the reference stage's keys; missing keys raise (KeyError names the first one)."""
+        get = lambda k: np.asarray(sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k], dtype=np.float32)  # noqa: E731
+        for i in range(self.depth):
+            p = f"{prefix}{i}."
+            for name in self._DIRECT:
+                self._put(i, name, get(p + name))
+            self._put(i, "attn.bias_table", relative_position_bias(get(p + "attn.meta_mlp.fc1.weight"), get(p + "attn.meta_mlp.fc1.bias"),
+                                                                  get(p + "attn.meta_mlp.fc2.weight"), get(p + "attn.meta_mlp.fc2.bias"),
+                                                                  self.window))
+            self._put(i, "attn.logit_scale", effective_logit_scale(get(p + "attn.logit_scale")))
+        _check(self.lib.wx_swin_finalize(self._h))
+        self._loaded = True
+
+    @property
+    def flops(self) -> float:
+        f = C.c_double()
+        _check(self.lib.wx_swin_flops(self._h, C.byref(f)))
+        return float(f.value)
+
+    def __call__(self, x, out=None):
+        """x [H, W, C] (or [H*W, C]) on the GPU in the stage's precision -> the stage output, same shape (out may be x)."""
+        import torch
+        want = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        H, W = self.feat
+        if not self._loaded:
+            raise WXEngineError("load_state_dict first")
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == want and x.is_contiguous() and x.numel() == H * W * self.dim
+                and x.shape[-1] == self.dim):
+            raise WXEngineError(f"x must be a contiguous {want} tensor [{H}, {W}, {self.dim}] on the GPU")
+        if x.device.index != self.device:
+            raise WXEngineError(f"x is on cuda:{x.device.index}, the stage was created for cuda:{self.device}")
+        if out is None:
+            out = torch.empty_like(x)
+        elif not (out.is_cuda and out.dtype == want and out.is_contiguous() and out.shape == x.shape):
+            raise WXEngineError("out must match x")
+        with torch.cuda.device(self.device):
+            _check(self.lib.wx_swin_apply(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out

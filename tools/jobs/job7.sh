@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+(WX_ABL=1 WX_ONLY=0 timeout 900 tools/_build/gemm_s32_probe 0 2>&1) > gpurun_out/j7_abl.log 2>&1
+grep -E "ablation|us .* TF|FAIL|PROBE" gpurun_out/j7_abl.log

@@ -296,6 +296,83 @@ def swin_golden():
     np.savez_compressed(os.path.join(GOLD, "swin_attention.npz"), **out)
 
 
+def swin_block_golden():
+    """SURVEY.md 8(f) row 4, part 2: the whole Swin V2 (Cr) BLOCK and a two-block stage, through the reference's own code:
+    `SwinTransformerV2CrBlock.forward` (:484-502), `._shifted_window_attn` (:451-486), `._make_attention_mask` (:411-427) and
+    `._calc_window_shift` (:405-409) called on a duck-typed `self` that carries real `nn.Linear` / `nn.LayerNorm` modules, and
+    `WindowMultiHeadAttention.forward`, `._relative_positional_encodings`, `._make_pair_wise_relative_positions` (:254-330) on a
+    `WindowMultiHeadAttention` built without its constructor.  NOT reference code: `timm.layers.Mlp` (the block's `mlp` and the
+    attention's `meta_mlp`) -- timm is neither vendored nor pinned; `_Mlp` below restates it as fc1 -> act -> fc2
+    (eval mode: its dropouts are identities), which is the part of this fixture that stays unpinned.
+    Blocks alternate shift 0 / window // 2 exactly as SwinTransformerV2CrStage (:616-640) builds them."""
+    import types
+    from credit.models import swin as R
+
+    class _Mlp(torch.nn.Module):
+        def __init__(self, i, h, o, act):
+            super().__init__()
+            self.fc1, self.act, self.fc2 = torch.nn.Linear(i, h), act(), torch.nn.Linear(h, o)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    out = {}
+    cases = {"rect": ((12, 16), (4, 8), 2, 32, 2), "fuxi_like": ((14, 21), (7, 7), 1, 128, 2), "clipped": ((4, 16), (8, 8), 2, 32, 2)}
+    for name, (feat, ws_t, heads, hd, depth) in cases.items():
+        C = heads * hd
+        g = torch.Generator().manual_seed(1000 + sum(map(ord, name)))
+        rnd = lambda *shape, s=1.0: torch.randn(*shape, generator=g) * s  # noqa: E731
+        x = rnd(1, feat[0], feat[1], C)
+        sd = {}
+        ys = []
+        cur = x
+        for i in range(depth):
+            blk = types.SimpleNamespace(dim=C, feat_size=feat, target_shift_size=tuple(0 if i % 2 == 0 else w // 2 for w in ws_t))
+            blk.window_size, blk.shift_size = R.SwinTransformerV2CrBlock._calc_window_shift(blk, ws_t)
+            ws = blk.window_size
+            blk.window_area = ws[0] * ws[1]
+            attn = R.WindowMultiHeadAttention.__new__(R.WindowMultiHeadAttention)
+            torch.nn.Module.__init__(attn)
+            attn.in_features, attn.window_size, attn.num_heads, attn.sequential_attn = C, ws, heads, False
+            attn.qkv, attn.proj = torch.nn.Linear(C, 3 * C), torch.nn.Linear(C, C)
+            attn.attn_drop, attn.proj_drop = torch.nn.Identity(), torch.nn.Identity()
+            attn.meta_mlp = _Mlp(2, 48, heads, torch.nn.ReLU)
+            attn.logit_scale = torch.nn.Parameter(torch.log(10 * torch.ones(heads)) + rnd(heads, s=0.3))
+            R.WindowMultiHeadAttention._make_pair_wise_relative_positions(attn)
+            blk.attn = attn
+            blk.norm1, blk.norm2, blk.norm3 = torch.nn.LayerNorm(C), torch.nn.LayerNorm(C), torch.nn.Identity()
+            blk.drop_path1, blk.drop_path2 = torch.nn.Identity(), torch.nn.Identity()
+            blk.mlp = _Mlp(C, 4 * C, C, torch.nn.GELU)
+            with torch.no_grad():
+                for lin, sc in ((attn.qkv, C ** -0.5), (attn.proj, C ** -0.5), (blk.mlp.fc1, C ** -0.5), (blk.mlp.fc2, (4 * C) ** -0.5),
+                                (attn.meta_mlp.fc1, 0.7), (attn.meta_mlp.fc2, 0.15)):
+                    lin.weight.copy_(rnd(*lin.weight.shape, s=sc))
+                    lin.bias.copy_(rnd(*lin.bias.shape, s=0.1))
+                for nm in (blk.norm1, blk.norm2):
+                    nm.weight.copy_(1.0 + rnd(C, s=0.2))
+                    nm.bias.copy_(rnd(C, s=0.1))
+            blk.register_buffer = lambda k, v, persistent=False, b=blk: setattr(b, k, v)
+            R.SwinTransformerV2CrBlock._make_attention_mask(blk)
+            blk._shifted_window_attn = types.MethodType(R.SwinTransformerV2CrBlock._shifted_window_attn, blk)
+            with torch.no_grad():
+                cur = R.SwinTransformerV2CrBlock.forward(blk, cur)
+            ys.append(cur[0].numpy().astype(np.float32))
+            for mod, pre in ((attn.qkv, "attn.qkv."), (attn.proj, "attn.proj."), (attn.meta_mlp.fc1, "attn.meta_mlp.fc1."),
+                             (attn.meta_mlp.fc2, "attn.meta_mlp.fc2."), (blk.norm1, "norm1."), (blk.norm2, "norm2."),
+                             (blk.mlp.fc1, "mlp.fc1."), (blk.mlp.fc2, "mlp.fc2.")):
+                sd[f"blocks.{i}.{pre}weight"] = mod.weight.detach().numpy().astype(np.float32)
+                sd[f"blocks.{i}.{pre}bias"] = mod.bias.detach().numpy().astype(np.float32)
+            sd[f"blocks.{i}.attn.logit_scale"] = attn.logit_scale.detach().numpy().astype(np.float32)
+        out[f"{name}/x"] = x[0].numpy().astype(np.float32)
+        out[f"{name}/geom"] = np.array([feat[0], feat[1], ws_t[0], ws_t[1], heads, hd, depth], dtype=np.int64)
+        for k, v in sd.items():
+            out[f"{name}/sd/{k}"] = v
+        for i, y in enumerate(ys):
+            out[f"{name}/y{i}"] = y
+        print(f"[golden] swin block {name}: feat {feat} window {ws_t} heads {heads} hd {hd} depth {depth}  mean|y|={np.abs(ys[-1]).mean():.4f}")
+    np.savez_compressed(os.path.join(GOLD, "swin_block.npz"), **out)
+
+
 def fixer_inputs(seed=11):
     """Physically plausible random fields on the reference's 10x18 / 7-level demo grid.
     x: [T(7) | q(7) | U(7) | V(7)] x 2 frames; y: the same 28 + [TOA solar, TOA OLR, surf solar, surf LR, SH, LH, precip, evapor]."""
@@ -553,7 +630,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,swin,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
+    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -564,6 +641,8 @@ def main():
             glue_golden()
         elif item == "swin":
             swin_golden()
+        elif item == "swinblock":
+            swin_block_golden()
         elif item == "rollC1":      # BASELINE config 2: 24-step rollout on the 1-degree grid
             long_rollout_golden("C1", 24, 20)
         elif item == "rollC3S":     # 8 steps on the 0.25-degree grid (small-width model)

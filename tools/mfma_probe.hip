@@ -15,9 +15,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // SHAPE 0: 16x16x32 with NA x NB accumulators of 4 regs; SHAPE 1: 32x32x16 with NA x NB accumulators of 16 regs
 // PARTNER 0: every wave runs MFMAs; 1: waves >= 4 of the workgroup run v_fma chains; 2: waves >= 4 run v_exp chains; 3: waves >= 4 idle-exit
+// PARTNER 4: the MFMA waves exit (VALU stream alone); 5 / 6: as 1 with s_setprio 3 on the MFMA waves / on the VALU waves
 template <int SHAPE, int NA, int NB, int PARTNER>
 __global__ __launch_bounds__(512) void mfma_stream(const bf16x8* __restrict__ src, float* __restrict__ out, int iters, int valu_iters) {
-  const int tid = threadIdx.x, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (PARTNER == 4 && wave < 4) return;
+  if (PARTNER == 5 && wave < 4) __builtin_amdgcn_s_setprio(3);
+  if (PARTNER == 6 && wave >= 4) __builtin_amdgcn_s_setprio(3);
   if (PARTNER != 0 && wave >= 4) {
     if (PARTNER == 3) return;
     float v[16];
@@ -26,7 +30,7 @@ __global__ __launch_bounds__(512) void mfma_stream(const bf16x8* __restrict__ sr
     for (int it = 0; it < valu_iters; ++it) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        if (PARTNER == 1) v[i] = __builtin_fmaf(v[i], 0.999f, 0.001f);
+        if (PARTNER != 2) v[i] = __builtin_fmaf(v[i], 0.999f, 0.001f);
         else v[i] = __builtin_amdgcn_exp2f(v[i] * 0.5f);
       }
     }
@@ -82,6 +86,102 @@ __global__ __launch_bounds__(512) void mfma_stream(const bf16x8* __restrict__ sr
   }
 }
 
+// ONE wave per SIMD: NV independent v_fma_f32 (inline asm, pinned order) after every MFMA -- how many VALU slots hide under an MFMA
+// FILL 0: v_fma_f32   1: s_add_u32 (SALU)   2: ds_read_b128 (one s_waitcnt lgkmcnt(0) per 8 MFMAs)   3: s_nop 0
+#define FMA1(x)                                                                                                        \
+  do {                                                                                                                 \
+    if constexpr (FILL == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c0), "v"(c1));                     \
+    else if constexpr (FILL == 1) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sacc));                                     \
+    else if constexpr (FILL == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(ldsv) : "v"(ldsa));                         \
+    else asm volatile("s_nop 0");                                                                                       \
+  } while (0)
+template <int SHAPE, int NV, int WAVES, int FILL = 0>
+__global__ __launch_bounds__(64 * WAVES) void mfma_interleave(const bf16x8* __restrict__ src, float* __restrict__ out, int iters) {
+  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) char lds_buf[64 * 1024];
+  unsigned sacc = blockIdx.x;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 ldsv = {0, 0, 0, 0};
+  const unsigned ldsa = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_buf + (tid * 16) % 65536;
+  if (FILL == 2) { for (int i = tid; i < 16384; i += blockDim.x) reinterpret_cast<unsigned*>(lds_buf)[i] = i; __syncthreads(); }
+  bf16x8 a[2], b[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a[i] = src[(blockIdx.x * 7 + i) * 512 % 4096 + tid];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = src[(blockIdx.x * 3 + i + 5) * 512 % 4096 + tid];
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)(tid + i) * 1e-3f;
+  const float c0 = 0.999f, c1 = 0.001f;
+  float s = 0.f;
+  if constexpr (SHAPE == 0) {
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
+#pragma unroll
+          for (int k = 0; k < NV; ++k) FMA1(v[k & 7]);
+        }
+      if constexpr (FILL == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ldsv));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0];
+  } else {
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
+#pragma unroll
+          for (int k = 0; k < NV; ++k) FMA1(v[k & 7]);
+        }
+      if constexpr (FILL == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ldsv));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i];
+  s += (float)sacc + (float)ldsv[0];
+  if (s == 12345.678f) out[tid] = s;
+}
+template <int SHAPE, int NV, int WAVES, int FILL = 0>
+void run_il(const bf16x8* src, float* out) {
+  const int iters = 4000;
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  hipLaunchKernelGGL((mfma_interleave<SHAPE, NV, WAVES, FILL>), dim3(256), dim3(64 * WAVES), 0, 0, src, out, iters);
+  CK(hipEventRecord(a));
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((mfma_interleave<SHAPE, NV, WAVES, FILL>), dim3(256), dim3(64 * WAVES), 0, 0, src, out, iters);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  const double us = ms * 200.0, n_mfma = 8.0 * iters;
+  const double flop = (SHAPE == 0 ? 2.0 * 16 * 16 * 32 : 2.0 * 32 * 32 * 16) * n_mfma * WAVES * 256;
+  const char* fn[4] = {"v_fma", "s_add", "ds_read_b128", "s_nop"};
+  printf("%s %d waves/CU, %d %s after each MFMA: %8.1f us  %6.1f ns per MFMA  %6.0f TF/s   VALU %.2f Gop/s/SIMD-wave\n", SHAPE == 0 ? "16x16x32" : "32x32x16", WAVES, NV, fn[FILL], us,
+         us * 1e3 / n_mfma, flop / us * 1e-6, NV * n_mfma / us * 1e-3);
+}
+
 template <typename F> double t_us(F&& f, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int i = 0; i < 2; ++i) f();
@@ -96,7 +196,7 @@ void run(const char* tag, const bf16x8* src, float* out, int threads, int wg_per
   const int mfma_waves = PARTNER ? 4 : threads / 64;
   const int grid = 256 * wg_per_cu;
   // partner loops sized to last about as long as the MFMA stream (16 ops x valu_iters)
-  const int valu_iters = PARTNER == 1 ? iters * NA * NB * (SHAPE == 0 ? 4 : 8) / 16 : iters * NA * NB * (SHAPE == 0 ? 4 : 8) / 64;
+  const int valu_iters = PARTNER != 2 ? iters * NA * NB * (SHAPE == 0 ? 4 : 8) / 16 : iters * NA * NB * (SHAPE == 0 ? 4 : 8) / 64;
   const double us = t_us([&] { hipLaunchKernelGGL((mfma_stream<SHAPE, NA, NB, PARTNER>), dim3(grid), dim3(threads), 0, 0, src, out, iters, valu_iters); }, 5);
   const double tf = flop_per * NA * NB * iters * mfma_waves * grid / us * 1e-6;
   printf("%-64s %8.1f us  %7.0f TF/s  (%.1f %% of 2500)\n", tag, us, tf, tf / 25.0);
@@ -132,6 +232,18 @@ int main() {
     snprintf(t, 128, "32x32x16 5x2 + partner wave v_fma stream    %s", d); run<1, 5, 2, 1>(t, src, out, 512, 1);
     snprintf(t, 128, "32x32x16 5x2 + partner wave v_exp stream    %s", d); run<1, 5, 2, 2>(t, src, out, 512, 1);
     snprintf(t, 128, "32x32x16 5x2 + partner wave exits           %s", d); run<1, 5, 2, 3>(t, src, out, 512, 1);
+    snprintf(t, 128, "(TF column meaningless) v_fma stream ALONE, MFMA waves exit %s", d); run<0, 5, 8, 4>(t, src, out, 512, 1);
+    snprintf(t, 128, "16x16x32 5x8 + partner v_fma, MFMA waves setprio 3  %s", d); run<0, 5, 8, 5>(t, src, out, 512, 1);
+    snprintf(t, 128, "16x16x32 5x8 + partner v_fma, VALU waves setprio 3  %s", d); run<0, 5, 8, 6>(t, src, out, 512, 1);
+    run_il<0, 0, 4>(src, out); run_il<0, 1, 4>(src, out); run_il<0, 2, 4>(src, out); run_il<0, 3, 4>(src, out); run_il<0, 4, 4>(src, out);
+    run_il<0, 6, 4>(src, out); run_il<0, 8, 4>(src, out);
+    run_il<1, 0, 4>(src, out); run_il<1, 2, 4>(src, out); run_il<1, 4, 4>(src, out); run_il<1, 6, 4>(src, out); run_il<1, 8, 4>(src, out); run_il<1, 12, 4>(src, out);
+    run_il<0, 0, 8>(src, out); run_il<0, 2, 8>(src, out); run_il<0, 4, 8>(src, out);
+    run_il<0, 1, 4, 1>(src, out); run_il<0, 2, 4, 1>(src, out); run_il<0, 4, 4, 1>(src, out); run_il<0, 8, 4, 1>(src, out);
+    run_il<1, 2, 4, 1>(src, out); run_il<1, 4, 4, 1>(src, out); run_il<1, 8, 4, 1>(src, out);
+    run_il<0, 1, 4, 2>(src, out); run_il<0, 2, 4, 2>(src, out); run_il<1, 1, 4, 2>(src, out); run_il<1, 2, 4, 2>(src, out);
+    run_il<0, 2, 4, 3>(src, out); run_il<0, 4, 4, 3>(src, out); run_il<1, 4, 4, 3>(src, out);
+    run_il<0, 2, 8, 1>(src, out); run_il<0, 4, 8, 1>(src, out); run_il<0, 1, 8, 2>(src, out); run_il<1, 1, 8, 2>(src, out);
   }
   return 0;
 }
