@@ -96,57 +96,44 @@ __device__ inline uint4 pack16<bf16_t>(const float* in) {
 }
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// GELU for the bf16 engine: x * Phi(x) with Phi(x) - 1/2 = xc * P(xc^2) / Q(xc^2), xc = clamp(x, -5, 5), a (3,3)
-// rational minimax fit (weighted for the GELU error): |gelu_fast - gelu| <= 1.5e-5 for |x| <= 9 (fp32 evaluation),
-// i.e. < 1/100 of a bf16 ulp of the result wherever the result is not itself negligible.  ~10 VALU slots per element
-// (two elements per v_pk_fma) against ~45 for libm erff, which made the FF1 epilogue VALU-bound (tools/gemm_probe).
-// The fp32 engine keeps erff.
+// GELU for the bf16 engine: x * sigmoid(g(xc)), xc = clamp(x, -8, 8), g an odd degree-5 polynomial fitted to logit(Phi(x)) (minimax on
+// |x sigmoid(g(x)) - gelu(x)|, x in [-7, 7]): |gelu_fast - gelu| <= 2.6e-5 in fp32 evaluation -- 1/150 of a bf16 ulp at 1 --
+// as 1 / (1 + exp2(xc * q(xc^2))) with -log2(e) folded into q.  7 VALU + 2 transcendental ops per element (v_exp_f32, v_rcp_f32).
+// Round 3 (tools/mfma_probe): every plain VALU instruction costs a 4-cycle slot of the port the MFMAs are issued through, from
+// this wave or its SIMD partner alike, while a transcendental costs less than half of that -- the (3,3) rational of rounds 1-2
+// (11 VALU + 1/4 v_rcp per element; |err| 1.5e-5) made the FeedForward epilogues a third of their kernels.  The fp32 engine keeps erff.
 __device__ inline f32x2_t gelu_fast2(f32x2_t x) {
-  const f32x2_t xc = {__builtin_amdgcn_fmed3f(x.x, -5.f, 5.f), __builtin_amdgcn_fmed3f(x.y, -5.f, 5.f)};
-  const f32x2_t u = xc * xc;
-  f32x2_t pn = u * 3.009831178e-05f + 3.759064428e-03f;
-  f32x2_t qn = u * 1.096669979e-03f + 2.464125424e-02f;
-  pn = pn * u + 2.940779157e-02f;
-  qn = qn * u + 2.400543728e-01f;
-  pn = pn * u + 3.988773138e-01f;
-  qn = qn * u + 1.0f;
-  const f32x2_t rq = {__builtin_amdgcn_rcpf(qn.x), __builtin_amdgcn_rcpf(qn.y)};
-  return x * (xc * (pn * rq) + 0.5f);
+  const f32x2_t xc = {__builtin_amdgcn_fmed3f(x.x, -8.f, 8.f), __builtin_amdgcn_fmed3f(x.y, -8.f, 8.f)};
+  const f32x2_t t = xc * xc;
+  f32x2_t q = t * 1.014263058e-03f + -1.067757239e-01f;
+  q = q * t + -2.301121342e+00f;
+  const f32x2_t u = xc * q;
+  const f32x2_t d = {1.0f + __builtin_amdgcn_exp2f(u.x), 1.0f + __builtin_amdgcn_exp2f(u.y)};
+  return f32x2_t{x.x * __builtin_amdgcn_rcpf(d.x), x.y * __builtin_amdgcn_rcpf(d.y)};
 }
-// N pairs at a time, written step-by-step ACROSS the pairs: hipcc keeps the source order, and a chain-by-chain
-// formulation leaves every packed op waiting on its predecessor (s_nop between dependent v_pk_* ops) -- the
-// feed-forward kernels are VALU-bound on exactly this code.  One v_rcp_f32 (quarter rate) serves four denominators:
-//   r = 1/(Q0 Q1 Q2 Q3);  1/Q0 = r (Q2 Q3) Q1, ...   (Q in [1, 40]: the product stays far inside fp32 range)
+// N pairs at a time, written step-by-step ACROSS the pairs: hipcc keeps the source order, and a chain-by-chain formulation
+// leaves every op waiting on its predecessor
 template <int NP>
-__device__ inline void gelu_fast_pairs(f32x2_t* v) {  // NP even
-  f32x2_t xc[NP], u[NP], pn[NP], qn[NP];
+__device__ inline void gelu_fast_pairs(f32x2_t* v) {
+  f32x2_t xc[NP], t[NP], q[NP];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) xc[i] = f32x2_t{__builtin_amdgcn_fmed3f(v[i].x, -5.f, 5.f), __builtin_amdgcn_fmed3f(v[i].y, -5.f, 5.f)};
+  for (int i = 0; i < NP; ++i) xc[i] = f32x2_t{__builtin_amdgcn_fmed3f(v[i].x, -8.f, 8.f), __builtin_amdgcn_fmed3f(v[i].y, -8.f, 8.f)};
 #pragma unroll
-  for (int i = 0; i < NP; ++i) u[i] = xc[i] * xc[i];
+  for (int i = 0; i < NP; ++i) t[i] = xc[i] * xc[i];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) { pn[i] = u[i] * 3.009831178e-05f + 3.759064428e-03f; qn[i] = u[i] * 1.096669979e-03f + 2.464125424e-02f; }
+  for (int i = 0; i < NP; ++i) q[i] = t[i] * 1.014263058e-03f + -1.067757239e-01f;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) { pn[i] = pn[i] * u[i] + 2.940779157e-02f; qn[i] = qn[i] * u[i] + 2.400543728e-01f; }
+  for (int i = 0; i < NP; ++i) q[i] = q[i] * t[i] + -2.301121342e+00f;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) { pn[i] = pn[i] * u[i] + 3.988773138e-01f; qn[i] = qn[i] * u[i] + 1.0f; }
-  f32x2_t qq[NP / 2];
-  float r[NP / 2];
+  for (int i = 0; i < NP; ++i) q[i] = xc[i] * q[i];
 #pragma unroll
-  for (int i = 0; i < NP / 2; ++i) qq[i] = qn[2 * i] * qn[2 * i + 1];  // (Qa.x Qb.x, Qa.y Qb.y)
+  for (int i = 0; i < NP; ++i) q[i] = f32x2_t{__builtin_amdgcn_exp2f(q[i].x), __builtin_amdgcn_exp2f(q[i].y)};
 #pragma unroll
-  for (int i = 0; i < NP / 2; ++i) r[i] = __builtin_amdgcn_rcpf(qq[i].x * qq[i].y);
+  for (int i = 0; i < NP; ++i) q[i] = q[i] + 1.0f;
 #pragma unroll
-  for (int i = 0; i < NP / 2; ++i) {
-    const f32x2_t rr = f32x2_t{qq[i].y, qq[i].x} * r[i];  // (1/(Qa.x Qb.x), 1/(Qa.y Qb.y))
-    const f32x2_t ia = rr * qn[2 * i + 1], ib = rr * qn[2 * i];
-    pn[2 * i] = pn[2 * i] * ia;
-    pn[2 * i + 1] = pn[2 * i + 1] * ib;
-  }
+  for (int i = 0; i < NP; ++i) q[i] = f32x2_t{__builtin_amdgcn_rcpf(q[i].x), __builtin_amdgcn_rcpf(q[i].y)};
 #pragma unroll
-  for (int i = 0; i < NP; ++i) xc[i] = xc[i] * pn[i] + 0.5f;
-#pragma unroll
-  for (int i = 0; i < NP; ++i) v[i] = v[i] * xc[i];
+  for (int i = 0; i < NP; ++i) v[i] = v[i] * q[i];
 }
 __device__ inline void gelu_fast4(f32x2_t& a, f32x2_t& b) {
   f32x2_t v[2] = {a, b};

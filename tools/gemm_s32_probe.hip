@@ -255,7 +255,15 @@ int main(int argc, char** argv) {
         qd.dbg = dbg;
         double t = 1e30;
         for (int round = 0; round < 3; ++round) t = std::min(t, time_us(st, reps, [&] { launch_gemm_s32<5, 2, 4, 1, true>(qd, s.variant, st); }));
-        printf("    PIN n4 ablation dbg=%2d (%s%s%s%s): %7.1f us %5.0f TF\n", dbg, dbg & 1 ? "no-epilogue " : "", dbg & 2 ? "no-DMA " : "", dbg & 4 ? "no-barrier " : "",
+        printf("    PIN 160x256 n4 o1 ablation dbg=%2d (%s%s%s%s): %7.1f us %5.0f TF\n", dbg, dbg & 1 ? "no-epilogue " : "", dbg & 2 ? "no-DMA " : "", dbg & 4 ? "no-barrier " : "",
+               dbg & 8 ? "no-frag-reads" : "", t, fl / t);
+      }
+      for (int dbg : {0, 1, 3, 5, 9, 7, 15}) {   // the same body at two workgroups per CU (128 x 256 tiles, 3 stages)
+        StreamGemmParams qd = qn;
+        qd.dbg = dbg;
+        double t = 1e30;
+        for (int round = 0; round < 3; ++round) t = std::min(t, time_us(st, reps, [&] { launch_gemm_s32<4, 2, 3, 2, true>(qd, s.variant, st); }));
+        printf("    PIN 128x256 n3 o2 ablation dbg=%2d (%s%s%s%s): %7.1f us %5.0f TF\n", dbg, dbg & 1 ? "no-epilogue " : "", dbg & 2 ? "no-DMA " : "", dbg & 4 ? "no-barrier " : "",
                dbg & 8 ? "no-frag-reads" : "", t, fl / t);
       }
     }
