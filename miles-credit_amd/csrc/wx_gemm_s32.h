@@ -38,7 +38,7 @@ __device__ __forceinline__ int s32_pi(int i) { return (i & 0x13) | (((i >> 2) & 
 // PIN: the stage body in an explicit instruction order (one sched_barrier-fenced group per MFMA: the MFMA, then two fragment reads or
 // one LDS-DMA piece) for ONE wave per SIMD, where nothing but the wave's own next instructions can fill the 16 port-free cycles
 // of a 32x32 MFMA; the wait for the next stage allows NST - 2 stages in flight.
-template <int FM, int FN, int NST, bool LN, bool ACT, bool RES, bool STAT, int OCC, bool PIN = false>
+template <int FM, int FN, int NST, bool LN, bool ACT, bool RES, bool STAT, int OCC, int PIN = 0>
 __global__ __launch_bounds__(256, OCC) void gemm_s32_kernel(const StreamGemmParams p) {
   constexpr int BM = 32 * FM, WN = 32 * FN, BN = 4 * WN, KB = 64;
   constexpr int A_TOT = BM / 16, B_TOT = BN / 16;
@@ -70,10 +70,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_s32_kernel(const StreamGemmPara
   // ---- DMA coordinates ----------------------------------------------------------------------------------
   const int lrow = lane >> 2, lslot = lane & 3;
   const unsigned piece = (unsigned)((lslot ^ ((lrow >> 2) & 3)) * 16);
-  const int a_cnt = (A_TOT - wave + 3) / 4;   // wave-uniform
+  // PIN == 2: every wave issues A_I pieces (the surplus ones re-load the tile's last 16 rows: same bytes, same place)
+  const int a_cnt = PIN == 2 ? A_I : (A_TOT - wave + 3) / 4;   // wave-uniform
+  auto a_piece = [&](int i) { const int q = i * 4 + wave; return PIN == 2 ? (q < A_TOT ? q : A_TOT - 1) : q; };
   unsigned a_dst[A_I], b_dst[B_I], b_off[B_I], a_off[A_I];
 #pragma unroll
-  for (int i = 0; i < A_I; ++i) a_dst[i] = lds_addr_sgpr(smem + (i * 4 + wave) * 1024);
+  for (int i = 0; i < A_I; ++i) a_dst[i] = lds_addr_sgpr(smem + a_piece(i) * 1024);
 #pragma unroll
   for (int i = 0; i < B_I; ++i) {
     const int q = i * 4 + wave, row = q * 16 + lrow;   // LDS weight row of this lane's slot
@@ -91,12 +93,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_s32_kernel(const StreamGemmPara
   unsigned i_stage = 0;
   const char* i_sa = a_base;
   const char* i_sb = w_base;
-  auto set_issue_tile = [&](int r) {
+  auto set_issue_tile = [&](int r) __attribute__((always_inline)) {
     const int m_blk = (first + r * stride) * BM;
     const int last = p.M - 1 - m_blk;   // rows beyond M re-read the last valid row (never stored)
 #pragma unroll
     for (int i = 0; i < A_I; ++i) {
-      int row = (i * 4 + wave) * 16 + lrow;
+      int row = a_piece(i) * 16 + lrow;
       row = row < last ? row : last;
       a_off[i] = (unsigned)row * a_rstride + piece;
     }
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_s32_kernel(const StreamGemmPara
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  auto row_stat = [&](int m) -> float2 {
+  auto row_stat = [&](int m) __attribute__((always_inline)) -> float2 {
     if (p.stat_tiles == 0) return p.rowstat[m];
     float s = 0.f, q = 0.f;
     const float2* src = p.rowstat + (int64_t)m * p.stat_tiles;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_s32_kernel(const StreamGemmPara
     const float var = fmaxf(q * p.stat_inv_c - mean * mean, 0.f);
     return make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
   };
-  auto stage_stats = [&](int r) {
+  auto stage_stats = [&](int r) __attribute__((always_inline)) {
     if constexpr (LN) {
       if (tid < BM) {
         int m = (first + r * stride) * BM + tid;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_s32_kernel(const StreamGemmPara
 
   // Loads unconditional, stores to a sink beyond M, explicit vmcnt after the stores: see gemm_stream_kernel (hipcc's vmcnt
   // scoreboard must not carry anything "pending" over the loop back-edge, or it drains the DMA ring inside the K loop).
-  auto epilogue = [&](int r) {
+  auto epilogue = [&](int r) __attribute__((always_inline)) {
     const int m_blk = (first + r * stride) * BM;
     if (r + 1 < n_my) stage_stats(r + 1);
     float s1[FM], s2[FM];
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_s32_kernel(const StreamGemmPara
 
   // ---- main loop over the flattened (tile, k step) stream -------------------------------------------------
   uint4 xa[FM], wa[FN], xb[FM], wb[FN];
-  auto read_set = [&](const char* st, int kk, uint4* xf, uint4* wf) {
+  auto read_set = [&](const char* st, int kk, uint4* xf, uint4* wf) __attribute__((always_inline)) {
     const int fb = f_base ^ (kk << 5);
 #pragma unroll
     for (int a = 0; a < FN; ++a) wf[a] = *reinterpret_cast<const uint4*>(st + w_frag + a * 32 * KB + fb);
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_s32_kernel(const StreamGemmPara
   unsigned c_stage = 0;
   read_set(smem, 0, xa, wa);
   int ks = 0, r = 0;
-  if constexpr (!PIN) {
+  if constexpr (PIN == 0) {
     for (int step = 0; step < total; ++step) {
       if (issued < total) { issue(); ++issued; }
       const char* cur = smem + c_stage * STAGE;
@@ -315,6 +317,111 @@ __global__ __launch_bounds__(256, OCC) void gemm_s32_kernel(const StreamGemmPara
         ++r;
         read_set(smem + c_stage * STAGE, 0, xa, wa);   // (stale bytes after the last tile: never used)
       }
+    }
+  } else if constexpr (PIN == 2) {
+    // One wave per SIMD, no branch in the steady state: five instances of one stage body (first / middle / last stage of a tile,
+    // with / without a DMA issue), every wave issues the same A_I + B_I pieces, the wait for stage s + 1 is one immediate.
+    constexpr int NM = FM * FN, NR = FM + FN, NP = A_I + B_I, NRH = (NR + 1) / 2;
+    constexpr int E_ST = FM * FN * 2 + (STAT ? FM : 0);   // stores of one epilogue
+    static_assert(NRH + NP <= NM + 3 && NST >= 4, "interleave plan");
+    auto mma1 = [&](int i, const uint4* xf, const uint4* wf, auto first_c) __attribute__((always_inline)) {
+      const int b = i / FN, a = i % FN;
+      if constexpr (decltype(first_c)::value) {
+        f32x16_t z;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) z[e] = 0.f;
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[a]), __builtin_bit_cast(bf16x8_t, xf[b]), z, 0, 0, 0);
+      } else {
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[a]), __builtin_bit_cast(bf16x8_t, xf[b]), acc[a][b], 0, 0, 0);
+      }
+    };
+    auto read1 = [&](int j, const char* st, int fb, uint4* xf, uint4* wf) __attribute__((always_inline)) {
+      if (j < FN) wf[j] = *reinterpret_cast<const uint4*>(st + w_frag + j * 32 * KB + fb);
+      else if (j < NR) xf[j - FN] = *reinterpret_cast<const uint4*>(st + (j - FN) * 32 * KB + fb);
+    };
+    unsigned i_so = 0;
+    auto piece1 = [&](int j) __attribute__((always_inline)) {
+      if (j < A_I) lds_dma16_sv(i_sa, a_off[j < A_I ? j : 0], a_dst[j < A_I ? j : 0] + i_so);
+      else if (j < NP) lds_dma16_sv(i_sb, b_off[j - A_I < B_I ? j - A_I : 0], b_dst[j - A_I < B_I ? j - A_I : 0] + i_so);
+    };
+    auto issue_advance = [&]() __attribute__((always_inline)) {
+      i_stage = (i_stage + 1 == NST) ? 0 : i_stage + 1;
+      i_sa += a_kstep;
+      i_sb += w_kstep;
+      if (++i_ks == nk) {
+        i_ks = 0;
+        if (++i_r < n_my) set_issue_tile(i_r);
+      }
+    };
+    using TT = std::true_type;
+    using FT = std::false_type;
+    const bool no_epi = p.dbg & 1;
+    auto stage = [&](auto first_c, auto last_c, auto issue_c, bool after_epi) __attribute__((always_inline)) {
+      constexpr bool LAST = decltype(last_c)::value, ISSUE = decltype(issue_c)::value;
+      const char* cur = smem + c_stage * STAGE;
+      i_so = i_stage * STAGE;
+      const int fb1 = f_base ^ 32;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        mma1(i, xa, wa, first_c);
+        if (2 * i < NR) { read1(2 * i, cur, fb1, xb, wb); read1(2 * i + 1, cur, fb1, xb, wb); }
+        else if constexpr (ISSUE) {
+          piece1(i - NRH);
+          if (i == NM - 1) {
+#pragma unroll
+            for (int j = NM - NRH; j < NP; ++j) piece1(j);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (ISSUE) {
+        issue_advance();
+        // stage s + 1 landed; the NST - 2 stages issued after it stay in flight -- and, for the two stages that follow an epilogue,
+        // its stores (younger than the pieces waited for: no reason to sit out their write-back)
+        if (after_epi) dma_wait_allow<(NST - 2) * NP + E_ST>(); else dma_wait_allow<(NST - 2) * NP>();
+      } else {
+        dma_wait_all();
+      }
+      ring_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      c_stage = (c_stage + 1 == NST) ? 0 : c_stage + 1;
+      const char* nxt = smem + c_stage * STAGE;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        mma1(i, xb, wb, FT{});
+        if (2 * i < NR && !LAST) { read1(2 * i, nxt, f_base, xa, wa); read1(2 * i + 1, nxt, f_base, xa, wa); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (LAST) {
+        if (!no_epi) epilogue(r);
+        else {
+#pragma unroll
+          for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+              asm volatile("" ::"v"(acc[a][b]));
+#endif
+            }
+        }
+        ++r;
+        read_set(nxt, 0, xa, wa);
+      }
+    };
+    // tiles before the last: every stage issues; last tile: its final NST - 1 stages do not (nk > NST is checked by the launcher)
+    for (int t = 0; t + 1 < n_my; ++t) {
+      stage(TT{}, FT{}, TT{}, t > 0);
+      stage(FT{}, FT{}, TT{}, t > 0);
+      for (int k2 = 2; k2 < nk - 1; ++k2) stage(FT{}, FT{}, TT{}, false);
+      stage(FT{}, TT{}, TT{}, false);
+    }
+    {
+      const bool ae = n_my > 1;
+      stage(TT{}, FT{}, TT{}, ae);
+      stage(FT{}, FT{}, TT{}, ae);
+      for (int k2 = 2; k2 <= nk - NST; ++k2) stage(FT{}, FT{}, TT{}, false);
+      for (int k2 = nk - NST + 1; k2 < nk - 1; ++k2) stage(FT{}, FT{}, FT{}, false);
+      stage(FT{}, TT{}, FT{}, false);
     }
   } else {
     constexpr int NM = FM * FN, NR = FM + FN;
@@ -414,7 +521,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_s32_kernel(const StreamGemmPara
   }
 }
 
-template <int FM, int FN, int NST, bool LN, bool ACT, bool RES, bool STAT, int OCC, bool PIN = false>
+template <int FM, int FN, int NST, bool LN, bool ACT, bool RES, bool STAT, int OCC, int PIN = 0>
 inline void launch_gemm_s32_v(StreamGemmParams p, hipStream_t stream) {
   constexpr int BN = 128 * FN;
   constexpr int LDS = NST * (32 * FM + BN) * 64 + 2 * BN * 4 + 2 * 32 * FM * 8;
@@ -431,7 +538,7 @@ inline void launch_gemm_s32_v(StreamGemmParams p, hipStream_t stream) {
 }
 
 // variant: 0 = plain (bias), 1 = LN fold, 2 = LN fold + GELU, 3 = bias + residual + row partials (stat slot = 32*FN channels)
-template <int FM, int FN, int NST, int OCC, bool PIN = false>
+template <int FM, int FN, int NST, int OCC, int PIN = 0>
 inline void launch_gemm_s32(const StreamGemmParams& p, int variant, hipStream_t stream) {
   switch (variant) {
     case 0: launch_gemm_s32_v<FM, FN, NST, false, false, false, false, OCC, PIN>(p, stream); break;

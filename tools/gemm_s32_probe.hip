@@ -155,11 +155,11 @@ int main(int argc, char** argv) {
     StreamGemmParams qh = qn;       // 128-column tiles (32 channels per wave)
     qh.stat_slots = N / 32;
     q4.out = y0; q4.stat_out = res ? so0 : nullptr; q.out = y0;
-    auto v_a = [&] { launch_gemm_s32<5, 2, 4, 1, true>(qn, s.variant, st); };   // 160 x 256, 4 stages, 1 workgroup per CU, pinned order
+    auto v_a = [&] { launch_gemm_s32<5, 2, 4, 1, 2>(qn, s.variant, st); };   // 160 x 256, 4 stages, 1 workgroup per CU, branch-free pinned order
     auto v_b = [&] { launch_gemm_s32<5, 2, 3, 1>(qn, s.variant, st); };   // 160 x 256, 3 stages (80 KB + ...): 1 per CU when LDS > 80 KB
     auto v_c = [&] { launch_gemm_s32<4, 2, 3, 2>(qn, s.variant, st); };   // 128 x 256, 3 stages, 2 per CU
     auto v_d = [&] { launch_gemm_s32<5, 1, 3, 2>(qh, s.variant, st); };   // 160 x 128, 3 stages, 2 per CU
-    auto v_e = [&] { launch_gemm_s32<5, 2, 5, 1, true>(qn, s.variant, st); };   // 160 x 256, 5 stages, 1 per CU, pinned order
+    auto v_e = [&] { launch_gemm_s32<5, 2, 5, 1, 2>(qn, s.variant, st); };   // 160 x 256, 5 stages, 1 per CU, branch-free pinned order
     std::function<void()> vars[5] = {v_a, v_b, v_c, v_d, v_e};
     const char* vname[5] = {"160x256 n4 PIN", "160x256 n3 o1", "128x256 n3 o2", "160x128 n3 o2", "160x256 n5 PIN"};
     const bool v_ok[5] = {N % 256 == 0, N % 256 == 0, N % 256 == 0, N % 128 == 0, N % 256 == 0};
@@ -250,19 +250,19 @@ int main(int argc, char** argv) {
         if (v_ok[v]) t_new[v] = std::min(t_new[v], time_us(st, reps, vars[v]));
     }
     if (getenv("WX_ABL")) {   // ablations of the pinned one-wave-per-SIMD K loop (p.dbg bits: 1 no epilogue, 2 no DMA, 4 no barrier, 8 no fragment reads)
-      for (int dbg : {0, 1, 3, 5, 9, 7, 15, 11, 13}) {
+      for (int dbg : {0, 1}) {
         StreamGemmParams qd = qn;
         qd.dbg = dbg;
         double t = 1e30;
-        for (int round = 0; round < 3; ++round) t = std::min(t, time_us(st, reps, [&] { launch_gemm_s32<5, 2, 4, 1, true>(qd, s.variant, st); }));
-        printf("    PIN 160x256 n4 o1 ablation dbg=%2d (%s%s%s%s): %7.1f us %5.0f TF\n", dbg, dbg & 1 ? "no-epilogue " : "", dbg & 2 ? "no-DMA " : "", dbg & 4 ? "no-barrier " : "",
+        for (int round = 0; round < 3; ++round) t = std::min(t, time_us(st, reps, [&] { launch_gemm_s32<5, 2, 5, 1, 2>(qd, s.variant, st); }));
+        printf("    PIN2 160x256 n5 o1 ablation dbg=%2d (%s%s%s%s): %7.1f us %5.0f TF\n", dbg, dbg & 1 ? "no-epilogue " : "", dbg & 2 ? "no-DMA " : "", dbg & 4 ? "no-barrier " : "",
                dbg & 8 ? "no-frag-reads" : "", t, fl / t);
       }
       for (int dbg : {0, 1, 3, 5, 9, 7, 15}) {   // the same body at two workgroups per CU (128 x 256 tiles, 3 stages)
         StreamGemmParams qd = qn;
         qd.dbg = dbg;
         double t = 1e30;
-        for (int round = 0; round < 3; ++round) t = std::min(t, time_us(st, reps, [&] { launch_gemm_s32<4, 2, 3, 2, true>(qd, s.variant, st); }));
+        for (int round = 0; round < 3; ++round) t = std::min(t, time_us(st, reps, [&] { launch_gemm_s32<4, 2, 3, 2, 1>(qd, s.variant, st); }));
         printf("    PIN 128x256 n3 o2 ablation dbg=%2d (%s%s%s%s): %7.1f us %5.0f TF\n", dbg, dbg & 1 ? "no-epilogue " : "", dbg & 2 ? "no-DMA " : "", dbg & 4 ? "no-barrier " : "",
                dbg & 8 ? "no-frag-reads" : "", t, fl / t);
       }
