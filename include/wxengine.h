@@ -283,6 +283,15 @@ int wx_band_exchange(wx_handle h, int xid, wx_band_msg* sends, int cap_sends, in
 int wx_band_begin(wx_handle h, const float* x_band, const float* frc_band, float* y_band, float* y_phys_band, float* x_next_band,
                   void* stream, int* next_xid);
 int wx_band_resume(wx_handle h, int* next_xid);   /* *next_xid = -1 when the step is complete */
+/* Overlap of an exchange with compute (credit/domain_parallel/halo_exchange.py:45-79 waits for its batch_isend_irecv in place):
+ * after this call the caller moves the bytes of every exchange on the returned stream (`adopt_stream`, or one the engine creates when
+ * it is NULL) instead of the compute stream.  wx_band_begin / wx_band_resume make that stream wait for the pack kernel, launch the
+ * part of the NEXT op that does not need the exchange (the interior rows of the 3x3 convolution behind a halo exchange) on the
+ * compute stream, and wx_band_resume makes the compute stream wait for whatever the caller has put on the transport stream before
+ * it unpacks.  wx_band_step_rccl does the same with its own stream when env WX_BAND_OVERLAP=1.  OFF by default: measured on MI355X
+ * (profiles/r03_latband_overlap_virtual_ranks_C3_bf16.txt) the two extra one-row launches and the two cross-stream event edges per exchange cost more than
+ * the ~20 us halo exchange they hide. */
+int wx_band_comm_stream(wx_handle h, void* adopt_stream, void** stream_out);
 /* RCCL transport inside the engine (one process per GPU; xGMI peer-to-peer): rank 0 draws an id, every rank receives it
  * through any side channel (the Python shim broadcasts it with torch.distributed), wx_band_rccl_init creates the
  * communicator (ncclCommInitRank), and wx_band_step_rccl runs a whole step with a grouped ncclSend/ncclRecv per exchange

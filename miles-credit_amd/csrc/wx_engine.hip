@@ -134,6 +134,7 @@ class EngineBase {
   virtual int band_messages_of(int xid, wx_band_msg* sends, int cap_s, int* n_s, wx_band_msg* recvs, int cap_r, int* n_r) = 0;
   virtual int band_begin(const float* x_own, const float* frc_own, float* y, float* y_phys, float* x_next, hipStream_t s) = 0;
   virtual int band_resume() = 0;
+  virtual void* band_comm_stream(void* adopt) = 0;
   virtual void band_rccl_init(const ncclUniqueId& id) = 0;
   virtual void band_step_rccl(const float* x_own, const float* frc_own, float* y, float* y_phys, float* x_next, hipStream_t s) = 0;
   int device = 0;
@@ -151,6 +152,8 @@ class Engine : public EngineBase {
     if (device < 0) return;   // host-only instance (wx_band_plan_create): nothing was allocated
     (void)hipSetDevice(device);
     if (b_comm) (void)RcclApi::get().CommDestroy(b_comm);
+    if (b_cstream_own && b_cstream) (void)hipStreamDestroy(b_cstream);
+    if (b_ev_pack) { (void)hipEventDestroy(b_ev_pack); (void)hipEventDestroy(b_ev_done); }
     roll_invalidate();
     if (roll_stream) { (void)hipStreamDestroy(roll_stream); (void)hipEventDestroy(roll_ev_in); (void)hipEventDestroy(roll_ev_out); }
     for (void* p : allocs) (void)hipFree(p);
@@ -1144,8 +1147,9 @@ class Engine : public EngineBase {
       made_stats = true;
     }
     if (want_gn && fuse_ln && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr)) {
-      p.gn_out = gnpart;
+      p.gn_out = gnpart + (int64_t)gn_tile_off * w.n;   // gn_accum: several launches (interior / boundary rows) append their tiles
       made_stats = true;
+      if (gn_accum) gn_tile_off += cdiv((int64_t)out_h * out_w, 128);
     }
     if constexpr (sizeof(T) == 2) {
       // LayerNorm-folded 1x1 layers with many rows and K >= 512 (to_qkv, FeedForward layer 1 of stages 2-3): the persistent
@@ -1302,14 +1306,18 @@ class Engine : public EngineBase {
     stat_tiles_ready = st ? last_stat_slots : 0;
     capture(dbg_name, x, h, w, c, ld, w);
   }
+  int gn_tile_off = 0;      // tiles already written to gnpart by earlier launches of the same conv (gn_accum)
+  bool gn_accum = false;
   void gn_local_stats(const T* x, int c, int64_t m, bool have_partials) {   // -> gn_acc[2c] (sum, sum sq) in fp64
     constexpr int VEC = 16 / (int)sizeof(T);
     if (c / VEC > 256) throw ConfigError("GroupNorm width unsupported");
     if (have_partials) {  // the producing conv's epilogue left per-tile (sum, sum sq): just fold them
-      timed("gn_stats", 0.0, (double)cdiv(m, 128) * c * 8.0, [&] {
-        hipLaunchKernelGGL(gn_fold_partials_kernel, dim3(c), dim3(256), 0, cur_stream, gnpart, cdiv(m, 128), c, gn_acc);
+      const int tiles = gn_tile_off > 0 ? gn_tile_off : cdiv(m, 128);
+      timed("gn_stats", 0.0, (double)tiles * c * 8.0, [&] {
+        hipLaunchKernelGGL(gn_fold_partials_kernel, dim3(c), dim3(256), 0, cur_stream, gnpart, tiles, c, gn_acc);
         WX_HIP(hipGetLastError());
       });
+      gn_tile_off = 0;
     } else {
       WX_HIP(hipMemsetAsync(gn_acc, 0, 2 * c * sizeof(double), cur_stream));
       const int rows_per_block = 256 / (c / VEC);
@@ -1539,6 +1547,38 @@ class Engine : public EngineBase {
   int64_t b_send_need = 0, b_recv_need = 0;
   std::vector<std::function<void()>> b_ops;
   std::vector<int> b_xid;              // exchange that follows op i, or -1
+  std::vector<std::function<void()>> b_pre;   // op i's part that does not depend on the exchange before it (interior rows): launched
+                                              // right after that exchange's pack, i.e. while its bytes are on the wire
+  // overlap: the transport of an exchange runs on a second stream between two events (pack done -> bytes moved), so the compute
+  // stream keeps going with b_pre[i]; credit/domain_parallel/halo_exchange.py:45-79 waits for its batch_isend_irecv in place
+  hipStream_t b_cstream = nullptr;
+  hipEvent_t b_ev_pack = nullptr, b_ev_done = nullptr;
+  bool b_async = false, b_cstream_own = false;
+  // interior / boundary split of the convolutions behind a halo exchange: OFF unless an overlapped transport asks for it (measured on
+  // MI355X, profiles/r03_latband_overlap_virtual_ranks_C3_bf16.txt: the two one-row launches cost each rank more than the ~20 us exchange they would hide)
+  bool b_split = getenv("WX_BAND_SPLIT") && getenv("WX_BAND_SPLIT")[0] == '1';
+  void* band_comm_stream(void* adopt) override {
+    band_need();
+    WX_HIP(hipSetDevice(device));
+    if (adopt) {
+      if (b_cstream_own && b_cstream) (void)hipStreamDestroy(b_cstream);
+      b_cstream = (hipStream_t)adopt; b_cstream_own = false;
+    } else if (!b_cstream) {
+      WX_HIP(hipStreamCreateWithFlags(&b_cstream, hipStreamNonBlocking));
+      b_cstream_own = true;
+    }
+    if (!b_ev_pack) {
+      WX_HIP(hipEventCreateWithFlags(&b_ev_pack, hipEventDisableTiming));
+      WX_HIP(hipEventCreateWithFlags(&b_ev_done, hipEventDisableTiming));
+    }
+    b_async = true;
+    if (!b_split) {   // an overlapped transport: give it something to overlap with
+      if (b_pending >= 0) throw StateError("wx_band_comm_stream: a step is in flight");
+      b_split = true;
+      band_build_program();
+    }
+    return (void*)b_cstream;
+  }
   size_t b_pc = 0;
   int b_pending = -1;
   const float *bx_own = nullptr, *bfrc_own = nullptr;
@@ -1803,7 +1843,9 @@ class Engine : public EngineBase {
     }
     b_ops.push_back(std::move(f));
     b_xid.push_back(xid);
+    b_pre.emplace_back();
   }
+  void band_pre(std::function<void()> f) { b_pre.back() = std::move(f); }   // the exchange-independent part of the op pushed last
   void band_attach(const std::string& name) {   // the exchange follows the op pushed last
     if (b_xid.empty() || b_xid.back() >= 0) throw StateError("band: two exchanges after one op at " + name);
     b_xid.back() = band_take(name);
@@ -1826,10 +1868,41 @@ class Engine : public EngineBase {
     if (m_local <= 0) return;
     gn_finalize_apply(x, c, m_local, m_global, g_off, b_off, res, res_ld, out, out_ld);
   }
+  // A 3x3 conv (+ GroupNorm partials) over a band whose input buffer carries one halo row above and below (rows + 2 buffer rows).
+  // Output rows 1 .. rows - 2 need no halo: they are launched as the op's `pre` part, right after the halo exchange was packed
+  // (boundary = false); the two outer rows follow once the halo rows have arrived (boundary = true).  The GroupNorm tile
+  // partials of the three launches are appended to one list and folded together.
+  bool band_conv3_rows(const ConvW& w, const T* in, T* out, int rows, int wd, int c, bool boundary) {
+    if (rows <= 0) { if (boundary) gn_tile_off = 0; return false; }
+    const int64_t row = (int64_t)wd * c;
+    const bool split = b_split && rows >= 4;
+    bool gp = false;
+    if (!boundary) {
+      gn_tile_off = 0;
+      if (!split) return false;
+      gn_accum = true;
+      gp = gemm("gemm_conv3", w, in + row, rows, wd, c, 1, 0, 1, rows - 2, wd, out + row, c, nullptr, 0, nullptr, 0, 0, 0, 0, 0, false, true);
+      gn_accum = false;
+      if (!gp) gn_tile_off = 0;
+      return gp;
+    }
+    if (!split) {
+      gn_tile_off = 0;
+      return gemm("gemm_conv3", w, in, rows + 2, wd, c, 1, 0, 1, rows, wd, out, c, nullptr, 0, nullptr, 0, 0, 0, 0, 0, false, true);
+    }
+    const bool pre_gp = gn_tile_off > 0;   // the interior launch left partials
+    gn_accum = true;
+    gp = gemm("gemm_conv3", w, in, 3, wd, c, 1, 0, 1, 1, wd, out, c, nullptr, 0, nullptr, 0, 0, 0, 0, 0, false, pre_gp);
+    gp = gemm("gemm_conv3", w, in + (rows - 1) * row, 3, wd, c, 1, 0, 1, 1, wd, out + (rows - 1) * row, c, nullptr, 0, nullptr, 0, 0, 0, 0, 0, false,
+              pre_gp) && gp;
+    gn_accum = false;
+    if (!(pre_gp && gp)) gn_tile_off = 0;   // (no partials: band_gn_local falls back to the two-pass statistics kernel)
+    return pre_gp && gp;
+  }
   void band_build_program() {
     const BandGeom& g = bplan.g;
     const int r = b_rank;
-    b_ops.clear(); b_xid.clear(); b_next_x = 0;
+    b_ops.clear(); b_xid.clear(); b_pre.clear(); b_next_x = 0;
     band_op([] {}, "x_rows");
     // stage 0: pack the band's padded patch, CrossEmbed
     band_op([this, r] {
@@ -1898,15 +1971,12 @@ class Engine : public EngineBase {
         }
       }, "halo_scut", lv);
       band_op([this, i, so, r] {
-        const BandGeom& g = bplan.g;
         const UpL& u = ups[i];
-        const int rows = g.rows_short(so, r);
-        bool gp = false;
-        if (rows > 0)
-          gp = gemm("gemm_conv3", u.c1, bscut, rows + 2, sw[so], u.cout, 1, 0, 1, rows, sw[so], bta, u.cout, nullptr, 0, nullptr, 0, 0, 0, 0, 0,
-                    false, true);
+        const int rows = bplan.g.rows_short(so, r);
+        const bool gp = band_conv3_rows(u.c1, bscut, bta, rows, sw[so], u.cout, /*boundary=*/true);
         band_gn_local(bta, u.cout, (int64_t)rows * sw[so], gp);
       }, "gn", lv + ".0");
+      band_pre([this, i, so, r] { band_conv3_rows(ups[i].c1, bscut, bta, bplan.g.rows_short(so, r), sw[so], ups[i].cout, /*boundary=*/false); });
       band_op([this, i, so, r] {
         const BandGeom& g = bplan.g;
         const UpL& u = ups[i];
@@ -1915,15 +1985,12 @@ class Engine : public EngineBase {
                        btb + (int64_t)sw[so] * u.cout, u.cout);
       }, "halo_tb", lv);
       band_op([this, i, so, r] {
-        const BandGeom& g = bplan.g;
         const UpL& u = ups[i];
-        const int rows = g.rows_short(so, r);
-        bool gp = false;
-        if (rows > 0)
-          gp = gemm("gemm_conv3", u.c2, btb, rows + 2, sw[so], u.cout, 1, 0, 1, rows, sw[so], bta, u.cout, nullptr, 0, nullptr, 0, 0, 0, 0, 0,
-                    false, true);
+        const int rows = bplan.g.rows_short(so, r);
+        const bool gp = band_conv3_rows(u.c2, btb, bta, rows, sw[so], u.cout, /*boundary=*/true);
         band_gn_local(bta, u.cout, (int64_t)rows * sw[so], gp);
       }, "gn", lv + ".1");
+      band_pre([this, i, so, r] { band_conv3_rows(ups[i].c2, btb, bta, bplan.g.rows_short(so, r), sw[so], ups[i].cout, /*boundary=*/false); });
       band_op([this, i, so, r] {
         const BandGeom& g = bplan.g;
         const UpL& u = ups[i];
@@ -2026,6 +2093,11 @@ class Engine : public EngineBase {
       ++b_pc;
       if (xid >= 0) {
         timed("band_pack", 0.0, (double)band_send_bytes(bplan.xs[xid], b_rank) * 2.0, [&] { band_pack(xid); });
+        if (b_async) {   // the transport (second stream) may start now ...
+          WX_HIP(hipEventRecord(b_ev_pack, cur_stream));
+          WX_HIP(hipStreamWaitEvent(b_cstream, b_ev_pack, 0));
+        }
+        if (b_pc < b_ops.size() && b_pre[b_pc]) b_pre[b_pc]();   // ... while the next op's interior rows are computed
         b_pending = xid;
         return xid;
       }
@@ -2064,6 +2136,7 @@ class Engine : public EngineBase {
     if (!b_recv && b_recv_need) b_recv = (char*)dalloc((size_t)b_recv_need);
     b_msgs.resize(bplan.xs.size());
     for (size_t x = 0; x < bplan.xs.size(); ++x) band_messages(bplan.xs[x], b_rank, &b_msgs[x].first, &b_msgs[x].second);
+    if (getenv("WX_BAND_OVERLAP") && getenv("WX_BAND_OVERLAP")[0] == '1') band_comm_stream(nullptr);
   }
   void band_step_rccl(const float* x_own, const float* frc_own, float* y, float* y_phys, float* x_next, hipStream_t s) override {
     if (!b_comm) throw StateError("wx_band_step_rccl: no communicator (wx_band_rccl_init)");
@@ -2073,8 +2146,9 @@ class Engine : public EngineBase {
       const auto& m = b_msgs[xid];
       if (!m.first.empty() || !m.second.empty()) {   // every pair at once: the grouped send/recv idiom (all-to-all safe)
         api.check(api.GroupStart(), "ncclGroupStart");
-        for (const BandMsg& q : m.first) api.check(api.Send(b_send + q.offset, (size_t)q.bytes, ncclInt8, q.peer, b_comm, cur_stream), "ncclSend");
-        for (const BandMsg& q : m.second) api.check(api.Recv(b_recv + q.offset, (size_t)q.bytes, ncclInt8, q.peer, b_comm, cur_stream), "ncclRecv");
+        hipStream_t ts = b_async ? b_cstream : cur_stream;   // second stream: the exchange overlaps the next op's interior rows
+        for (const BandMsg& q : m.first) api.check(api.Send(b_send + q.offset, (size_t)q.bytes, ncclInt8, q.peer, b_comm, ts), "ncclSend");
+        for (const BandMsg& q : m.second) api.check(api.Recv(b_recv + q.offset, (size_t)q.bytes, ncclInt8, q.peer, b_comm, ts), "ncclRecv");
         api.check(api.GroupEnd(), "ncclGroupEnd");
       }
       xid = band_resume();
@@ -2086,6 +2160,10 @@ class Engine : public EngineBase {
     WX_HIP(hipSetDevice(device));
     {
       const int xid = b_pending;
+      if (b_async) {   // everything the transport put on the second stream has to land before the unpack
+        WX_HIP(hipEventRecord(b_ev_done, b_cstream));
+        WX_HIP(hipStreamWaitEvent(cur_stream, b_ev_done, 0));
+      }
       timed("band_unpack", 0.0, (double)band_recv_bytes(bplan.xs[xid], b_rank) * 2.0, [&] { band_unpack(xid); });
     }
     return band_run();
@@ -2344,6 +2422,13 @@ int wx_band_resume(wx_handle h, int* next_xid) {
     WX_NEED(h);
     if (!next_xid) throw wx::ConfigError("wx_band_resume: null next_xid");
     *next_xid = h->impl->band_resume();
+  });
+}
+int wx_band_comm_stream(wx_handle h, void* adopt_stream, void** stream_out) {
+  return guarded([&] {
+    WX_NEED(h);
+    void* st = h->impl->band_comm_stream(adopt_stream);
+    if (stream_out) *stream_out = st;
   });
 }
 int wx_band_rccl_unique_id(uint8_t id[128]) {

@@ -115,6 +115,7 @@ _PROTOTYPES = {
     "wx_winattn_create": ([C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     "wx_winattn_apply": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "wx_winattn_destroy": ([C.c_void_p], C.c_int),
+    "wx_band_comm_stream": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)], C.c_int),
     "wx_swin_create": ([C.c_void_p, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     "wx_swin_load": ([C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_float), C.c_int64], C.c_int),
     "wx_swin_finalize": ([C.c_void_p], C.c_int),

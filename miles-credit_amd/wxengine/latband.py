@@ -107,6 +107,13 @@ class BandRank:
         _check(self.eng.lib.wx_band_resume(self.eng._h, C.byref(xid)))
         return xid.value
 
+    def use_comm_stream(self, stream=None):
+        """Move this rank's exchanges to a second stream (a torch.cuda.Stream, or None for one the engine creates): the engine then
+        overlaps each exchange with the interior rows of the op behind it (wx_band_comm_stream).  Returns the raw stream handle."""
+        out = C.c_void_p()
+        _check(self.eng.lib.wx_band_comm_stream(self.eng._h, C.c_void_p(stream.cuda_stream) if stream is not None else None, C.byref(out)))
+        return out.value
+
     def band_shape(self, channels: int) -> Tuple[int, int, int]:
         return (channels, self.rows, self.eng.cfg.image_width)
 
@@ -128,7 +135,7 @@ class VirtualBands:
     staging buffers.  Used by the parity tests (sharded == unsharded) and to exercise the sharded algorithm without a node."""
 
     def __init__(self, cfg: WXConfig, state_dict, nranks: int, precision: str = "bf16", device: int = 0, setup=None,
-                 post_factory=None):
+                 post_factory=None, async_copies: bool = False):
         """setup(engine): denorm / layout / tracer configuration of every rank's engine.
         post_factory(rank, row0, rows) -> WXPostBlock already restricted to those rows (WXPostBlock.set_band) and carrying
         the same fixers on every rank; it is attached before the engine is switched to band mode."""
@@ -146,15 +153,26 @@ class VirtualBands:
             self.ranks.append(BandRank(eng, r, nranks))
         self.starts = [b.row0 for b in self.ranks] + [self.ranks[-1].row0 + self.ranks[-1].rows]
         self.exchanged_bytes = 0
+        # async_copies: the exchanges' device copies go to ONE side stream shared by the virtual ranks (every engine adopts it), the
+        # one-GPU stand-in for an RCCL transport stream: copies then run beside the interior-row kernels the engines launch after a pack
+        self.side = None
+        if async_copies:
+            import torch
+            self.side = torch.cuda.Stream(device=device)
+            for b in self.ranks:
+                b.use_comm_stream(self.side)
 
     def _exchange(self, xid: int):
-        for src in self.ranks:
-            sends, _ = src.messages(xid)
-            for peer, off, nbytes in sends:
-                dst = self.ranks[peer]
-                roff = next(o for (q, o, b) in dst.messages(xid)[1] if q == src.rank and b == nbytes)
-                dst.recv[roff:roff + nbytes].copy_(src.send[off:off + nbytes])
-                self.exchanged_bytes += nbytes
+        import contextlib
+        import torch
+        with (torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext()):
+            for src in self.ranks:
+                sends, _ = src.messages(xid)
+                for peer, off, nbytes in sends:
+                    dst = self.ranks[peer]
+                    roff = next(o for (q, o, b) in dst.messages(xid)[1] if q == src.rank and b == nbytes)
+                    dst.recv[roff:roff + nbytes].copy_(src.send[off:off + nbytes], non_blocking=True)
+                    self.exchanged_bytes += nbytes
 
     def step(self, x, frc=None, want_phys: bool = False, want_next: bool = False):
         """x: [1, C_in, 1, H, W] or [C_in, H, W] (full grid).  Returns full-grid (y, y_phys, x_next) like WXEngine.step."""

@@ -90,6 +90,31 @@ def test_sharded_step_equals_unsharded(name, prec, n):
         assert vb.exchanged_bytes > 0
 
 
+@pytest.mark.parametrize("name,prec,n", [("T1", "fp32", 3), ("C1", "bf16", 4), ("C1W", "fp32", 4)])
+def test_overlapped_exchanges_are_bit_identical(name, prec, n, monkeypatch):
+    """Comm / compute overlap (wx_band_comm_stream): exchanges on a second stream between two events while the interior rows of the
+    3x3 convolution behind a halo exchange are computed.  (a) asynchronous device copies on a side stream give the SAME bits as
+    copies on the compute stream -- a missing event edge shows up here as a stale halo row; repeated to give a race a chance;
+    (b) the interior / boundary split changes only the partition of the GroupNorm tile partials: against the default (unsplit)
+    program the difference stays at summation noise."""
+    cfg = named_config(name)
+    sd = synth_state_dict(cfg)
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    monkeypatch.setenv("WX_BAND_SPLIT", "1")     # the split program, exchanges on the compute stream
+    sync = VirtualBands(cfg, sd, n, prec, setup=_setup(cfg))
+    monkeypatch.delenv("WX_BAND_SPLIT")
+    y_sync = sync.step(x)[0].clone()
+    asy = VirtualBands(cfg, sd, n, prec, setup=_setup(cfg), async_copies=True)   # wx_band_comm_stream switches the split on
+    for _ in range(4):
+        y_async = asy.step(x)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(y_async, y_sync)
+    whole = VirtualBands(cfg, sd, n, prec, setup=_setup(cfg))     # default: unsplit program
+    y_whole = whole.step(x)[0]
+    assert not torch.equal(y_whole, y_sync) or prec == "fp32", "the split should change the GroupNorm partial partition (is it taken?)"
+    _close(y_sync, y_whole, prec, l2_tol=8e-3)
+
+
 @pytest.mark.parametrize("key", ["w2", "w3", "w1", "w16", "w5p"])
 def test_odd_geometries_engine_vs_oracle_and_sharded(key):
     """Window / pad combinations outside the BASELINE family: the unsharded fp32 engine against the CPU oracle (1e-4 * max|y|),

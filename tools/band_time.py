@@ -61,7 +61,42 @@ for n in [int(a) for a in sys.argv[3:]]:
           f"(sum over ranks {sum(per_rank):.3f} ms = {sum(per_rank) / t_ref:.2f}x the unsharded work)")
     print(f"     {vb.ranks[0].num_exchanges} exchanges / step, {vb.exchanged_bytes / K / n / 1e6:.1f} MB sent per rank per step; "
           f"max|y - y_unsharded| / max|y| = {err:.2e}")
-    out["bands"].append({"n": n, "rows": vb.starts, "per_rank_ms": per_rank, "pack_unpack_ms": xch, "slowest_ms": slow,
+    # comm / compute overlap on ONE GPU: the same world with the exchanges' device copies on a side stream (what an RCCL transport
+    # stream does on a node); wall time of whole steps, profiling off, sync vs async copies
+    import time
+    walls = {}
+    for mode in ("sync", "split", "async"):
+        if mode == "split":
+            os.environ["WX_BAND_SPLIT"] = "1"
+        w = vb if mode == "sync" else VirtualBands(cfg, sd, n, prec, async_copies=(mode == "async"))
+        os.environ.pop("WX_BAND_SPLIT", None)
+        if mode == "split":   # what the split itself costs every rank in kernel time
+            for r in w.ranks:
+                r.eng.profile(1)
+            w.step(x)
+            for r in w.ranks:
+                r.eng.profile_reset()
+            for _ in range(K):
+                w.step(x)
+            torch.cuda.synchronize()
+            split_rank = [sum(k["ms"] for k in r.eng.profile_read()) / K for r in w.ranks]
+            print(f"     interior / boundary split of the six decoder convolutions: per-rank kernel ms {[round(t, 3) for t in split_rank]} "
+                  f"(slowest {max(split_rank):.3f} vs {slow:.3f} unsplit)")
+        for r in w.ranks:
+            r.eng.profile(0)
+        w.step(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            w.step(x)
+        torch.cuda.synchronize()
+        walls[mode] = (time.perf_counter() - t0) / K * 1e3
+        if mode != "sync":
+            del w
+    print(f"     whole-world wall per step (all {n} virtual ranks back to back on this GPU, profiling off): unsplit, copies on the compute "
+          f"stream {walls['sync']:.3f} ms | split, compute stream {walls['split']:.3f} ms | split, copies on a side stream between events "
+          f"{walls['async']:.3f} ms ({2 * n * vb.ranks[0].num_exchanges} cross-stream event edges per step)")
+    out["bands"].append({"n": n, "rows": vb.starts, "wall_sync_ms": walls["sync"], "wall_split_ms": walls["split"], "wall_async_ms": walls["async"], "per_rank_ms": per_rank, "pack_unpack_ms": xch, "slowest_ms": slow,
                          "exchanges_per_step": vb.ranks[0].num_exchanges, "sent_MB_per_rank": vb.exchanged_bytes / K / n / 1e6,
                          "rel_err_vs_unsharded": err})
     del vb
