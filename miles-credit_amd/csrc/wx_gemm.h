@@ -500,26 +500,61 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   // TAPIN (compile time: a run-time switch here cost 12 B of scratch inside the K loop and 30-80 % per launch)
   // measured: ConvT-k4 (8 chunks) 0.41 -> 0.31 ms with taps inner; CrossEmbed k=4 on 2 chunks 0.11 -> 0.15 ms, so narrow
   // inputs keep the chunk-inner order
-  auto issue = [&](unsigned stage_off, int ks) {
+  // k x k path: the source of a piece is  a_tap0[i] + tap_off  with a_tap0 the (possibly out-of-image) address of tap (0, 0), chunk 0
+  // of this lane's pixel and tap_off a SCALAR that walks (ky, kx, cc); whether the tap is inside the image is one bit test against
+  // two per-lane masks built once per tile (bit ky of a_ym: 0 <= iy0 + ky < in_h, bit kx of a_xm likewise; m >= M clears both).
+  // Round 3: the earlier form recomputed iy, ix, four compares and a 64-bit multiply-add per piece and step -- ~50 VALU instructions
+  // per 16 MFMAs, and every VALU instruction costs the SIMD a quarter of an MFMA's issue time (tools/mfma_probe).
+  const char* a_tap0[A_I];
+  unsigned a_ym[A_I], a_xm[A_I];
+  bool lane_in = true;   // every tap of every piece of this lane is inside the image
+  if constexpr (!ONE) {
 #pragma unroll
     for (int i = 0; i < A_I; ++i) {
-      const char* src;
-      if constexpr (ONE) {
-        src = a_src[i] + (int64_t)ks * a_step[i];
+      a_tap0[i] = in + (((int64_t)a_iy0[i] * p.in_w + a_ix0[i]) * p.in_ld) * (int64_t)sizeof(T) + a_piece[i];
+      // taps [lo, hi) are inside: lo = max(0, -i0), hi = min(k, extent - i0)
+      auto range_mask = [](int i0, int k, int extent) -> unsigned {
+        const int lo = i0 < 0 ? -i0 : 0, hi = (extent - i0) < k ? (extent - i0) : k;
+        if (hi <= lo) return 0u;
+        const unsigned up = hi >= 32 ? ~0u : (1u << hi) - 1u;
+        return up & ~((1u << lo) - 1u);   // lo < hi <= 32, so lo <= 31
+      };
+      const unsigned ym = a_ok[i] ? range_mask(a_iy0[i], p.kh, p.in_h) : 0u, xm = a_ok[i] ? range_mask(a_ix0[i], p.kw, p.in_w) : 0u;
+      a_ym[i] = ym; a_xm[i] = xm;
+      lane_in = lane_in && ym == ((p.kh >= 32) ? ~0u : (1u << p.kh) - 1u) && xm == ((p.kw >= 32) ? ~0u : (1u << p.kw) - 1u);
+    }
+  }
+  // wave-uniform: no lane of this wave ever leaves the image -> the steps skip the mask test (interior tiles of the large maps)
+  const bool wave_in = !ONE && __builtin_amdgcn_readfirstlane((int)(__ballot(lane_in) == ~0ull)) != 0;
+  const int64_t tap_x = (int64_t)p.in_ld * (int64_t)sizeof(T);           // one pixel to the right
+  const int64_t tap_y = (int64_t)p.in_w * p.in_ld * (int64_t)sizeof(T);  // one row down
+  unsigned b_mask[B_I];   // weights: all ones for a real row, 0 for a row of the zero page (its offset stays 0)
+#pragma unroll
+  for (int i = 0; i < B_I; ++i) b_mask[i] = b_step[i] ? ~0u : 0u;
+  auto issue = [&](unsigned stage_off, int ks) {
+    if constexpr (ONE) {
+#pragma unroll
+      for (int i = 0; i < A_I; ++i) lds_dma16_s(a_src[i] + (int64_t)ks * a_step[i], a_dst[i] + stage_off);
+    } else {
+      const int64_t tap_off = ky * tap_y + kx * tap_x + (int64_t)cc * KB;   // scalar
+      if (wave_in) {
+#pragma unroll
+        for (int i = 0; i < A_I; ++i) lds_dma16_s(a_tap0[i] + tap_off, a_dst[i] + stage_off);
       } else {
-        const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-        const bool ok = a_ok[i] && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-        src = ok ? in + (((int64_t)iy * p.in_w + ix) * p.in_ld + cc * BKE) * (int64_t)sizeof(T) + a_piece[i] : zsrc;
+#pragma unroll
+        for (int i = 0; i < A_I; ++i) {
+          const bool ok = ((a_ym[i] >> ky) & (a_xm[i] >> kx) & 1u) != 0;
+          lds_dma16_s(ok ? a_tap0[i] + tap_off : zsrc, a_dst[i] + stage_off);
+        }
       }
-      lds_dma16_s(src, a_dst[i] + stage_off);
     }
     // K order for k x k convolutions: channel chunk OUTER, taps INNER.  Consecutive steps then re-read the same 64-byte
     // channel slice at shifted pixels (L1/L2 hits); with taps outer a tap's re-use came cchunks steps later, after
     // the CU's four workgroups had streamed 8 MB through a 4 MB L2 -- PMC: 605 MB FETCH_SIZE per ConvT-k4 parity
     // launch for a 164 MB input, i.e. every tap fetched from the fabric.  The weight row stays [ky][kx][c].
-    const int64_t wstep = ONE ? (int64_t)ks : (int64_t)(ky * p.kw + kx) * cchunks + cc;
+    const unsigned woff = (unsigned)((ONE ? ks : (ky * p.kw + kx) * cchunks + cc) * KB);   // scalar, < 2^31 (K bytes of one weight row)
 #pragma unroll
-    for (int i = 0; i < B_I; ++i) lds_dma16_s(b_src[i] + wstep * b_step[i], b_dst[i] + stage_off);
+    for (int i = 0; i < B_I; ++i) lds_dma16_s(b_src[i] + (woff & b_mask[i]), b_dst[i] + stage_off);
     if constexpr (!ONE) {
       if constexpr (TAPIN) {
         if (++kx == p.kw) {
