@@ -46,6 +46,29 @@ __host__ __device__ inline float bf2f(bf16_t h) {
   return __builtin_bit_cast(float, u);
 }
 
+// float -> IEEE half bits, round-to-nearest-even (host side: the f16 image of the feed-forward layer-2 weights)
+inline uint16_t f2h_bits(float f) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const int32_t e = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+  uint32_t m = u & 0x7fffffu;
+  if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0u));
+  if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (e <= 0) {
+    if (e < -10) return (uint16_t)sign;
+    m |= 0x800000u;
+    const int sh = 14 - e;
+    uint32_t h = m >> sh;
+    const uint32_t rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    if (rem > half || (rem == half && (h & 1u))) ++h;
+    return (uint16_t)(sign | h);
+  }
+  uint32_t h = ((uint32_t)e << 10) | (m >> 13);
+  const uint32_t rem = m & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+  return (uint16_t)(sign | h);
+}
+
 template <typename T>
 struct Elem;
 template <>
@@ -134,6 +157,38 @@ __device__ inline void gelu_fast_pairs(f32x2_t* v) {
   for (int i = 0; i < NP; ++i) q[i] = f32x2_t{__builtin_amdgcn_rcpf(q[i].x), __builtin_amdgcn_rcpf(q[i].y)};
 #pragma unroll
   for (int i = 0; i < NP; ++i) v[i] = v[i] * q[i];
+}
+// The same GELU on packed halves (v_pk_mul_f16 / v_pk_fma_f16: two elements per VALU instruction; v_exp_f16 / v_rcp_f16 per element) for
+// consumers that take the result as an f16 MFMA operand: 4.5 VALU + 2 transcendental per element instead of 7 + 2, and no f32 -> bf16
+// pack behind it.  f16 carries 11 significand bits against bf16's 8, so the hidden activations lose LESS than in the bf16 form; the
+// sigmoid saturates cleanly (exp2 overflows to inf -> rcp 0; underflows to 0 -> 1).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <int NP>
+__device__ inline void gelu_fast_pairs_f16(const f32x2_t* v, uint32_t* out) {
+  f16x2_t x[NP], xc[NP], t[NP], q[NP];
+  const f16x2_t lo = {(_Float16)-8.0f, (_Float16)-8.0f}, hi = {(_Float16)8.0f, (_Float16)8.0f};
+  const f16x2_t c2 = {(_Float16)1.014263058e-03f, (_Float16)1.014263058e-03f}, c1 = {(_Float16)-1.067757239e-01f, (_Float16)-1.067757239e-01f},
+                c0 = {(_Float16)-2.301121342e+00f, (_Float16)-2.301121342e+00f}, one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) x[i] = __builtin_convertvector(v[i], f16x2_t);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) xc[i] = __builtin_elementwise_min(__builtin_elementwise_max(x[i], lo), hi);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) t[i] = xc[i] * xc[i];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) q[i] = t[i] * c2 + c1;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) q[i] = q[i] * t[i] + c0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) q[i] = xc[i] * q[i];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) q[i] = f16x2_t{(_Float16)__builtin_exp2f16(q[i].x), (_Float16)__builtin_exp2f16(q[i].y)};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) q[i] = q[i] + one;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) q[i] = f16x2_t{(_Float16)__builtin_amdgcn_rcph(q[i].x), (_Float16)__builtin_amdgcn_rcph(q[i].y)};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) out[i] = __builtin_bit_cast(uint32_t, x[i] * q[i]);
 }
 __device__ inline void gelu_fast4(f32x2_t& a, f32x2_t& b) {
   f32x2_t v[2] = {a, b};

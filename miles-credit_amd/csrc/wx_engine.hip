@@ -661,7 +661,14 @@ class Engine : public EngineBase {
       for (int o = 0; o < c; ++o)
         for (int g = 0; g < 4; ++g)
           for (int j = 0; j < 8; ++j)
-            wt_host[base + 32 * (int64_t)c + (int64_t)o * 32 + ff_w2_slot(o, g) * 8 + j] = wt_host[f.w2.wt + (int64_t)o * hidden + ch * 32 + ff_perm(g, j)];
+          {
+            const T wv = wt_host[f.w2.wt + (int64_t)o * hidden + ch * 32 + ff_perm(g, j)];
+            // WX_FF_F16: the kernel's GEMM2 runs on f16 operands (hidden activations in f16): the SAME rounded bf16 weight, re-encoded
+            // (exact: 8 significand bits into 11; only magnitudes below 6e-8 are lost)
+            T enc = wv;
+            if constexpr (sizeof(T) == 2) { if (WX_FF_F16) enc = (T)f2h_bits(Elem<T>::to_f(wv)); }
+            wt_host[base + 32 * (int64_t)c + (int64_t)o * 32 + ff_w2_slot(o, g) * 8 + j] = enc;
+          }
     }
     return off;
   }

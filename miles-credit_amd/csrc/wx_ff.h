@@ -59,6 +59,13 @@ inline int ff_perm(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 
 // physical 16-byte slot of logical slot g in row o of a W2 chunk (64-byte rows)
 inline int ff_w2_slot(int o, int g) { return (g + 2 * ((o & 15) >> 2)) & 3; }
 
+#ifndef WX_FF_F16
+#define WX_FF_F16 1   // hidden activations and the layer-2 weights of the chunk blocks as f16 (0: bf16, rounds 1-2)
+#endif
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ inline f32x4_t mma_f16(const uint4& a, const uint4& b, f32x4_t acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
 #ifndef WX_FF_TAIL_PIPE
 #define WX_FF_TAIL_PIPE 1   // software-pipelined to_qkv tail (0: the plain read -> multiply -> epilogue -> barrier order)
 #endif
@@ -283,6 +290,14 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
         v[f * 4 + 2] = f32x2_t{rs * (h[1][f][0] - mu * c1.x) + d1.x, rs * (h[1][f][1] - mu * c1.y) + d1.y};
         v[f * 4 + 3] = f32x2_t{rs * (h[1][f][2] - mu * c1.z) + d1.z, rs * (h[1][f][3] - mu * c1.w) + d1.w};
       }
+#if WX_FF_F16
+      // GELU on packed halves, result = the f16 B operand of GEMM2 (W2's chunk is stored as f16 by pack_ff)
+      uint32_t hw[PXF * 4];
+#pragma unroll
+      for (int i = 0; i < PXF * 4; i += GP) gelu_fast_pairs_f16<GP>(v + i, hw + i);
+#pragma unroll
+      for (int f = 0; f < PXF; ++f) hb[f] = make_uint4(hw[f * 4], hw[f * 4 + 1], hw[f * 4 + 2], hw[f * 4 + 3]);
+#else
 #ifndef WX_FF_NOGELU   // tools/ff_probe ablation: without the activation the C = 128 block runs 13 % faster, the C = 256 block 11 %
 #pragma unroll
       for (int i = 0; i < PXF * 4; i += GP) gelu_fast_pairs<GP>(v + i);  // GP pairs in lock-step (ILP vs registers)
@@ -291,6 +306,7 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
       for (int f = 0; f < PXF; ++f)
         hb[f] = make_uint4(pack_bf16x2(v[f * 4].x, v[f * 4].y), pack_bf16x2(v[f * 4 + 1].x, v[f * 4 + 1].y),
                            pack_bf16x2(v[f * 4 + 2].x, v[f * 4 + 2].y), pack_bf16x2(v[f * 4 + 3].x, v[f * 4 + 3].y));
+#endif
     }
     FF_TICK(tc2);
     // GEMM2, output fragments in batches of 4; the next batch is read while the current one multiplies
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int f = 0; f < PXF; ++f) y[m0 + m][f] = mma_sub<bf16_t>(a2[m], hb[f], y[m0 + m][f]);
+        for (int f = 0; f < PXF; ++f) y[m0 + m][f] = WX_FF_F16 ? mma_f16(a2[m], hb[f], y[m0 + m][f]) : mma_sub<bf16_t>(a2[m], hb[f], y[m0 + m][f]);
       if (m0 + 4 < MF) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) a2[m] = an[m];
