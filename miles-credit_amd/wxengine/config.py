@@ -308,6 +308,10 @@ def named_config(name: str) -> WXConfig:
         mc = dict(base, image_height=61, image_width=120, levels=5, output_only_channels=2,
                   dim=[32, 64, 128, 256], depth=[2, 1, 2, 1], global_window_size=[5, 5, 2, 1], local_window_size=5,
                   padding_conf=dict(activate=True, mode="earth", pad_lat=[11, 9], pad_lon=[24, 16]))
+    elif name == "T0F":  # T0 with two input frames (crossformer.py:604-609: x.reshape(b, c * t, h, w), channel-major then time)
+        mc = dict(base, frames=2, output_frames=1, image_height=37, image_width=72, levels=3, output_only_channels=3,
+                  dim=[32, 64, 128, 256], depth=[1, 1, 2, 1], global_window_size=[4, 2, 2, 1], local_window_size=3,
+                  padding_conf=dict(activate=True, mode="earth", pad_lat=[6, 6], pad_lon=[12, 12]))
     elif name == "T5":  # T1 geometry with the WIDTHS of the 0.25-degree model (C = 128 / 256 / 512 / 1024): every launch shape of
         # C3's stages 2-3 (persistent GEMM, k-blocked hidden, 4-token packed windows, v-only long attention) on 200 / 50 rows
         mc = dict(base, image_height=61, image_width=120, levels=5, output_only_channels=2,

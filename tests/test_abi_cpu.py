@@ -139,7 +139,7 @@ def test_synthetic_weights_are_deterministic_and_warm():
 @pytest.mark.reference
 def test_state_spec_equals_reference_state_dict():
     import make_goldens
-    for name in ("T0", "T1", "T0W", "T0U", "T0M"):
+    for name in ("T0", "T1", "T0W", "T0U", "T0M", "T0F"):
         cfg = named_config(name)
         m = make_goldens.reference_model(cfg)
         ref = {k: tuple(v.shape) for k, v in m.state_dict().items()}

@@ -47,7 +47,7 @@ def check(y, ref, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", ["T0", "T1", "T0W", "T0U", "T0M"])
+@pytest.mark.parametrize("name", ["T0", "T1", "T0W", "T0U", "T0M", "T0F"])
 def test_forward_and_every_block_vs_oracle(name, prec):
     cfg = named_config(name)
     sd = synth_state_dict(cfg)

@@ -59,7 +59,7 @@ def test_mirror_pad_matches_reference():
 _SLOW = os.environ.get("WX_SLOW", "0") == "1"
 
 
-@pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W", "T0U", "T0M", "RT",
+@pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W", "T0U", "T0M", "T0F", "RT",
                                   pytest.param("C3", marks=pytest.mark.skipif(
                                       not _SLOW, reason="~1.5 min of CPU; set WX_SLOW=1"))])
 def test_forward_matches_reference_golden(name):

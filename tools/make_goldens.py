@@ -630,7 +630,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,RT")
+    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,T0F,RT")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -665,7 +665,7 @@ def main():
             reconstruct_golden()
         elif item == "asm":
             assemble_golden()
-        elif item in ("T0", "T1", "T0W", "T0U", "T0M"):
+        elif item in ("T0", "T1", "T0W", "T0U", "T0M", "T0F"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "RT":   # the model of the reference's own tests/test_crossformer.py
             model_golden(item, 2, False)
