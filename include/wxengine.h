@@ -194,6 +194,39 @@ int wx_swin_apply(wx_swin_handle s, const void* x_in_dev, void* x_out_dev, void*
 int wx_swin_flops(wx_swin_handle s, double* flops);   /* algorithmic FLOPs of one wx_swin_apply (2*MAC of the Linear layers + attention) */
 int wx_swin_destroy(wx_swin_handle s);
 
+/* ---- the FuXi forward (BASELINE config 5) --------------------------------------------------------------------------
+ * credit/models/fuxi.py:454-500 (Fuxi.forward) for one sample, padding_conf / post_conf off, image a multiple of the patch
+ * (then the trailing F.interpolate(size = image) is the identity), frame_patch_size == frames (the time axis collapses, :470):
+ *   x [C_in][frames][H][W] float32 -> CubeEmbedding (:82-143) -> UTransformer (:204-310: DownBlock, zero-pad to the window,
+ *   Swin stage, crop, concat, UpBlock) -> fc + patch reshape (:484-488) -> y [C_out][H][W] float32.
+ * The stage in the middle is the engine's V2-Cr stage (wx_swin above; the reference instantiates timm's class, not vendored:
+ * parity of the stage is pinned to credit/models/swin.py instead), everything around it follows the reference's own modules.
+ *   wx_fuxi_load(name, ...): name = the reference's state-dict key with EFFECTIVE weights (eval-mode spectral norm folded by the
+ *     caller, fuxi.py:16-22): "cube_embedding.proj.weight" [dim][C_in][frames][ph][pw], "cube_embedding.proj.bias",
+ *     "cube_embedding.norm.{weight,bias}", "u_transformer.down.conv.{weight [dim][dim][3][3],bias}",
+ *     "u_transformer.down.b.{0,3}.{weight,bias}" (Conv2d), "u_transformer.down.b.{1,4}.{weight,bias}" (GroupNorm), the same under
+ *     "u_transformer.up." with "u_transformer.up.conv.weight" [2 dim][dim][2][2] (ConvTranspose2d), "fc.weight" [C_out ph pw][dim],
+ *     "fc.bias", and "u_transformer.layer.blocks.<i>.<wx_swin_load name>" for the stage.
+ *   wx_fuxi_debug_map(name in {"embed", "down", "stage", "up"}): an intermediate token map [rows][cols][dim] of the LAST forward,
+ *     converted to float32 (tests); host == NULL only reports the shape. */
+typedef struct wx_fuxi_desc {
+  int32_t precision;            /* WX_PREC_FP32 / WX_PREC_BF16 */
+  int32_t H, W;                 /* image_height, image_width */
+  int32_t C_in, C_out;          /* channels*levels + surface (+ input-only | + output-only) */
+  int32_t frames;               /* = frame_patch_size */
+  int32_t patch_h, patch_w;
+  int32_t dim, heads, window, depth;
+  int32_t groups_down, groups_up;   /* to_2tuple(num_groups) */
+} wx_fuxi_desc;
+typedef struct wx_fuxi* wx_fuxi_handle;
+int wx_fuxi_create(const wx_fuxi_desc* desc, int device, wx_fuxi_handle* out);
+int wx_fuxi_load(wx_fuxi_handle f, const char* name, const float* host_data, int64_t count);
+int wx_fuxi_finalize(wx_fuxi_handle f);
+int wx_fuxi_forward(wx_fuxi_handle f, const float* x_dev, float* y_dev, void* stream);
+int wx_fuxi_debug_map(wx_fuxi_handle f, const char* name, float* host, int64_t capacity, int64_t shape[3]);
+int wx_fuxi_flops(wx_fuxi_handle f, double* flops);
+int wx_fuxi_destroy(wx_fuxi_handle f);
+
 /* ---- conservation fixers (PostBlock) -------------------------------------------
  * A wx_post is the device-side counterpart of credit/postblock/gen1.py::PostBlock for pressure-level grids: an ordered
  * list of TracerFixer (:111-167), GlobalMassFixer (:170-391), GlobalWaterFixer (:394-569) and GlobalEnergyFixer

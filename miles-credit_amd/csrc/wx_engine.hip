@@ -27,6 +27,7 @@
 #include "wx_gemm.h"
 #include "wx_gemm_stream.h"
 #include "wx_swin.h"
+#include "wx_fuxi.h"
 #include "wx_post.h"
 #include "wx_pre.h"
 
@@ -2740,6 +2741,60 @@ int wx_swin_flops(wx_swin_handle w, double* flops) {
   return guarded([&] { if (!w || !flops) throw wx::ConfigError("swin: null argument"); *flops = w->impl->flops(); });
 }
 int wx_swin_destroy(wx_swin_handle w) { return guarded([&] { delete w; }); }
+
+// ---- the FuXi forward (BASELINE config 5; credit/models/fuxi.py:454-500) -----------------------------------------------------------
+struct wx_fuxi {
+  std::unique_ptr<wx::FuxiBase> impl;
+};
+int wx_fuxi_create(const wx_fuxi_desc* d, int device, wx_fuxi_handle* out) {
+  return guarded([&] {
+    if (!d || !out) throw wx::ConfigError("null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw wx::HipError("no HIP device visible: wxengine has no CPU fallback");
+    if (d->precision != WX_PREC_FP32 && d->precision != WX_PREC_BF16) throw wx::ConfigError("fuxi: unknown precision");
+    if (d->H < 1 || d->W < 1 || d->C_in < 1 || d->C_out < 1 || d->frames < 1 || d->patch_h < 1 || d->patch_w < 1 || d->dim < 1 || d->heads < 1 ||
+        d->window < 1 || d->depth < 1 || d->groups_down < 1 || d->groups_up < 1)
+      throw wx::ConfigError("fuxi: bad geometry");
+    wx::FuxiDesc fd{d->H, d->W, d->C_in, d->C_out, d->frames, d->patch_h, d->patch_w, d->dim, d->heads, d->window, d->depth, d->groups_down, d->groups_up};
+    auto w = std::make_unique<wx_fuxi>();
+    try {
+      if (d->precision == WX_PREC_BF16) w->impl = std::make_unique<wx::FuxiModel<wx::bf16_t>>(fd, device);
+      else w->impl = std::make_unique<wx::FuxiModel<float>>(fd, device);
+    } catch (const wx::HipError&) { throw; } catch (const std::runtime_error& e) {
+      throw wx::ConfigError(e.what());
+    }
+    *out = w.release();
+  });
+}
+int wx_fuxi_load(wx_fuxi_handle w, const char* name, const float* host, int64_t count) {
+  return guarded([&] {
+    if (!w || !name || !host) throw wx::ConfigError("fuxi: null argument");
+    try { w->impl->load(name, host, count); } catch (const wx::HipError&) { throw; } catch (const std::runtime_error& e) { throw wx::ShapeError(e.what()); }
+  });
+}
+int wx_fuxi_finalize(wx_fuxi_handle w) {
+  return guarded([&] {
+    if (!w) throw wx::StateError("null fuxi handle");
+    try { w->impl->finalize(); } catch (const wx::HipError&) { throw; } catch (const std::runtime_error& e) { throw wx::StateError(e.what()); }
+  });
+}
+int wx_fuxi_forward(wx_fuxi_handle w, const float* x_dev, float* y_dev, void* stream) {
+  return guarded([&] {
+    if (!w) throw wx::StateError("null fuxi handle");
+    if (!x_dev || !y_dev) throw wx::ConfigError("fuxi: null tensor pointer");
+    try { w->impl->forward(x_dev, y_dev, (hipStream_t)stream); } catch (const wx::HipError&) { throw; } catch (const std::runtime_error& e) { throw wx::StateError(e.what()); }
+  });
+}
+int wx_fuxi_debug_map(wx_fuxi_handle w, const char* name, float* host, int64_t capacity, int64_t shape[3]) {
+  return guarded([&] {
+    if (!w || !name || !shape) throw wx::ConfigError("fuxi: null argument");
+    try { w->impl->debug_copy(name, host, capacity, shape); } catch (const wx::HipError&) { throw; } catch (const std::runtime_error& e) { throw wx::ShapeError(e.what()); }
+  });
+}
+int wx_fuxi_flops(wx_fuxi_handle w, double* flops) {
+  return guarded([&] { if (!w || !flops) throw wx::ConfigError("fuxi: null argument"); *flops = w->impl->flops(); });
+}
+int wx_fuxi_destroy(wx_fuxi_handle w) { return guarded([&] { delete w; }); }
 
 const char* wx_last_error(void) { return wx::g_last_error.c_str(); }
 #ifndef WX_SOURCE_HASH

@@ -20,8 +20,8 @@
 
 namespace wx {
 
-// x[row] += LayerNorm(t[row]) * g + b   (eps inside the square root, biased variance: torch.nn.LayerNorm)
-template <typename T>
+// x[row] += LayerNorm(t[row]) * g + b   (eps inside the square root, biased variance: torch.nn.LayerNorm);  RES = false: x[row] = ...
+template <typename T, bool RES = true>
 __global__ __launch_bounds__(256) void ln_residual_kernel(const T* __restrict__ t, T* __restrict__ x, const float* __restrict__ g,
                                                            const float* __restrict__ b, int rows, int C, float eps) {
   constexpr int VEC = 16 / (int)sizeof(T), MAXP = 4;
@@ -62,7 +62,11 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const T* __restrict__ 
     const int pc = lane + 64 * j;
     if (pc < pieces) {
       float xv[VEC], gv[VEC], bv[VEC];
-      unpack16<T>(*reinterpret_cast<const uint4*>(xr + pc * VEC), xv);
+      if constexpr (RES) unpack16<T>(*reinterpret_cast<const uint4*>(xr + pc * VEC), xv);
+      else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) xv[e] = 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < VEC; e += 4) {
         const float4 g4 = *reinterpret_cast<const float4*>(g + pc * VEC + e), b4 = *reinterpret_cast<const float4*>(b + pc * VEC + e);

@@ -1,0 +1,192 @@
+"""BASELINE config 5 -- the FuXi forward (credit/models/fuxi.py:454-500) around a Swin V2 (Cr) stage.
+
+Golden: tests/golden/fuxi_{FT0,FT1,FT2}.npz = the output and four intermediate maps of the reference's own `Fuxi.forward`,
+`UTransformer.forward`, `CubeEmbedding`, `DownBlock`, `UpBlock`, `apply_spectral_norm` run in the dev container with the reference's
+V2-Cr blocks as the stage (tools/make_goldens.py::fuxi_golden; timm's stage class is not vendored), on the keyed
+synthetic weights of wxengine.fuxi.synth_fuxi_state_dict (loaded there strict=True: the key names are pinned too).
+CPU: oracle/fuxi_oracle.py against the goldens (fp32: 2e-5 of max|.|; fp64 evaluation = the fixture's noise floor), the host's
+spectral-norm fold against the oracle's, config / state-spec logic.
+GPU: the HIP model (`wx_fuxi_*`) against the goldens and the oracle:
+    fp32 (exact-f32 MFMA)  max|y - ref| <= 2e-4 * max|ref| on y and every intermediate map
+    bf16                   rel-L2 <= 2e-2 and max err <= 6e-2 * max|ref| on y; rel-L2 <= 2e-2 on the maps
+and, at BASELINE config 5's own size (F6H: 640 x 1280, patch 4, dim 1024, 16 blocks), size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fuxi_oracle as FO
+from wxengine.fuxi import FuxiConfig, fold_spectral_norm, named_fuxi_config, synth_fuxi_state_dict, window_padding
+from wxengine.synth import keyed_normal
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = ["FT0", "FT1", "FT2"]
+MAPS = ["embed", "down", "stage", "up"]
+
+
+def case(name):
+    cfg = named_fuxi_config(name)
+    sd = synth_fuxi_state_dict(cfg)
+    x = keyed_normal("fuxi/x0", (1, cfg.in_chans, cfg.frames, cfg.image_height, cfg.image_width), 1000)
+    return cfg, sd, x, np.load(os.path.join(GOLD, f"fuxi_{name}.npz"))
+
+
+def run_oracle(cfg, sd, x, dtype=torch.float32):
+    taps = {}
+    y = FO.forward(torch.from_numpy(x[0]).to(dtype), {k: torch.from_numpy(v) for k, v in sd.items()}, cfg.num_heads, cfg.window_size, cfg.depth,
+                   cfg.groups, cfg.out_chans, taps)
+    return y, taps
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_the_reference_forward(name):
+    cfg, sd, x, g = case(name)
+    y, taps = run_oracle(cfg, sd, x)
+    for k in MAPS:
+        ref = torch.from_numpy(g[k])
+        assert taps[k].shape == ref.shape, k
+        assert (taps[k] - ref).abs().max() <= 2e-5 * ref.abs().max(), f"{k}: {(taps[k] - ref).abs().max():.3e}"
+    ref = torch.from_numpy(g["y"])
+    assert y.shape == ref.shape == (cfg.out_chans, cfg.image_height, cfg.image_width)
+    assert (y - ref).abs().max() <= 2e-5 * ref.abs().max()
+    y64, _ = run_oracle(cfg, sd, x, torch.float64)
+    assert (y64 - ref.double()).abs().max() <= 2e-5 * ref.abs().max()
+    pl, pr, pt, pb = (int(v) for v in g["padding"])            # fuxi.py get_pad2d: (left, right, top, bottom)
+    hd, wd = cfg.patches[0] // 2, cfg.patches[1] // 2
+    assert window_padding(hd, cfg.window_size) == (pt, pb) and window_padding(wd, cfg.window_size) == (pl, pr)
+    assert cfg.stage_feat == (hd + pt + pb, wd + pl + pr)
+
+
+def test_host_spectral_norm_fold_matches_the_oracle():
+    cfg = named_fuxi_config("FT0")
+    sd = synth_fuxi_state_dict(cfg)
+    host = fold_spectral_norm(sd)
+    orc = FO.effective_weights({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert set(host) == set(orc)
+    for k in host:
+        np.testing.assert_allclose(host[k], orc[k].numpy(), rtol=2e-6, atol=1e-7, err_msg=k)
+    assert not any(k.endswith(("_orig", "_u", "_v")) for k in host)
+    # ConvTranspose2d: sigma over dim 1 (torch.nn.utils.spectral_norm's default for transposed convolutions)
+    w = sd["u_transformer.up.conv.weight_orig"]
+    mat = np.moveaxis(w, 1, 0).reshape(w.shape[1], -1)
+    sigma = sd["u_transformer.up.conv.weight_u"] @ (mat @ sd["u_transformer.up.conv.weight_v"])
+    np.testing.assert_allclose(host["u_transformer.up.conv.weight"], w / sigma, rtol=1e-6)
+    assert 0.5 < sigma < 1.5 * np.linalg.svd(mat, compute_uv=False)[0]
+
+
+def test_config_mirrors_the_reference_constructor():
+    cfg = FuxiConfig.from_model_conf(dict(image_height=640, patch_height=4, image_width=1280, patch_width=4, levels=15, frames=2, frame_patch_size=2,
+                                          dim=1024, num_groups=32, channels=4, surface_channels=7, num_heads=8, depth=16, window_size=7,
+                                          use_spectral_norm=True, interp=True, padding_conf={"activate": False}, post_conf={"activate": False},
+                                          proj_drop=0, attn_drop=0, drop_path=0, type="fuxi"))
+    assert (cfg.in_chans, cfg.out_chans) == (67, 67) and cfg.patches == (160, 320) and cfg.stage_feat == (84, 161)
+    assert cfg == named_fuxi_config("F6H")
+    spec = cfg.state_spec()
+    assert spec["cube_embedding.proj.weight"] == (1024, 67, 2, 4, 4) and "cube_embedding.proj.weight_orig" not in spec   # Conv3d is not wrapped
+    assert spec["u_transformer.up.conv.weight_orig"] == (2048, 1024, 2, 2) and spec["u_transformer.up.conv.weight_u"] == (1024,)
+    assert spec["fc.weight_orig"] == (67 * 16, 1024)
+    for bad in (dict(padding_conf={"activate": True}), dict(post_conf={"activate": True}), dict(use_noise=True), dict(drop_path=0.1),
+                dict(frame_patch_size=1), dict(image_height=642), dict(patch_height=5), dict(not_a_key=1)):
+        with pytest.raises(ValueError):
+            FuxiConfig.from_model_conf({**dict(image_height=64, patch_height=4, image_width=64, patch_width=4, frames=2, frame_patch_size=2), **bad})
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------------------------
+def build(cfg, sd, prec):
+    from wxengine.fuxi import FuxiHIP
+    m = FuxiHIP(precision=prec, cfg=cfg)
+    m.load_state_dict(sd)
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", CASES)
+def test_hip_fuxi_vs_reference_golden(name, prec):
+    cfg, sd, x, g = case(name)
+    m = build(cfg, sd, prec)
+    xd = torch.from_numpy(x).cuda()
+    y = m(xd)
+    assert y.shape == (1, cfg.out_chans, 1, cfg.image_height, cfg.image_width) and y.dtype == torch.float32
+    y = y[0, :, 0].cpu()
+    ref = torch.from_numpy(g["y"])
+    yo, _ = run_oracle(cfg, sd, x)
+    for k in MAPS:
+        got, want = torch.from_numpy(m.debug_map(k)), torch.from_numpy(g[k])
+        assert got.shape == want.shape, k
+        if prec == "fp32":
+            assert (got - want).abs().max() <= 2e-4 * want.abs().max(), f"{k}: {(got - want).abs().max():.3e} of {want.abs().max():.3e}"
+        else:
+            l2 = ((got - want).norm() / want.norm()).item()
+            assert l2 <= 2e-2, f"{k}: bf16 rel-L2 {l2:.3e}"
+    if prec == "fp32":
+        assert (y - ref).abs().max() <= 2e-4 * ref.abs().max(), f"y: {(y - ref).abs().max():.3e}"
+        assert (y - yo).abs().max() <= 2e-4 * ref.abs().max()
+    else:
+        l2 = ((y - ref).norm() / ref.norm()).item()
+        assert l2 <= 2e-2 and (y - ref).abs().max() <= 6e-2 * ref.abs().max(), f"bf16 rel-L2 {l2:.3e} max {(y - ref).abs().max():.3e}"
+    # the forward is a pure function of x: bit-identical when repeated, and per batch item
+    y2 = m(torch.cat([xd, 2 * xd]))
+    assert torch.equal(y2[0, :, 0].cpu(), y)
+    assert not torch.equal(y2[1], y2[0])
+
+
+@pytest.mark.gpu
+def test_hip_fuxi_rejects_what_it_does_not_implement():
+    from wxengine.engine import WXEngineError
+    from wxengine.fuxi import FuxiHIP
+    cfg, sd, x, _ = case("FT0")
+    m = FuxiHIP(precision="bf16", cfg=cfg)
+    with pytest.raises(WXEngineError):
+        m(torch.from_numpy(x).cuda())                                   # nothing loaded
+    with pytest.raises(KeyError):
+        m.load_state_dict({k: v for k, v in sd.items() if k != "fc.bias"})
+    with pytest.raises(KeyError):
+        m.load_state_dict({**sd, "u_transformer.noise_inject.weight": np.zeros(3, np.float32)})
+    with pytest.raises(ValueError):
+        m.load_state_dict({**sd, "fc.bias": np.zeros(3, np.float32)})
+    m.load_state_dict(sd)
+    with pytest.raises(WXEngineError):
+        m(torch.from_numpy(x))                                          # host tensor
+    with pytest.raises(WXEngineError):
+        m(torch.from_numpy(x).cuda()[:, :, :1])                         # one frame of two
+    with pytest.raises(WXEngineError):
+        m(torch.from_numpy(x).cuda().double())
+    with pytest.raises(WXEngineError):                                  # head_dim 16 has no attention kernel
+        FuxiHIP(precision="bf16", cfg=FuxiConfig(image_height=16, patch_height=2, image_width=48, patch_width=4, levels=2, frames=2, frame_patch_size=2,
+                                                  dim=64, num_groups=8, channels=3, surface_channels=1, num_heads=4, depth=2, window_size=4))
+
+
+@pytest.mark.gpu
+def test_fuxi_6h_full_size_properties_and_throughput():
+    """BASELINE config 5's model (260 M parameters, 67 x 2 x 640 x 1280 in, 51,200 patch tokens, 13,524 stage tokens): finite output of
+    the right size, bit-identical repeats, the stage's zero padding really is invisible to the valid region's statistics, bf16 close
+    to fp32-free invariants -- plus the timing line DESIGN.md quotes.  (No full-size golden: the oracle needs minutes and ~10 GB.)"""
+    from wxengine.fuxi import FuxiHIP
+    cfg = named_fuxi_config("F6H")
+    sd = synth_fuxi_state_dict(cfg)
+    m = FuxiHIP(precision="bf16", cfg=cfg)
+    m.load_state_dict(sd)
+    x = torch.randn(1, cfg.in_chans, cfg.frames, cfg.image_height, cfg.image_width, generator=torch.Generator().manual_seed(4)).cuda()
+    y = m(x)
+    torch.cuda.synchronize()
+    assert y.shape == (1, 67, 1, 640, 1280) and torch.isfinite(y).all()
+    assert 0.05 < y.abs().mean().item() < 50.0
+    y2 = m(x)
+    assert torch.equal(y, y2)
+    # linearity of the last layer only: the output is NOT linear in x, a different input must give a different field everywhere
+    y3 = m(x.flip(-1))
+    assert (y3 - y).abs().mean().item() > 1e-3
+    # embed map statistics: LayerNorm output has per-token mean beta-ish and unit-ish variance (gamma ~ 1 +- 0.1, beta ~ 0.1 z)
+    e = torch.from_numpy(m.debug_map("embed"))
+    assert e.shape == (160, 320, 1024)
+    assert abs(e.mean().item()) < 0.05 and 0.8 < e.std().item() < 1.2
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        m(x, y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f"\nFuXi-6h 0.25 deg forward (bf16): {ms:.2f} ms, {1e3 / ms:.1f} forwards/s, {m.flops / ms / 1e9:.0f} TFLOP/s algorithmic")

@@ -373,6 +373,119 @@ def swin_block_golden():
     np.savez_compressed(os.path.join(GOLD, "swin_block.npz"), **out)
 
 
+def fuxi_golden():
+    """BASELINE config 5: the FuXi forward through the reference's own modules (credit/models/fuxi.py): `CubeEmbedding`, `DownBlock`,
+    `UpBlock`, `get_pad2d`, `UTransformer.forward`, `Fuxi.forward`, `apply_spectral_norm`, the two classes built without their
+    constructors (which need timm) and populated with exactly the attributes those constructors set.  In the place of timm's
+    `SwinTransformerV2Stage` (not vendored, not pinned: SURVEY.md 8(c)) sits a stage of the reference's OWN V2-Cr blocks
+    (credit/models/swin.py: `SwinTransformerV2CrBlock.forward / _shifted_window_attn / _make_attention_mask / _calc_window_shift`,
+    `WindowMultiHeadAttention.forward`), shift alternating 0 / window // 2 as SwinTransformerV2CrStage (:616-640) builds them; `_Mlp`
+    restates timm.layers.Mlp (fc1 -> act -> fc2).  Weights: wxengine.fuxi.synth_fuxi_state_dict, loaded strict=True -- which also
+    pins the key names and shapes of FuxiConfig.state_spec() outside the stage.  Stored: y and four intermediate maps."""
+    from credit.models import fuxi as RF
+    from credit.models import swin as RS
+    from wxengine.fuxi import named_fuxi_config, synth_fuxi_state_dict
+    from wxengine.synth import keyed_normal
+    nn = torch.nn
+
+    class _Mlp(nn.Module):
+        def __init__(self, i, h, o, act):
+            super().__init__()
+            self.fc1, self.act, self.fc2 = nn.Linear(i, h), act(), nn.Linear(h, o)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    class _CrBlock(nn.Module):
+        forward = RS.SwinTransformerV2CrBlock.forward
+        _shifted_window_attn = RS.SwinTransformerV2CrBlock._shifted_window_attn
+        _make_attention_mask = RS.SwinTransformerV2CrBlock._make_attention_mask
+        _calc_window_shift = RS.SwinTransformerV2CrBlock._calc_window_shift
+
+        def __init__(self, C, feat, ws_t, heads, shifted, meta_hidden):
+            super().__init__()
+            self.dim, self.feat_size = C, feat
+            self.target_shift_size = tuple(w // 2 if shifted else 0 for w in ws_t)
+            self.window_size, self.shift_size = self._calc_window_shift(ws_t)
+            self.window_area = self.window_size[0] * self.window_size[1]
+            attn = RS.WindowMultiHeadAttention.__new__(RS.WindowMultiHeadAttention)
+            nn.Module.__init__(attn)
+            attn.in_features, attn.window_size, attn.num_heads, attn.sequential_attn = C, self.window_size, heads, False
+            attn.qkv, attn.proj = nn.Linear(C, 3 * C), nn.Linear(C, C)
+            attn.attn_drop, attn.proj_drop = nn.Identity(), nn.Identity()
+            attn.meta_mlp = _Mlp(2, meta_hidden, heads, nn.ReLU)
+            attn.logit_scale = nn.Parameter(torch.zeros(heads))
+            attn._make_pair_wise_relative_positions()
+            self.attn = attn
+            self.norm1, self.norm2, self.norm3 = nn.LayerNorm(C), nn.LayerNorm(C), nn.Identity()
+            self.drop_path1, self.drop_path2 = nn.Identity(), nn.Identity()
+            self.mlp = _Mlp(C, 4 * C, C, nn.GELU)
+            self._make_attention_mask()
+
+    class _CrStage(nn.Module):
+        def __init__(self, C, feat, window, heads, depth, meta_hidden):
+            super().__init__()
+            self.blocks = nn.ModuleList([_CrBlock(C, feat, (window, window), heads, i % 2 == 1, meta_hidden) for i in range(depth)])
+
+        def forward(self, x):
+            for b in self.blocks:
+                x = b(x)
+            return x
+
+    for name in ("FT0", "FT1", "FT2"):
+        cfg = named_fuxi_config(name)
+        img = (cfg.frames, cfg.image_height, cfg.image_width)
+        patch = (cfg.frame_patch_size, cfg.patch_height, cfg.patch_width)
+        m = RF.Fuxi.__new__(RF.Fuxi)
+        nn.Module.__init__(m)
+        # the attributes Fuxi.__init__ (:358-452) sets, padding_conf / post_conf / noise off
+        m.use_interp, m.use_spectral_norm, m.use_padding, m.use_post_block = cfg.interp, cfg.use_spectral_norm, False, False
+        m.img_size_original = m.img_size = img
+        m.patch_size = patch
+        m.input_resolution = (round(img[1] / patch[1] / 2), round(img[2] / patch[2] / 2))
+        m.out_chans = cfg.out_chans
+        m.cube_embedding = RF.CubeEmbedding(img, patch, cfg.in_chans, cfg.dim)
+        ut = RF.UTransformer.__new__(RF.UTransformer)
+        nn.Module.__init__(ut)
+        # UTransformer.__init__ (:216-276)
+        ut.padding = RF.get_pad2d(m.input_resolution, (cfg.window_size, cfg.window_size))
+        ut.pad = nn.ZeroPad2d(ut.padding)
+        res = (m.input_resolution[0] + ut.padding[2] + ut.padding[3], m.input_resolution[1] + ut.padding[0] + ut.padding[1])
+        assert res == cfg.stage_feat, (res, cfg.stage_feat)
+        ut.down = RF.DownBlock(cfg.dim, cfg.dim, cfg.groups[0])
+        ut.layer = _CrStage(cfg.dim, res, cfg.window_size, cfg.num_heads, cfg.depth, cfg.meta_hidden)
+        ut.up = RF.UpBlock(cfg.dim * 2, cfg.dim, cfg.groups[1])
+        ut.use_noise = False
+        m.u_transformer = ut
+        m.fc = nn.Linear(cfg.dim, cfg.out_chans * patch[1] * patch[2])
+        if cfg.use_spectral_norm:
+            RF.apply_spectral_norm(m)
+        sd = synth_fuxi_state_dict(cfg)
+        res_ld = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        assert not res_ld.missing_keys and not res_ld.unexpected_keys
+        m.eval()
+        taps = {}
+        hooks = [m.cube_embedding.register_forward_hook(lambda _m, _i, o: taps.__setitem__("embed", o[0, :, 0].permute(1, 2, 0))),
+                 ut.down.register_forward_hook(lambda _m, _i, o: taps.__setitem__("down", o[0].permute(1, 2, 0))),
+                 ut.layer.register_forward_hook(lambda _m, _i, o: taps.__setitem__("stage_padded", o[0])),
+                 ut.register_forward_hook(lambda _m, _i, o: taps.__setitem__("up", o[0].permute(1, 2, 0)))]
+        x = torch.from_numpy(keyed_normal("fuxi/x0", (1, cfg.in_chans, cfg.frames, cfg.image_height, cfg.image_width), 1000))
+        with torch.no_grad():
+            y = RF.Fuxi.forward(m, x)
+        for h in hooks:
+            h.remove()
+        pl, _, pt, _ = ut.padding
+        hd, wd = m.input_resolution
+        taps["stage"] = taps.pop("stage_padded")[pt: pt + hd, pl: pl + wd]
+        assert y.shape == (1, cfg.out_chans, 1, cfg.image_height, cfg.image_width)
+        out = {"y": y[0, :, 0].numpy().astype(np.float32), "padding": np.array(ut.padding, dtype=np.int64)}
+        for k, v in taps.items():
+            out[k] = v.contiguous().numpy().astype(np.float32)
+        np.savez_compressed(os.path.join(GOLD, f"fuxi_{name}.npz"), **out)
+        print(f"[golden] fuxi {name}: in {tuple(x.shape)} stage map {res} padding {ut.padding}  mean|y|={y.abs().mean():.4f} "
+              + " ".join(f"{k}:{tuple(v.shape)}" for k, v in taps.items()))
+
+
 def fixer_inputs(seed=11):
     """Physically plausible random fields on the reference's 10x18 / 7-level demo grid.
     x: [T(7) | q(7) | U(7) | V(7)] x 2 frames; y: the same 28 + [TOA solar, TOA OLR, surf solar, surf LR, SH, LH, precip, evapor]."""
@@ -630,7 +743,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,T0F,RT")
+    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,fuxi,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,T0F,RT")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -643,6 +756,8 @@ def main():
             swin_golden()
         elif item == "swinblock":
             swin_block_golden()
+        elif item == "fuxi":
+            fuxi_golden()
         elif item == "rollC1":      # BASELINE config 2: 24-step rollout on the 1-degree grid
             long_rollout_golden("C1", 24, 20)
         elif item == "rollC3S":     # 8 steps on the 0.25-degree grid (small-width model)
