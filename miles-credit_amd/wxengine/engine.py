@@ -122,6 +122,13 @@ _PROTOTYPES = {
     "wx_swin_apply": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "wx_swin_flops": ([C.c_void_p, C.POINTER(C.c_double)], C.c_int),
     "wx_swin_destroy": ([C.c_void_p], C.c_int),
+    "wx_fuxi_create": ([C.c_void_p, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    "wx_fuxi_load": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64], C.c_int),
+    "wx_fuxi_finalize": ([C.c_void_p], C.c_int),
+    "wx_fuxi_forward": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "wx_fuxi_debug_map": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)], C.c_int),
+    "wx_fuxi_flops": ([C.c_void_p, C.POINTER(C.c_double)], C.c_int),
+    "wx_fuxi_destroy": ([C.c_void_p], C.c_int),
     "wx_last_error": ([], C.c_char_p),
     "wx_version": ([], C.c_char_p),
 }
