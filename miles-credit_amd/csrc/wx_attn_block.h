@@ -1,0 +1,387 @@
+// The attention BLOCK of the wide-and-shallow stages (C = 128 / 256, bf16 engine) as ONE launch:
+//
+//   x <- x + Wout . attn( Wqkv' . LN(x) ) + bo          credit/models/crossformer.py:247-316 (Attention.forward) inside the
+//                                                        residual of Transformer.forward (:351-356)
+//
+// The unfused chain writes q|k|v (3C wide) and the attention output (C wide) to HBM and reads them back: 4C of the 6C
+// channels a sub-block moves per token.  Here a workgroup owns one window (short: a contiguous wsz x wsz block, long: the dilated
+// grid) and one WAVE owns one head (dim_head = 32, C / 32 waves), and nothing but x crosses HBM:
+//
+//   prologue  the window's token rows (<= 112 x C) -> LDS, slot-swizzled; LayerNorm statistics per token (two-pass, fp32)
+//             from the registers the rows pass through
+//   project   q^T, k^T, v^T [32 x tokens] = W' rows of this head (A, straight from L2) . x rows (B, from the LDS tile), LayerNorm
+//             folded in the accumulator: rstd * (acc - mean * colsum) + bias (wx_gemm.h's fold).  The accumulator layout
+//             (4 consecutive head channels of one token per lane) IS an MFMA operand layout once q and k use the SAME channel
+//             permutation for the contraction -> q^T / k^T go to the score MFMAs without leaving the register file;
+//             v^T is stored as the row-major V image the transpose read (ds_read_b64_tr_b16) wants
+//   attend    per 16-query block exactly the stand-alone kernel's sequence (wx_attn.h): S^T = K . Q^T with the position bias as
+//             the accumulator's initial value, row maximum, 2^(s - m) and the row sum on the matrix pipe, O^T = V^T . P^T
+//             -> normalised, bf16, into the (now dead) x tile at this head's channels
+//   out       y^T[32 x tokens] = Wout rows [32 w, 32 w + 32) (A, from L2) . o rows (B, LDS) + bo + x (re-read from L2,
+//             8 bytes per lane) -> x in place
+//
+// LDS: tile 16 NKF x 2C bytes + one 8 KB V image per head + bias table: 66 KB (C = 128, two workgroups per CU) / 128 KB (C = 256).
+#pragma once
+#include "wx_attn.h"
+
+namespace wx {
+
+struct AttnBlockParams {
+  bf16_t* x;            // residual stream [H * W][ld], updated in place (a token belongs to exactly one window)
+  int64_t ld;
+  const bf16_t* wqkv;   // [3C][C] gain-folded rows (q rows carry softmax scale x log2 e), K-contiguous
+  const float* csq;     // [3C] column sums of the rounded rows
+  const float* bq;      // [3C] folded bias
+  const bf16_t* wout;   // [C][C]
+  const float* bo;      // [C]
+  const float* tb;      // position-bias generating table [(2 wsz - 1)^2], x log2 e
+  int H, W, wsz, kind;  // kind 0 short, 1 long (dilated)
+  unsigned long long* trace = nullptr;   // tools/attn_block_probe only (WX_ATTN_TRACE builds): [workgroups * waves][8] phase ticks
+  int dbg = 0;                           // probe ablations: 1 skip the attention loop, 2 skip the projections, 4 skip the out-projection
+};
+
+template <int C, int NKF>
+__global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(const AttnBlockParams p) {
+  typedef bf16_t T;
+  constexpr int HEADS = C / 32, NT = 64 * HEADS;
+  constexpr int TBN = 1024;
+  constexpr int NP = NKF * 16;
+  constexpr int NKB = (NKF + 1) / 2;
+  constexpr int KS = C / 32;            // k steps of the projections
+  constexpr int RB = C * 2;             // tile row bytes
+  constexpr int PR = C / 8;             // 16-byte pieces per row
+  constexpr int VSUB = NKB * 32 * 32;   // bytes of one 16-channel sub-image of V
+  constexpr int VT_BYTES = 2 * VSUB;
+  constexpr bool PREF = C == 128;       // next matrix's weight rows requested one matrix ahead (C = 256: 64 more registers -> spills)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;                                         // [NP][RB]: x rows, later the attention output
+  char* vimg = smem + NP * RB;                               // [HEADS][VT_BYTES]
+  float* s_tb = reinterpret_cast<float*>(vimg + HEADS * VT_BYTES);   // [TBN]
+  int* s_bk = reinterpret_cast<int*>(s_tb + TBN);            // [NP]
+  float2* s_stat = reinterpret_cast<float2*>(s_bk + NP);     // [NP] (mean, rstd)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int head = wave;
+  const int N = p.wsz * p.wsz;
+  const int wins_x = p.W / p.wsz, wins_y = p.H / p.wsz;
+  const int win = blockIdx.x;
+  const int wy0 = win / wins_x, wx0 = win - wy0 * wins_x;
+  int CT, CL, BY, BX;
+  if (p.kind == 0) { CT = p.W - p.wsz; CL = 1; BY = p.wsz * p.W; BX = p.wsz; }
+  else { CT = wins_y * p.W - p.wsz * wins_x; CL = wins_x; BY = p.W; BX = 1; }
+  const unsigned mg_x = (65536u + (unsigned)p.wsz - 1u) / (unsigned)p.wsz;
+  // token t of the window -> pixel; padded tokens alias the last one (their keys carry a -1e30 bias, their query rows are never stored)
+  auto token_pixel = [&](int t) -> int {
+    const int tl = min(t, N - 1);
+    const int ty = (int)(((unsigned)tl * mg_x) >> 16);
+    return ty * CT + tl * CL + wy0 * BY + wx0 * BX;
+  };
+  char* __restrict__ xg = reinterpret_cast<char*>(p.x);
+  const unsigned row_bytes = (unsigned)p.ld * 2u;
+
+#ifdef WX_ATTN_TRACE
+#define AB_TICK(v) const unsigned long long v = trace_tick()
+#define AB_SKIP(bit) (p.dbg & (bit))
+#else
+#define AB_TICK(v)
+#define AB_SKIP(bit) false
+#endif
+  AB_TICK(ab0);
+  // ---- prologue: bias table request, x rows -> registers -> statistics -> LDS --------------------------------------------------------
+  float tbv[TBN / NT];
+  {
+    const int side2 = (2 * p.wsz - 1) * (2 * p.wsz - 1);
+#pragma unroll
+    for (int i = 0; i < TBN / NT; ++i) tbv[i] = p.tb[min(tid + i * NT, side2 - 1)];
+  }
+  {
+    const int piece = tid % PR, r0 = tid / PR;       // 16 rows per pass
+    uint4 xv[NKF];
+#pragma unroll
+    for (int it = 0; it < NKF; ++it)
+      xv[it] = attn_ld16(xg + __umul24((unsigned)token_pixel(it * 16 + r0), row_bytes) + piece * 16);
+#pragma unroll
+    for (int it = 0; it < NKF; ++it) {
+      const int row = it * 16 + r0;
+      float v[8];
+      unpack16<T>(xv[it], v);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[e];
+#pragma unroll
+      for (int o = 1; o < PR; o <<= 1) s += __shfl_xor(s, o);
+      const float mean = s * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q += (v[e] - mean) * (v[e] - mean);
+#pragma unroll
+      for (int o = 1; o < PR; o <<= 1) q += __shfl_xor(q, o);
+      if (piece == 0) s_stat[row] = make_float2(mean, rsqrtf(q * (1.0f / C) + 1e-5f));
+      attn_st16(tile + row * RB + ((piece ^ (row & 15)) << 4), xv[it]);
+    }
+  }
+  {
+    const int side = 2 * p.wsz - 1;
+#pragma unroll
+    for (int i = 0; i < TBN / NT; ++i) {
+      const int e = tid + i * NT;
+      s_tb[e] = e < side * side ? tbv[i] : -1.0e30f;
+    }
+    if (tid < NP) {
+      const int t = tid;
+      const int ty = (int)(((unsigned)t * mg_x) >> 16), tx = t - ty * p.wsz;
+      s_bk[t] = t < N ? 4 * (ty * side + tx) : -2048;
+    }
+  }
+  char* vt = vimg + wave * VT_BYTES;
+  if constexpr (NKF & 1) {   // keys NP .. NKB * 32 of the V image are multiplied by probability 0: they must be finite
+    *reinterpret_cast<uint2*>(vt + (lane >> 5) * VSUB + NP * 32 + (lane & 31) * 16) = make_uint2(0u, 0u);
+    *reinterpret_cast<uint2*>(vt + (lane >> 5) * VSUB + NP * 32 + (lane & 31) * 16 + 8) = make_uint2(0u, 0u);
+  }
+  // this head's rows of W' (A operands), column sums and bias of matrix m (0 = q, 1 = k, 2 = v): requested one matrix ahead of
+  // their use -- the first set before the barrier -- so that no projection waits out an L2 round trip
+  auto load_w = [&](int m, uint4 (&w)[2][KS], float4 (&cs)[2], float4 (&bb)[2]) {
+    const int n0 = m * C + head * 32;
+#pragma unroll
+    for (int df = 0; df < 2; ++df) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) w[df][ks] = attn_ld16(p.wqkv + (size_t)(n0 + df * 16 + li) * C + ks * 32 + g * 8);
+      cs[df] = *reinterpret_cast<const float4*>(p.csq + n0 + df * 16 + g * 4);
+      bb[df] = *reinterpret_cast<const float4*>(p.bq + n0 + df * 16 + g * 4);
+    }
+  };
+  uint4 wf[2][KS];
+  float4 cs[2], bb[2];
+  load_w(0, wf, cs, bb);
+  __syncthreads();
+  AB_TICK(ab1);
+
+  // ---- projections: this head's q^T, k^T, v^T -----------------------------------------------------------------------------------
+  int tokpix[NKF];
+#pragma unroll
+  for (int j = 0; j < NKF; ++j) tokpix[j] = token_pixel(j * 16 + li);
+  uint4 qf[NKF], kf[NKF];
+#ifdef WX_ATTN_TRACE
+#pragma unroll
+  for (int j = 0; j < NKF; ++j) qf[j] = kf[j] = make_uint4(0u, 0u, 0u, 0u);
+#endif
+  if (!AB_SKIP(2))
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {            // 0 = q, 1 = k, 2 = v
+    uint4 wn[2][KS];
+    float4 csn[2], bbn[2];
+    if (PREF && m < 2) load_w(m + 1, wn, csn, bbn);
+    int xo = 0;
+    asm volatile("" : "+v"(xo));   // the x fragments are re-read from LDS for q, k and v: shared, they would be 4 KS NKF live registers
+#pragma unroll
+    for (int tb = 0; tb < NKF; ++tb) {
+      const int row = tb * 16 + li;
+      f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 xf = attn_ld16(tile + xo + row * RB + (((ks * 4 + g) ^ li) << 4));
+        acc[0] = mma_sub<T>(wf[0][ks], xf, acc[0]);
+        acc[1] = mma_sub<T>(wf[1][ks], xf, acc[1]);
+      }
+      const float2 st = s_stat[row];
+      const float ms = -st.x * st.y;     // rstd * (acc - mean * cs) + b = rstd * acc + (ms * cs + b)
+      float v0[4], v1[4];
+      v0[0] = st.y * acc[0][0] + (ms * cs[0].x + bb[0].x); v0[1] = st.y * acc[0][1] + (ms * cs[0].y + bb[0].y);
+      v0[2] = st.y * acc[0][2] + (ms * cs[0].z + bb[0].z); v0[3] = st.y * acc[0][3] + (ms * cs[0].w + bb[0].w);
+      v1[0] = st.y * acc[1][0] + (ms * cs[1].x + bb[1].x); v1[1] = st.y * acc[1][1] + (ms * cs[1].y + bb[1].y);
+      v1[2] = st.y * acc[1][2] + (ms * cs[1].z + bb[1].z); v1[3] = st.y * acc[1][3] + (ms * cs[1].w + bb[1].w);
+      const uint2 lo = make_uint2(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]));
+      const uint2 hi = make_uint2(pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3]));
+      if (m == 0) qf[tb] = make_uint4(lo.x, lo.y, hi.x, hi.y);        // contraction slot j of lane group g <-> channel (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
+      else if (m == 1) kf[tb] = make_uint4(lo.x, lo.y, hi.x, hi.y);   // the same map for q and k: the dot product does not care
+      else {   // V image: sub-image df = [keys][16 channels], 32-byte rows; this lane holds channels 4 g .. 4 g + 3 of key `row`
+        *reinterpret_cast<uint2*>(vt + row * 32 + g * 8) = lo;
+        *reinterpret_cast<uint2*>(vt + VSUB + row * 32 + g * 8) = hi;
+      }
+    }
+    if (m < 2) {
+      if constexpr (PREF) {
+#pragma unroll
+        for (int df = 0; df < 2; ++df) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) wf[df][ks] = wn[df][ks];
+          cs[df] = csn[df];
+          bb[df] = bbn[df];
+        }
+      } else {
+        load_w(m + 1, wf, cs, bb);
+      }
+    }
+  }
+  AB_TICK(ab2);
+  __syncthreads();   // every wave is done with the x rows: the tile becomes the attention output
+  AB_TICK(ab3);
+
+  // ---- attention: the query loop of window_attn_kernel<bf16, NKF, false, true> ----------------------------------------------------
+  auto read_vf = [&](int df, int b, int opaque) -> uint4 {
+    const char* base = vt + opaque + lane * 8 + df * VSUB + b * 1024;
+    const uint2 lo = lds_read_tr16(base), hi = lds_read_tr16(base + 512);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+  };
+  const int nqb = (N + 15) / 16;
+  // a rolled loop (unrolled, hipcc interleaves the blocks and needs > 256 registers); the block's query fragment is picked with
+  // constant indices only, so qf[] stays in registers
+  if (!AB_SKIP(1))
+#pragma unroll 1
+  for (int qb = 0; qb < nqb; ++qb) {
+    {
+      const int query = qb * 16 + li;
+      uint4 qcur = qf[0];
+#pragma unroll
+      for (int j = 1; j < NKF; ++j) {
+        qcur.x = (j == qb) ? qf[j].x : qcur.x; qcur.y = (j == qb) ? qf[j].y : qcur.y;
+        qcur.z = (j == qb) ? qf[j].z : qcur.z; qcur.w = (j == qb) ? qf[j].w : qcur.w;
+      }
+      float sv[NKF][4];
+      float mx = -3.0e38f;
+      const int aq = max(s_bk[query], 0) + 4 * ((p.wsz - 1) * (2 * p.wsz - 1) + (p.wsz - 1));
+      const char* tbb = reinterpret_cast<const char*>(s_tb) + aq;
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+        const int4 bk = *reinterpret_cast<const int4*>(s_bk + j * 16 + g * 4);
+        f32x4_t a = {*reinterpret_cast<const float*>(tbb - bk.x), *reinterpret_cast<const float*>(tbb - bk.y),
+                     *reinterpret_cast<const float*>(tbb - bk.z), *reinterpret_cast<const float*>(tbb - bk.w)};
+        a = mma_sub<T>(kf[j], qcur, a);
+        sv[j][0] = a[0]; sv[j][1] = a[1]; sv[j][2] = a[2]; sv[j][3] = a[3];
+      }
+      // asm VALU reads of MFMA results: the hazard recogniser does not see asm operands (wx_attn.h) -> wait out the write-back here
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][0]), "v"(sv[j][1]));
+        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][2]), "v"(sv[j][3]));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const unsigned mneg = pack_bf16x2(-mx, 0.f) & 0xffffu;
+      const uint4 a_one = make_uint4(g == 0 ? 0x3f80u : 0u, 0u, 0u, 0u), b_m = make_uint4(g == 0 ? mneg : 0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+        f32x4_t a = {sv[j][0], sv[j][1], sv[j][2], sv[j][3]};
+        a = mma_sub<T>(a_one, b_m, a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[j][r] = __builtin_amdgcn_exp2f(a[r]);
+      }
+      f32x4_t oacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+      f32x4_t osum = {0.f, 0.f, 0.f, 0.f};
+      int vo = 0;
+      asm volatile("" : "+v"(vo));
+#pragma unroll
+      for (int b = 0; b < NKB; ++b) {
+        float lo[4], hi[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lo[r] = sv[2 * b][r];
+          hi[r] = (2 * b + 1 < NKF) ? sv[(2 * b + 1 < NKF) ? 2 * b + 1 : 0][r] : 0.f;
+        }
+        const uint4 pf = make_uint4(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]));
+        oacc[0] = mma_sub<T>(read_vf(0, b, vo), pf, oacc[0]);
+        oacc[1] = mma_sub<T>(read_vf(1, b, vo), pf, oacc[1]);
+        osum = mma_sub<T>(make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u), pf, osum);
+      }
+      const float inv = __builtin_amdgcn_rcpf(osum[0]);
+      // o[query][head * 32 + df * 16 + 4 g + r] -> the tile, same swizzle as the x rows had (piece = channel / 8)
+#pragma unroll
+      for (int df = 0; df < 2; ++df) {
+        const uint2 w = make_uint2(pack_bf16x2(oacc[df][0] * inv, oacc[df][1] * inv), pack_bf16x2(oacc[df][2] * inv, oacc[df][3] * inv));
+        const int piece = head * 4 + df * 2 + (g >> 1);
+        *reinterpret_cast<uint2*>(tile + query * RB + ((piece ^ (query & 15)) << 4) + (g & 1) * 8) = w;
+      }
+    }
+  }
+  // ---- out-projection + bias + residual: this wave's 32 output channels ---------------------------------------------------------------
+  // Wout rows, bias and the residual rows (x again: L2 hits, 8 bytes per lane and fragment) are requested before the barrier
+  const int n0 = wave * 32;
+  uint4 wo[2][KS];
+  float4 bo[2];
+  uint2 res[NKF][2];
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wo[nf][ks] = attn_ld16(p.wout + (size_t)(n0 + nf * 16 + li) * C + ks * 32 + g * 8);
+    bo[nf] = *reinterpret_cast<const float4*>(p.bo + n0 + nf * 16 + g * 4);
+  }
+#pragma unroll
+  for (int tb = 0; tb < NKF; ++tb) {
+    const char* xrow = xg + __umul24((unsigned)tokpix[tb], row_bytes) + (n0 + g * 4) * 2;
+    res[tb][0] = *reinterpret_cast<const uint2*>(xrow);
+    res[tb][1] = *reinterpret_cast<const uint2*>(xrow + 32);
+  }
+  AB_TICK(ab4);
+  __syncthreads();
+  AB_TICK(ab5);
+  if (!AB_SKIP(4)) {
+#pragma unroll
+    for (int tb = 0; tb < NKF; ++tb) {
+      if (tb < nqb) {   // uniform
+        const int row = tb * 16 + li;
+        f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint4 of = attn_ld16(tile + row * RB + (((ks * 4 + g) ^ li) << 4));
+          acc[0] = mma_sub<T>(wo[0][ks], of, acc[0]);
+          acc[1] = mma_sub<T>(wo[1][ks], of, acc[1]);
+        }
+        if (row < N) {
+          auto bf = [](uint32_t w, int hi_half) { return __builtin_bit_cast(float, hi_half ? (w & 0xffff0000u) : (w << 16)); };
+          const uint2 r0 = res[tb][0], r1 = res[tb][1];
+          const uint2 y0 = make_uint2(pack_bf16x2(acc[0][0] + bo[0].x + bf(r0.x, 0), acc[0][1] + bo[0].y + bf(r0.x, 1)),
+                                      pack_bf16x2(acc[0][2] + bo[0].z + bf(r0.y, 0), acc[0][3] + bo[0].w + bf(r0.y, 1)));
+          const uint2 y1 = make_uint2(pack_bf16x2(acc[1][0] + bo[1].x + bf(r1.x, 0), acc[1][1] + bo[1].y + bf(r1.x, 1)),
+                                      pack_bf16x2(acc[1][2] + bo[1].z + bf(r1.y, 0), acc[1][3] + bo[1].w + bf(r1.y, 1)));
+          char* xrow = xg + __umul24((unsigned)tokpix[tb], row_bytes) + (n0 + g * 4) * 2;
+          *reinterpret_cast<uint2*>(xrow) = y0;
+          *reinterpret_cast<uint2*>(xrow + 32) = y1;
+        }
+      }
+    }
+  }
+#ifdef WX_ATTN_TRACE
+  if (p.trace && lane == 0) {
+    unsigned long long* t = p.trace + ((size_t)blockIdx.x * HEADS + wave) * 8;
+    const unsigned long long ab6 = trace_tick();
+    t[0] = ab1 - ab0; t[1] = ab2 - ab1; t[2] = ab3 - ab2; t[3] = ab4 - ab3; t[4] = ab5 - ab4; t[5] = ab6 - ab5; t[6] = ab6 - ab0;
+  }
+#endif
+}
+
+inline bool attn_block_supported(int c, int wsz) {
+  if (c != 128 && c != 256) return false;
+  const int nkf = attn_nkf_tokens(wsz * wsz);
+  return wsz >= 3 && (nkf == 1 || nkf == 2 || nkf == 4 || nkf == 7 || nkf == 8);
+}
+
+template <int C, int NKF>
+inline void launch_attn_block_v(const AttnBlockParams& p, hipStream_t stream) {
+  constexpr int NKB = (NKF + 1) / 2;
+  constexpr int LDS = NKF * 16 * C * 2 + (C / 32) * 2 * NKB * 32 * 32 + 1024 * 4 + NKF * 16 * 4 + NKF * 16 * 8;
+  auto kern = attn_block_kernel<C, NKF>;
+  static uint64_t attr_done_mask = 0;
+  if (!attr_done_on_device(attr_done_mask)) {
+    WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_mark_device(attr_done_mask);
+  }
+  const int n_win = (p.H / p.wsz) * (p.W / p.wsz);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_win), dim3(2 * C), LDS, stream, p);
+  WX_HIP(hipGetLastError());
+}
+
+inline void launch_attn_block(int c, const AttnBlockParams& p, hipStream_t stream) {
+  if ((int64_t)p.H * p.W >= (1 << 24) || p.ld * 2 >= (1 << 24) || (int64_t)p.H * p.W * p.ld * 2 >= (int64_t(1) << 32))
+    throw std::runtime_error("attention block: map too large for 24-bit pixel / 32-bit byte addressing");
+  if (!attn_block_supported(c, p.wsz) || (p.kind != 0 && p.kind != 1)) throw std::runtime_error("attention block: unsupported shape");
+  const int nkf = attn_nkf_tokens(p.wsz * p.wsz);
+#define WX_AB(CC, NN) launch_attn_block_v<CC, NN>(p, stream)
+  if (c == 128) { switch (nkf) { case 1: WX_AB(128, 1); break; case 2: WX_AB(128, 2); break; case 4: WX_AB(128, 4); break; case 7: WX_AB(128, 7); break; default: WX_AB(128, 8); } }
+  else { switch (nkf) { case 1: WX_AB(256, 1); break; case 2: WX_AB(256, 2); break; case 4: WX_AB(256, 4); break; case 7: WX_AB(256, 7); break; default: WX_AB(256, 8); } }
+#undef WX_AB
+}
+
+}  // namespace wx

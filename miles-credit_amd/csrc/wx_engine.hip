@@ -26,6 +26,7 @@
 #include <rccl/rccl.h>   // types and prototypes only: the library is bound with dlopen when a communicator is requested
 #include "wx_gemm.h"
 #include "wx_gemm_stream.h"
+#include "wx_attn_block.h"
 #include "wx_swin.h"
 #include "wx_fuxi.h"
 #include "wx_post.h"
@@ -826,6 +827,8 @@ class Engine : public EngineBase {
   bool fuse_ln = true;
   bool fuse_ff = true, fuse_out = true, fuse_qkv = true;          // stages with C in {128, 256}: FeedForward as one kernel (wx_ff.h), bf16 engine
   int ff_variant = 0, ff_dbg = 0, attn_split = 0;
+  bool attn_block = false;      // WX_ATTN_BLOCK=1: stages with C in {128, 256}, bf16 engine: LN + to_qkv + window attention + to_out + residual as ONE launch
+                                // (wx_attn_block.h).  Exact and tested, but measured SLOWER than the fused feed-forward chain on C3: off by default
   int ff_min_wgs = 256;         // fused feed-forward only when it yields at least this many workgroups (WX_FF_MIN_WGS)
   float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
@@ -884,6 +887,7 @@ class Engine : public EngineBase {
     if (const char* e = getenv("WX_NO_LNFUSE")) fuse_ln = !(e[0] == '1');
     if (const char* e = getenv("WX_NO_FFFUSE")) fuse_ff = !(e[0] == '1');
     if (const char* e = getenv("WX_FF_MIN_WGS")) ff_min_wgs = atoi(e);
+    if (const char* e = getenv("WX_ATTN_BLOCK")) attn_block = e[0] == '1';
     if (const char* e = getenv("WX_NO_OUTFUSE")) fuse_out = !(e[0] == '1');
     if (const char* e = getenv("WX_NO_QKVFUSE")) fuse_qkv = !(e[0] == '1');
     if (const char* e = getenv("WX_FF_VARIANT")) ff_variant = atoi(e);
@@ -1249,10 +1253,31 @@ class Engine : public EngineBase {
   }
   // defer_out: leave the attention output in attn_o; the fused feed-forward kernel applies to_out + residual itself
   // qkv_ready: the previous fused feed-forward kernel already wrote this attention's q|k|v into `scratch`
+  // the whole attention sub-block in one launch?  (bf16 engine, C = 128 / 256, unsharded maps; q|k|v and the attention output never
+  // exist in memory on this path: a debug run captures the sub-block's output only)
+  bool attn_block_ok(const AttnL& a, int s) const {
+    if (sizeof(T) != 2 || !attn_block || band_on || attn_kind_override >= 0 || a.bias_tb < 0) return false;
+    return a.wsz > 1 && attn_block_supported(cfg.dim[s], a.wsz) && (a.kind == 0 || a.kind == 1) && a.qkv.cin == cfg.dim[s] && a.out.cin == cfg.dim[s];
+  }
   void attention(const AttnL& a, int s, const std::string& dbg_name, bool defer_out = false, bool qkv_ready = false) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
     const int64_t ld = stream_ld(s);
+    if constexpr (sizeof(T) == 2) {
+      if (attn_block_ok(a, s)) {
+        if (defer_out || qkv_ready) throw StateError("attention block: the fused feed-forward variants must be off for this layer");
+        AttnBlockParams bp;
+        bp.x = reinterpret_cast<bf16_t*>(x); bp.ld = ld;
+        bp.wqkv = reinterpret_cast<const bf16_t*>(wt_dev + a.qkv.wt); bp.csq = f_dev + a.qkv.colsum; bp.bq = f_dev + a.qkv.bias;
+        bp.wout = reinterpret_cast<const bf16_t*>(wt_dev + a.out.wt); bp.bo = f_dev + a.out.bias;
+        bp.tb = f_dev + a.bias_tb; bp.H = h; bp.W = w; bp.wsz = a.wsz; bp.kind = a.kind;
+        const double n = (double)a.wsz * a.wsz;
+        timed("attn_block", 8.0 * m * c * c + 4.0 * m * n * c, 2.0 * m * c * sizeof(T), [&] { launch_attn_block(c, bp, cur_stream); });
+        stat_tiles_ready = 0;
+        capture(dbg_name, x, h, w, c, ld, w);
+        return;
+      }
+    }
     const float2* rs = qkv_ready ? nullptr : stream_stats(x, ld, c, m);
     if (a.wsz == 1) {
       gemm("gemm_qkv", a.vonly, x, h, w, ld, 1, 0, 0, h, w, attn_o, c, rs, 0, nullptr, 0);
@@ -1282,7 +1307,8 @@ class Engine : public EngineBase {
     return cdiv(m, cfg.dim[cur_stage] == 128 ? 128 : 64) >= ff_min_wgs;
   }
   bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on && ff_big_enough(); }
-  bool ff_makes_qkv(const FFL& f) const { return ff_takes_out(f) && fuse_qkv && f.pack_pp >= 0 && !band_on; }
+  bool ff_takes_out(const FFL& f, const AttnL& a) const { return ff_takes_out(f) && !attn_block_ok(a, cur_stage); }
+  bool ff_makes_qkv(const FFL& f) const { return ff_takes_out(f) && fuse_qkv && f.pack_pp >= 0 && !band_on && !(f.next && attn_block_ok(*f.next, cur_stage)); }
   void feedforward(const FFL& f, int s, const std::string& dbg_name, const AttnL* pre = nullptr) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
@@ -1434,7 +1460,7 @@ class Engine : public EngineBase {
     for (size_t d = 0; d < st.blocks.size(); ++d) {
       const std::string bp = sp + ".1.layers." + std::to_string(d);
       const BlockL& bl = st.blocks[d];
-      const bool ds = ff_takes_out(bl.sf), dl = ff_takes_out(bl.lf);
+      const bool ds = ff_takes_out(bl.sf, bl.sa), dl = ff_takes_out(bl.lf, bl.la);
       attention(bl.sa, s, bp + ".0", ds, qkv_made);
       feedforward(bl.sf, s, bp + ".1", ds ? &bl.sa : nullptr);
       attention(bl.la, s, bp + ".2", dl, ds && ff_makes_qkv(bl.sf));
@@ -1447,7 +1473,7 @@ class Engine : public EngineBase {
     const BlockL& bl = stages[s].blocks[d];
     const AttnL& a = long_half ? bl.la : bl.sa;
     const FFL& f = long_half ? bl.lf : bl.sf;
-    const bool df = ff_takes_out(f);
+    const bool df = ff_takes_out(f, a);
     attention(a, s, "", df, false);
     feedforward(f, s, "", df ? &a : nullptr);
   }
