@@ -195,3 +195,42 @@ class SwinStage:
             _check(self.lib.wx_swin_apply(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
                                           C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         return out
+
+
+class Attend:
+    """credit/attend.py::Attend (:40-120) for inference on the GPU: out = softmax(q k^T * scale) v per batch item and head, the
+    non-windowed "thin mode" of the attention operator -- every batch item is one window of the operator's
+    token map.  Same constructor vocabulary (`dropout` must be 0, `flash` is accepted and ignored: the HIP kernel IS the fused path,
+    `scale` None = head_dim ** -0.5).  q, k, v [b, h, n, d] on the GPU, n <= 128 tokens, d in {32, 64, 96, 128}; no CPU fallback."""
+
+    def __init__(self, dropout: float = 0.0, flash: bool = False, scale: Optional[float] = None, precision: str = "bf16"):
+        if dropout:
+            raise ValueError("Attend (HIP): dropout is a training-time option; the engine runs the eval forward")
+        self.scale, self.flash, self.precision = scale, flash, precision
+        self._ops = {}
+
+    @staticmethod
+    def _window(n: int) -> Tuple[int, int]:
+        wx = max(d for d in range(1, 17) if n % d == 0)
+        return n // wx, wx
+
+    def __call__(self, q, k, v):
+        import torch
+        if not (q.is_cuda and q.dim() == 4 and q.shape == k.shape == v.shape):
+            raise WXEngineError("Attend: q, k, v must be GPU tensors of one shape [b, h, n, d]")
+        b, h, n, d = q.shape
+        if n > 128:
+            raise WXEngineError("Attend (HIP): at most 128 tokens per sequence (one window of the attention kernel)")
+        wy, wx = self._window(n)
+        dt = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        key = (b, h, n, d, q.device.index)
+        if key not in self._ops:
+            self._ops[key] = WindowAttention((b * wy, wx), h, d, (wy, wx), (0, 0), kind="block", bias=None,
+                                             softmax_scale=self.scale if self.scale is not None else d ** -0.5,
+                                             precision=self.precision, device=q.device.index)
+        # [b, h, n, d] x 3 -> the operator's token-major map [b * wy, wx, 3 h d] (q | k | v, head-major)
+        qkv = torch.stack((q, k, v), 0).permute(1, 3, 0, 2, 4).reshape(b * wy, wx, 3 * h * d).to(dt).contiguous()
+        o = self._ops[key](qkv)                                             # [b * wy, wx, h d]
+        return o.reshape(b, n, h, d).permute(0, 2, 1, 3).to(q.dtype)
+
+    forward = __call__

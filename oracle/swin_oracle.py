@@ -10,6 +10,7 @@ Restates, in plain torch on the CPU:
   window_attention_core    swin.py:299-330 + :451-486  roll, partition, cosine / dot attention + bias + mask, softmax, P V, merge,
                            roll back -- everything between the qkv projection and the output projection
   block                    swin.py:488-505  x + norm1(proj(core(qkv(x)))), then x + norm2(mlp(x))
+  attend                   credit/attend.py:94-120  the non-windowed softmax(q k^T scale) v (pinned by tests/golden/attend.npz)
 """
 from __future__ import annotations
 
@@ -91,3 +92,9 @@ def block(x: Tensor, sd: dict, heads: int, ws: Tuple[int, int], shift: Tuple[int
     h = F.gelu(F.linear(x, sd[prefix + "mlp.fc1.weight"], sd[prefix + "mlp.fc1.bias"]))
     h = F.linear(h, sd[prefix + "mlp.fc2.weight"], sd[prefix + "mlp.fc2.bias"])
     return x + F.layer_norm(h, (C,), sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], 1e-5)
+
+
+def attend(q: Tensor, k: Tensor, v: Tensor, scale: Optional[float] = None) -> Tensor:
+    """credit/attend.py:94-120 (Attend.forward, non-flash branch): softmax(q k^T * scale) v, q / k / v [b, h, n, d]."""
+    sim = torch.einsum("bhid,bhjd->bhij", q, k) * (scale if scale is not None else q.shape[-1] ** -0.5)
+    return torch.einsum("bhij,bhjd->bhid", sim.softmax(dim=-1), v)

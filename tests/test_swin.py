@@ -244,3 +244,50 @@ def test_fuxi_sized_stage_properties_and_throughput():
     dt = (time.perf_counter() - t0) / n
     print(f"\n[fuxi-sized stage] 84x161 tokens, dim 1024, 8 heads, 7x7 windows, depth 16, bf16: {dt * 1e3:.2f} ms per stage pass, "
           f"{st.flops / dt / 1e12:.0f} TFLOP/s algorithmic (parity unpinned: FuXi's stage is timm's class)")
+
+
+# ---- Attend (credit/attend.py:94-120): the non-windowed mode ----------------------------------------------------------------------------
+ATTEND_GOLD = os.path.join(os.path.dirname(__file__), "golden", "attend.npz")
+ATTEND_CASES = ["n64_d32", "n128_d64_scaled", "n100_d32"]
+
+
+def load_attend(name):
+    g = np.load(ATTEND_GOLD)
+    sc = float(g[f"{name}/scale"][0])
+    return tuple(torch.from_numpy(g[f"{name}/{k}"]) for k in ("q", "k", "v", "out")) + (None if np.isnan(sc) else sc,)
+
+
+@pytest.mark.parametrize("name", ATTEND_CASES)
+def test_oracle_attend_matches_the_reference_class(name):
+    q, k, v, ref, scale = load_attend(name)
+    out = S.attend(q, k, v, scale)
+    assert (out - ref).abs().max() <= 2e-6 * ref.abs().max()
+    # the same thing as one window per batch item of the window-attention oracle (the mapping the HIP `Attend` uses)
+    from wxengine.swin import Attend
+    b, h, n, d = q.shape
+    wy, wx = Attend._window(n)
+    qkv = torch.stack((q, k, v), 0).permute(1, 3, 0, 2, 4).reshape(b * wy, wx, 3 * h * d)
+    o = S.window_attention_core(qkv, h, (wy, wx), (0, 0), None, None, scale if scale is not None else d ** -0.5)
+    o = o.reshape(b, n, h, d).permute(0, 2, 1, 3)
+    assert (o - ref).abs().max() <= 2e-6 * ref.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ATTEND_CASES)
+def test_hip_attend_vs_reference_golden(name, prec):
+    from wxengine.engine import WXEngineError
+    from wxengine.swin import Attend
+    q, k, v, ref, scale = load_attend(name)
+    att = Attend(flash=True, scale=scale, precision=prec)
+    out = att(q.cuda(), k.cuda(), v.cuda()).cpu()
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    if prec == "fp32":
+        assert (out - ref).abs().max() <= 1e-4 * ref.abs().max(), f"{(out - ref).abs().max():.3e}"
+    else:
+        l2 = ((out - ref).norm() / ref.norm()).item()
+        assert l2 <= 2e-2 and (out - ref).abs().max() <= 5e-2 * ref.abs().max(), f"bf16 rel-L2 {l2:.3e}"
+    with pytest.raises(ValueError):
+        Attend(dropout=0.1)
+    with pytest.raises(WXEngineError):
+        att(torch.zeros(1, 2, 200, 32).cuda(), torch.zeros(1, 2, 200, 32).cuda(), torch.zeros(1, 2, 200, 32).cuda())

@@ -373,6 +373,24 @@ def swin_block_golden():
     np.savez_compressed(os.path.join(GOLD, "swin_block.npz"), **out)
 
 
+def attend_golden():
+    """SURVEY.md 8(f) row 4, `Attend` (credit/attend.py:94-120, the non-flash branch: softmax(q k^T * scale) v per batch item and
+    head) run through the reference class itself.  Stored: q, k, v [b, h, n, d] and the output, two shapes / both scale conventions."""
+    from credit.attend import Attend
+    out = {}
+    for name, (b, h, n, d, scale) in {"n64_d32": (3, 4, 64, 32, None), "n128_d64_scaled": (2, 2, 128, 64, 0.2), "n100_d32": (2, 4, 100, 32, None)}.items():
+        g = torch.Generator().manual_seed(sum(map(ord, name)))
+        q, k, v = (torch.randn(b, h, n, d, generator=g) for _ in range(3))
+        att = Attend(dropout=0.0, flash=False, scale=scale).eval()
+        with torch.no_grad():
+            o = att(q, k, v)
+        for nm, t in (("q", q), ("k", k), ("v", v), ("out", o)):
+            out[f"{name}/{nm}"] = t.numpy().astype(np.float32)
+        out[f"{name}/scale"] = np.array([np.nan if scale is None else scale], dtype=np.float32)
+        print(f"[golden] attend {name}: {tuple(q.shape)} scale {scale} mean|out|={o.abs().mean():.4f}")
+    np.savez_compressed(os.path.join(GOLD, "attend.npz"), **out)
+
+
 def fuxi_golden():
     """BASELINE config 5: the FuXi forward through the reference's own modules (credit/models/fuxi.py): `CubeEmbedding`, `DownBlock`,
     `UpBlock`, `get_pad2d`, `UTransformer.forward`, `Fuxi.forward`, `apply_spectral_norm`, the two classes built without their
@@ -743,7 +761,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,fuxi,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,T0F,RT")
+    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,fuxi,attend,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,T0F,RT")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -758,6 +776,8 @@ def main():
             swin_block_golden()
         elif item == "fuxi":
             fuxi_golden()
+        elif item == "attend":
+            attend_golden()
         elif item == "rollC1":      # BASELINE config 2: 24-step rollout on the 1-degree grid
             long_rollout_golden("C1", 24, 20)
         elif item == "rollC3S":     # 8 steps on the 0.25-degree grid (small-width model)
