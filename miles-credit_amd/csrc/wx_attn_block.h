@@ -26,6 +26,10 @@
 
 namespace wx {
 
+#ifndef WX_AB_QUNROLL
+#define WX_AB_QUNROLL 1
+#endif
+
 struct AttnBlockParams {
   bf16_t* x;            // residual stream [H * W][ld], updated in place (a token belongs to exactly one window)
   int64_t ld;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
   // a rolled loop (unrolled, hipcc interleaves the blocks and needs > 256 registers); the block's query fragment is picked with
   // constant indices only, so qf[] stays in registers
   if (!AB_SKIP(1))
-#pragma unroll 1
+#pragma unroll WX_AB_QUNROLL
   for (int qb = 0; qb < nqb; ++qb) {
     {
       const int query = qb * 16 + li;
