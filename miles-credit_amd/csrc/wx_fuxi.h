@@ -53,6 +53,61 @@ __global__ __launch_bounds__(256) void fuxi_unpatchify_kernel(const T* __restric
   }
 }
 
+// The same two maps through LDS, for patch widths that divide 64 (every FuXi configuration): one workgroup per patch row y and chunk
+// of XB = 64 / pw patches, so that BOTH sides move full lines -- the strided side is the LDS side.
+//   gather:  reads 64 consecutive floats (XB patches x pw pixels) of image row (c, t, y ph + py) per wave, writes the XB finished
+//            patch rows (XB x Kpad elements, contiguous in P) with 16-byte stores
+//   scatter: reads the pw * C channels of sub-row py of XB2 = 64 patches, writes 64 pw consecutive floats of out[c][y ph + py] per channel
+template <typename T>
+__global__ __launch_bounds__(256) void fuxi_patchify_lds_kernel(const float* __restrict__ x, T* __restrict__ P, int C, int Tn, int H, int W, int ph,
+                                                                int pw, int Hp, int Wp, int K, int Kpad) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tile = reinterpret_cast<T*>(smem);          // [XB][Kpad]
+  const int XB = 64 / pw;
+  const int chunks = (Wp + XB - 1) / XB;
+  const int y = blockIdx.x / chunks, x0 = (blockIdx.x % chunks) * XB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xl = lane / pw, px = lane - xl * pw;
+  const bool ok = x0 + xl < Wp;
+  const int nseg = C * Tn * ph;                  // (c, t, py) image-row segments
+  for (int i = threadIdx.x; i < XB * (Kpad - K); i += 256) tile[(i / (Kpad - K)) * Kpad + K + i % (Kpad - K)] = Elem<T>::from_f(0.f);
+  const float* src = x + (int64_t)(y * ph) * W + (int64_t)(x0 + xl) * pw + px;
+#pragma unroll 4
+  for (int sg = wave; sg < nseg; sg += 4) {
+    const int py = sg % ph, ct = sg / ph;
+    const float v = ok ? src[((int64_t)ct * H + py) * W] : 0.f;
+    tile[xl * Kpad + sg * pw + px] = Elem<T>::from_f(v);
+  }
+  __syncthreads();
+  const int nx = min(XB, Wp - x0);
+  const int64_t total16 = (int64_t)nx * Kpad * (int)sizeof(T) / 16;
+  uint4* dst = reinterpret_cast<uint4*>(P + ((int64_t)y * Wp + x0) * Kpad);
+  const uint4* st = reinterpret_cast<const uint4*>(tile);
+  for (int64_t i = threadIdx.x; i < total16; i += 256) dst[i] = st[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fuxi_unpatchify_lds_kernel(const T* __restrict__ F, int64_t ldf, float* __restrict__ out, int C, int ph, int pw,
+                                                                  int Hp, int Wp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tile = reinterpret_cast<T*>(smem);          // [XB2][pw * C]
+  const int XB2 = 256 / pw;
+  const int chunks = (Wp + XB2 - 1) / XB2;
+  const int x0 = (blockIdx.x % chunks) * XB2, py = (blockIdx.x / chunks) % ph, y = blockIdx.x / (chunks * ph);
+  const int H = Hp * ph, W = Wp * pw, row = pw * C;
+  const int nx = min(XB2, Wp - x0);
+  for (int i = threadIdx.x; i < nx * row; i += 256) {
+    const int xl = i / row, j = i - xl * row;
+    tile[i] = F[((int64_t)y * Wp + x0 + xl) * ldf + py * row + j];
+  }
+  __syncthreads();
+  const int xl = threadIdx.x / pw, px = threadIdx.x - xl * pw;
+  if (xl < nx) {
+    float* dst = out + (int64_t)(y * ph + py) * W + (int64_t)(x0 + xl) * pw + px;
+    const T* srow = tile + xl * row + px * C;
+    for (int c = 0; c < C; ++c) dst[(int64_t)c * H * W] = Elem<T>::to_f(srow[c]);
+  }
+}
+
 // `pieces` 16-byte pieces of every pixel of a rows x cols window, between maps of different width / channel stride (pad, crop, concat)
 template <typename T>
 __global__ __launch_bounds__(256) void fuxi_copy_pixels_kernel(const T* __restrict__ src, int64_t src_ld, T* __restrict__ dst, int64_t dst_ld, int rows,
@@ -94,6 +149,7 @@ struct FuxiModel : FuxiBase {
   // activations
   T *P, *E, *D0, *TA, *TB, *S, *CAT, *U0, *UA, *UB, *U1, *F;
   double* gn_acc;
+  float2* gn_part;   // [M tiles of 128 rows][dim] per-channel (sum, sum sq) written by the producing convolution's epilogue
   char* zero_page;
   bool ready = false;
 
@@ -135,6 +191,7 @@ struct FuxiModel : FuxiBase {
     P = wT(Mp * K0p); E = wT(Mp * dim); D0 = wT(Md * dim); TA = wT(Mp * dim); TB = wT((Mp + 2 * Wp) * dim); S = wT(Ms * dim); CAT = wT(Md * 2 * dim);
     U0 = wT(Mp * dim); UA = TA; UB = TB; U1 = wT(Mp * dim); F = wT(Mp * (size_t)Nfcp);
     gn_acc = (double*)dalloc(2 * dim * sizeof(double));
+    gn_part = (float2*)dalloc((size_t)cdiv((int64_t)Mp, 128) * dim * sizeof(float2));
     zero_page = (char*)dalloc(256);
     WX_HIP(hipMemset(zero_page, 0, 256));
   }
@@ -249,21 +306,23 @@ struct FuxiModel : FuxiBase {
   }
   // ---- launch helpers ---------------------------------------------------------------------------------------------------------
   void conv(const T* in, int in_h, int in_w, int cin, const T* w, const float* bias, int n, int k, int stride, int pad, int out_h, int out_w, T* out,
-            int64_t out_ld, int out_mode, int cout, hipStream_t s) {
+            int64_t out_ld, int out_mode, int cout, hipStream_t s, bool gn = false) {
     ConvGemmParams p;
     std::memset(&p, 0, sizeof(p));
     p.in = in; p.in_h = in_h; p.in_w = in_w; p.in_ld = cin; p.cin = cin; p.kh = p.kw = k; p.stride = stride; p.pad_y = p.pad_x = pad;
     p.out_h = out_h; p.out_w = out_w; p.wt = w; p.n = n; p.n_alloc = n; p.bias = bias; p.out = out; p.out_ld = out_ld; p.out_mode = out_mode; p.cout = cout;
+    if (gn) {   // GroupNorm partials from the epilogue (fast path only: dim % 64 == 0 guarantees it)
+      if (!conv_gemm_is_dma<T>(p, zero_page)) throw std::runtime_error("fuxi: GroupNorm partials need the LDS-DMA GEMM path");
+      p.gn_out = gn_part;
+    }
     launch_conv_gemm<T>(p, zero_page, s, 0);
   }
   // out = SiLU(GroupNorm(x)) [+ res]
   void gn_silu(const T* x, int64_t m, const float* g, const float* b, int groups, const T* res, T* out, int64_t out_ld, hipStream_t s) {
     constexpr int VEC = 16 / (int)sizeof(T);
     const int c = d.dim;
-    WX_HIP(hipMemsetAsync(gn_acc, 0, 2 * c * sizeof(double), s));
-    const int rows_per_block = 256 / (c / VEC) > 0 ? 256 / (c / VEC) : 1;
-    const int blocks = (int)std::min<int64_t>(2048, (m + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(blocks), dim3(256), 2 * c * sizeof(double), s, x, (int64_t)c, c, m, gn_acc);
+    // statistics: fold the per-tile partials the producing convolution left in gn_part (fixed order: deterministic)
+    hipLaunchKernelGGL(gn_fold_partials_kernel, dim3(c), dim3(256), 0, s, gn_part, (int)cdiv(m, 128), c, gn_acc);
     const int64_t total = m * (c / VEC);
     const int ab = (int)std::min<int64_t>(2048, (total + 255) / 256);
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(ab), dim3(256), 2 * c * sizeof(float), s, x, (int64_t)c, c, m, gn_acc, g, b, groups, (double)m, 1e-5f, res,
@@ -276,14 +335,25 @@ struct FuxiModel : FuxiBase {
     const int dim = d.dim;
     const int64_t Mp = (int64_t)Hp * Wp, Md = (int64_t)Hd * Wd;
     // CubeEmbedding
-    hipLaunchKernelGGL(fuxi_patchify_kernel<T>, dim3(2048), dim3(256), 0, s, x, P, d.C_in, d.frames, d.H, d.W, d.ph, d.pw, Hp, Wp, K0, K0p);
+    const size_t pat_lds = (size_t)(64 / std::max(1, std::min(d.pw, 64))) * K0p * sizeof(T);
+    if (64 % d.pw == 0 && pat_lds <= 72 * 1024 && (K0p * sizeof(T)) % 16 == 0) {
+      const int xb = 64 / d.pw;
+      static uint64_t attr_done_mask = 0;
+      if (!attr_done_on_device(attr_done_mask)) {
+        WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fuxi_patchify_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        attr_mark_device(attr_done_mask);
+      }
+      hipLaunchKernelGGL(fuxi_patchify_lds_kernel<T>, dim3(Hp * cdiv(Wp, xb)), dim3(256), pat_lds, s, x, P, d.C_in, d.frames, d.H, d.W, d.ph, d.pw, Hp, Wp, K0, K0p);
+    } else {
+      hipLaunchKernelGGL(fuxi_patchify_kernel<T>, dim3(2048), dim3(256), 0, s, x, P, d.C_in, d.frames, d.H, d.W, d.ph, d.pw, Hp, Wp, K0, K0p);
+    }
     conv(P, 1, (int)Mp, K0p, w_emb, b_emb, dim, 1, 1, 0, 1, (int)Mp, TA, dim, 0, 0, s);
     hipLaunchKernelGGL((ln_residual_kernel<T, false>), dim3(cdiv(Mp, 4)), dim3(256), 0, s, TA, E, g_emb, be_emb, (int)Mp, dim, 1e-5f);
     // DownBlock
     conv(E, Hp, Wp, dim, w_dconv, b_dconv, dim, 3, 2, 1, Hd, Wd, D0, dim, 0, 0, s);
-    conv(D0, Hd, Wd, dim, w_d0, b_d0, dim, 3, 1, 1, Hd, Wd, TA, dim, 0, 0, s);
+    conv(D0, Hd, Wd, dim, w_d0, b_d0, dim, 3, 1, 1, Hd, Wd, TA, dim, 0, 0, s, true);
     gn_silu(TA, Md, gn_d[0], gn_d[1], d.groups_down, nullptr, TB, dim, s);
-    conv(TB, Hd, Wd, dim, w_d3, b_d3, dim, 3, 1, 1, Hd, Wd, TA, dim, 0, 0, s);
+    conv(TB, Hd, Wd, dim, w_d3, b_d3, dim, 3, 1, 1, Hd, Wd, TA, dim, 0, 0, s, true);
     gn_silu(TA, Md, gn_d[2], gn_d[3], d.groups_down, D0, CAT, 2 * dim, s);   // shortcut half of the concat buffer = the U-Transformer's skip
     // zero-pad to the window multiple, stage, crop into the second half of the concat buffer
     WX_HIP(hipMemsetAsync(S, 0, (size_t)Hs * Ws * dim * sizeof(T), s));
@@ -292,13 +362,18 @@ struct FuxiModel : FuxiBase {
     copy_pixels(S + ((int64_t)pt * Ws + pl) * dim, dim, CAT + dim, 2 * dim, Hd, Wd, Ws, Wd, s);
     // UpBlock
     conv(CAT, Hd, Wd, 2 * dim, w_uconv, b_uconv4, 4 * dim, 1, 1, 0, Hd, Wd, U0, dim, 1, dim, s);
-    conv(U0, Hp, Wp, dim, w_u0, b_u0, dim, 3, 1, 1, Hp, Wp, UA, dim, 0, 0, s);
+    conv(U0, Hp, Wp, dim, w_u0, b_u0, dim, 3, 1, 1, Hp, Wp, UA, dim, 0, 0, s, true);
     gn_silu(UA, Mp, gn_u[0], gn_u[1], d.groups_up, nullptr, UB, dim, s);
-    conv(UB, Hp, Wp, dim, w_u3, b_u3, dim, 3, 1, 1, Hp, Wp, UA, dim, 0, 0, s);
+    conv(UB, Hp, Wp, dim, w_u3, b_u3, dim, 3, 1, 1, Hp, Wp, UA, dim, 0, 0, s, true);
     gn_silu(UA, Mp, gn_u[2], gn_u[3], d.groups_up, U0, U1, dim, s);
     // fc + patch -> pixel
     conv(U1, 1, (int)Mp, dim, w_fc, b_fc, Nfcp, 1, 1, 0, 1, (int)Mp, F, Nfcp, 0, 0, s);
-    hipLaunchKernelGGL(fuxi_unpatchify_kernel<T>, dim3(2048), dim3(256), 0, s, F, (int64_t)Nfcp, y, d.C_out, d.ph, d.pw, Hp, Wp);
+    const size_t unp_lds = (size_t)(256 / std::max(1, std::min(d.pw, 256))) * d.pw * d.C_out * sizeof(T);
+    if (256 % d.pw == 0 && unp_lds <= 64 * 1024) {
+      hipLaunchKernelGGL(fuxi_unpatchify_lds_kernel<T>, dim3(Hp * d.ph * cdiv(Wp, 256 / d.pw)), dim3(256), unp_lds, s, F, (int64_t)Nfcp, y, d.C_out, d.ph, d.pw, Hp, Wp);
+    } else {
+      hipLaunchKernelGGL(fuxi_unpatchify_kernel<T>, dim3(2048), dim3(256), 0, s, F, (int64_t)Nfcp, y, d.C_out, d.ph, d.pw, Hp, Wp);
+    }
     WX_HIP(hipGetLastError());
   }
   // src pixel (r, c) at src[(r * src_w + c) * src_ld] -> dst[(r * dst_w + c) * dst_ld], `dim` channels each

@@ -17,6 +17,7 @@
 
 #include "wx_attn.h"
 #include "wx_gemm.h"
+#include "wx_gemm_stream.h"
 
 namespace wx {
 
@@ -100,6 +101,7 @@ struct SwinStage : SwinStageBase {
   int NP = 0;
   struct Block {
     T *wqkv = nullptr, *wproj = nullptr, *w1 = nullptr, *w2 = nullptr;
+    T *wqkv_kb = nullptr, *wproj_kb = nullptr, *w1_kb = nullptr, *w2_kb = nullptr;   // bf16, big maps: k-blocked copies [K / 32][N][32] for the persistent GEMM
     float *bqkv = nullptr, *bproj = nullptr, *b1 = nullptr, *b2 = nullptr, *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
     float *bias_tab = nullptr, *logit = nullptr;   // [heads][NP][NP] (x log2 e for bf16, padded keys -1e30), [heads] (x log2 e)
     std::vector<bool> seen = std::vector<bool>(14, false);
@@ -108,6 +110,8 @@ struct SwinStage : SwinStageBase {
   std::vector<void*> allocs;
   T *qkv = nullptr, *attn_o = nullptr, *branch = nullptr, *hidden = nullptr;
   char* zero_page = nullptr;
+  char* sink = nullptr;
+  bool use_stream = false;   // the four Linear layers on gemm_stream_kernel (wx_gemm_stream.h) instead of the 128 x 128 tile kernel
   bool ready = false;
 
   void* dalloc(size_t n) {
@@ -140,6 +144,17 @@ struct SwinStage : SwinStageBase {
       b.bias_tab = (float*)dalloc((size_t)d.heads * NP * NP * 4);
       b.logit = (float*)dalloc(d.heads * 4);
     }
+    const size_t stream_min_rows = getenv("WX_SWIN_STREAM_MIN_ROWS") ? (size_t)atoll(getenv("WX_SWIN_STREAM_MIN_ROWS")) : 4096;
+    use_stream = sizeof(T) == 2 && M >= stream_min_rows && d.C >= 512 && d.C % 256 == 0 && d.hidden % 256 == 0 && !getenv("WX_SWIN_NO_STREAM");
+    if (use_stream) {
+      for (Block& b : blocks) {
+        b.wqkv_kb = (T*)dalloc((size_t)3 * d.C * d.C * sizeof(T));
+        b.wproj_kb = (T*)dalloc((size_t)d.C * d.C * sizeof(T));
+        b.w1_kb = (T*)dalloc((size_t)d.hidden * d.C * sizeof(T));
+        b.w2_kb = (T*)dalloc((size_t)d.C * d.hidden * sizeof(T));
+      }
+      sink = (char*)dalloc(4096);
+    }
     qkv = (T*)dalloc(M * 3 * d.C * sizeof(T));
     attn_o = (T*)dalloc(M * d.C * sizeof(T));
     branch = (T*)dalloc(M * d.C * sizeof(T));
@@ -151,11 +166,18 @@ struct SwinStage : SwinStageBase {
     (void)hipSetDevice(device);
     for (void* p : allocs) (void)hipFree(p);
   }
-  void put_w(T* dst, const float* src, int64_t n, int64_t want) {
+  void put_w(T* dst, const float* src, int64_t n, int64_t want, T* dst_kb = nullptr, int64_t K = 0) {
     if (n != want) throw std::runtime_error("swin: tensor has " + std::to_string(n) + " elements, expected " + std::to_string(want));
     std::vector<T> h((size_t)n);
     for (int64_t i = 0; i < n; ++i) h[i] = Elem<T>::from_f(src[i]);
     WX_HIP(hipMemcpy(dst, h.data(), (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+    if (dst_kb) {   // the same rounded values, [K / 32][N][32]
+      const int64_t N = n / K;
+      std::vector<T> t((size_t)n);
+      for (int64_t r = 0; r < N; ++r)
+        for (int64_t k = 0; k < K; ++k) t[(size_t)(((k >> 5) * N + r) * 32 + (k & 31))] = h[(size_t)(r * K + k)];
+      WX_HIP(hipMemcpy(dst_kb, t.data(), (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+    }
   }
   void put_f(float* dst, const float* src, int64_t n, int64_t want) {
     if (n != want) throw std::runtime_error("swin: tensor has " + std::to_string(n) + " elements, expected " + std::to_string(want));
@@ -175,9 +197,9 @@ struct SwinStage : SwinStageBase {
     int which = -1;
     for (int i = 0; i < 14; ++i) if (k == keys[i]) which = i;
     switch (which) {
-      case 0: put_w(b.wqkv, data, count, 3 * C * C); break;
+      case 0: put_w(b.wqkv, data, count, 3 * C * C, b.wqkv_kb, C); break;
       case 1: put_f(b.bqkv, data, count, 3 * C); break;
-      case 2: put_w(b.wproj, data, count, C * C); break;
+      case 2: put_w(b.wproj, data, count, C * C, b.wproj_kb, C); break;
       case 3: put_f(b.bproj, data, count, C); break;
       case 4: {
         if (count != d.heads * N * N) throw std::runtime_error("swin: attn.bias_table must be [heads][N][N]");
@@ -197,9 +219,9 @@ struct SwinStage : SwinStageBase {
       }
       case 6: put_f(b.g1, data, count, C); break;
       case 7: put_f(b.be1, data, count, C); break;
-      case 8: put_w(b.w1, data, count, Hd * C); break;
+      case 8: put_w(b.w1, data, count, Hd * C, b.w1_kb, C); break;
       case 9: put_f(b.b1, data, count, Hd); break;
-      case 10: put_w(b.w2, data, count, C * Hd); break;
+      case 10: put_w(b.w2, data, count, C * Hd, b.w2_kb, Hd); break;
       case 11: put_f(b.b2, data, count, C); break;
       case 12: put_f(b.g2, data, count, C); break;
       case 13: put_f(b.be2, data, count, C); break;
@@ -218,7 +240,19 @@ struct SwinStage : SwinStageBase {
     const double M = (double)d.H * d.W, C = d.C, N = (double)d.wsz_y * d.wsz_x;
     return d.depth * (2.0 * M * C * (3 * C + C + 2.0 * d.hidden) + 4.0 * M * N * C);
   }
-  void linear(const T* in, int K, const T* w, const float* bias, int N, T* out, int act, hipStream_t s) {
+  void linear(const T* in, int K, const T* w, const float* bias, int N, T* out, int act, hipStream_t s, const T* w_kb = nullptr) {
+    if constexpr (sizeof(T) == 2) {
+      if (use_stream && w_kb && stream_gemm_ok((int64_t)d.H * d.W, N, K)) {
+        StreamGemmParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.a = reinterpret_cast<const bf16_t*>(in); q.lda = K; q.w = reinterpret_cast<const bf16_t*>(w_kb);
+        q.M = d.H * d.W; q.N = N; q.K = K; q.bias = bias;
+        q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = N; q.sink = sink;
+        if (act) launch_gemm_stream_v<5, 2, false, true, false, false>(q, s);   // tile choice per epilogue: wx_engine.hip (gemm())
+        else launch_gemm_stream<4, 3>(q, 0, s);
+        return;
+      }
+    }
     ConvGemmParams p;
     std::memset(&p, 0, sizeof(p));
     const int M = d.H * d.W;
@@ -236,7 +270,7 @@ struct SwinStage : SwinStageBase {
     for (int i = 0; i < d.depth; ++i) {
       const Block& b = blocks[i];
       const bool shifted = (i & 1) && (d.shift_y || d.shift_x);
-      linear(x, d.C, b.wqkv, b.bqkv, 3 * d.C, qkv, 0, s);
+      linear(x, d.C, b.wqkv, b.bqkv, 3 * d.C, qkv, 0, s, b.wqkv_kb);
       AttnParams a;
       a.trace = nullptr; a.tb = nullptr; a.pack = 1;
       a.qkv = qkv; a.ld_qkv = 3 * (int64_t)d.C; a.out = attn_o; a.ld_out = d.C; a.bias = b.bias_tab;
@@ -245,10 +279,10 @@ struct SwinStage : SwinStageBase {
       a.mask_val = d.mask_value * l2e; a.logit_scale = b.logit; a.scale = 1.0f; a.q_scale = 0.f;
       a.bias_head_stride = (int64_t)NP * NP;
       launch_window_attn_any<T>(a, d.C / d.heads, s);
-      linear(attn_o, d.C, b.wproj, b.bproj, d.C, branch, 0, s);
+      linear(attn_o, d.C, b.wproj, b.bproj, d.C, branch, 0, s, b.wproj_kb);
       hipLaunchKernelGGL(ln_residual_kernel<T>, dim3(cdiv(M, 4)), dim3(256), 0, s, branch, x, b.g1, b.be1, M, d.C, d.ln_eps);
-      linear(x, d.C, b.w1, b.b1, d.hidden, hidden, 1, s);
-      linear(hidden, d.hidden, b.w2, b.b2, d.C, branch, 0, s);
+      linear(x, d.C, b.w1, b.b1, d.hidden, hidden, 1, s, b.w1_kb);
+      linear(hidden, d.hidden, b.w2, b.b2, d.C, branch, 0, s, b.w2_kb);
       hipLaunchKernelGGL(ln_residual_kernel<T>, dim3(cdiv(M, 4)), dim3(256), 0, s, branch, x, b.g2, b.be2, M, d.C, d.ln_eps);
       WX_HIP(hipGetLastError());
     }

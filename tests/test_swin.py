@@ -246,6 +246,51 @@ def test_fuxi_sized_stage_properties_and_throughput():
           f"{st.flops / dt / 1e12:.0f} TFLOP/s algorithmic (parity unpinned: FuXi's stage is timm's class)")
 
 
+@pytest.mark.gpu
+def test_stage_linear_layers_on_the_persistent_gemm(monkeypatch):
+    """At FuXi's size (>= 4096 tokens, C >= 512) the stage's four Linear layers run on gemm_stream_kernel (k-blocked weight copies,
+    bias / bias + GELU epilogues) instead of the 128 x 128 tile kernel.  WX_SWIN_STREAM_MIN_ROWS=0 forces that path onto a map the CPU
+    oracle finishes in seconds (14 x 21 tokens, C = 512, 4 heads of 128, 7 x 7 windows, 3 blocks; 294 rows: ragged against the 128-
+    and 160-row tiles): checked against the oracle's block (pinned to the reference by swin_block.npz) under the bf16 gate, and against
+    the same stage on the tile kernel (WX_SWIN_NO_STREAM=1)."""
+    from wxengine.swin import SwinStage
+    feat, dim, heads, ws, depth = (14, 21), 512, 4, 7, 3
+    g = torch.Generator().manual_seed(31)
+    r = lambda *s_, sc=1.0: torch.randn(*s_, generator=g) * sc  # noqa: E731
+    sd = {}
+    for i in range(depth):
+        p = f"blocks.{i}."
+        sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"] = r(3 * dim, dim, sc=dim ** -0.5), r(3 * dim, sc=0.1)
+        sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"] = r(dim, dim, sc=dim ** -0.5), r(dim, sc=0.1)
+        sd[p + "attn.meta_mlp.fc1.weight"], sd[p + "attn.meta_mlp.fc1.bias"] = r(32, 2, sc=0.7), r(32, sc=0.1)
+        sd[p + "attn.meta_mlp.fc2.weight"], sd[p + "attn.meta_mlp.fc2.bias"] = r(heads, 32, sc=0.15), r(heads, sc=0.1)
+        sd[p + "attn.logit_scale"] = torch.log(10 * torch.ones(heads)) + r(heads, sc=0.2)
+        sd[p + "norm1.weight"], sd[p + "norm1.bias"] = 1.0 + r(dim, sc=0.2), r(dim, sc=0.1)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = r(4 * dim, dim, sc=dim ** -0.5), r(4 * dim, sc=0.1)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = r(dim, 4 * dim, sc=(4 * dim) ** -0.5), r(dim, sc=0.1)
+        sd[p + "norm2.weight"], sd[p + "norm2.bias"] = 1.0 + r(dim, sc=0.2), r(dim, sc=0.1)
+    x = r(feat[0], feat[1], dim)
+    ref = x
+    for i in range(depth):
+        shift = (0, 0) if i % 2 == 0 else (ws // 2, ws // 2)
+        ref = S.block(ref, sd, heads, (ws, ws), shift, prefix=f"blocks.{i}.")
+    outs = {}
+    for mode, env in (("stream", {"WX_SWIN_STREAM_MIN_ROWS": "0"}), ("tile", {"WX_SWIN_NO_STREAM": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        st = SwinStage(dim=dim, depth=depth, num_heads=heads, feat_size=feat, window_size=ws, precision="bf16")
+        for k in env:
+            monkeypatch.delenv(k)
+        st.load_state_dict(sd)
+        y = st(x.to(torch.bfloat16).cuda())
+        assert torch.equal(y, st(x.to(torch.bfloat16).cuda())), f"{mode}: two runs differ"
+        outs[mode] = y.float().cpu()
+        l2 = ((outs[mode] - ref).norm() / ref.norm()).item()
+        assert l2 <= 2e-2 and (outs[mode] - ref).abs().max() <= 6e-2 * ref.abs().max(), f"{mode}: bf16 rel-L2 {l2:.3e}"
+    l2 = ((outs["stream"] - outs["tile"]).norm() / outs["tile"].norm()).item()
+    assert l2 <= 1e-2, f"persistent GEMM vs tile kernel rel-L2 {l2:.3e}"
+
+
 # ---- Attend (credit/attend.py:94-120): the non-windowed mode ----------------------------------------------------------------------------
 ATTEND_GOLD = os.path.join(os.path.dirname(__file__), "golden", "attend.npz")
 ATTEND_CASES = ["n64_d32", "n128_d64_scaled", "n100_d32"]
