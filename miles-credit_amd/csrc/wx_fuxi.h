@@ -53,37 +53,39 @@ __global__ __launch_bounds__(256) void fuxi_unpatchify_kernel(const T* __restric
   }
 }
 
-// The same two maps through LDS, for patch widths that divide 64 (every FuXi configuration): one workgroup per patch row y and chunk
-// of XB = 64 / pw patches, so that BOTH sides move full lines -- the strided side is the LDS side.
-//   gather:  reads 64 consecutive floats (XB patches x pw pixels) of image row (c, t, y ph + py) per wave, writes the XB finished
-//            patch rows (XB x Kpad elements, contiguous in P) with 16-byte stores
-//   scatter: reads the pw * C channels of sub-row py of XB2 = 64 patches, writes 64 pw consecutive floats of out[c][y ph + py] per channel
+// The same two maps through LDS, so that BOTH sides move full lines -- the strided side is the LDS side.
+//   gather  (patch width 4): one workgroup per patch row y and group of G (c, t) planes; reads whole image rows (W floats, contiguous)
+//           as one float4 = one patch's pixels per lane, writes G ph pw consecutive elements (128 bytes) of every patch of the row
+//   scatter (patch widths dividing 256): reads the pw * C channels of sub-row py of 256 / pw patches, writes 256 consecutive floats of
+//           out[c][y ph + py] per channel
 template <typename T>
-__global__ __launch_bounds__(256) void fuxi_patchify_lds_kernel(const float* __restrict__ x, T* __restrict__ P, int C, int Tn, int H, int W, int ph,
-                                                                int pw, int Hp, int Wp, int K, int Kpad) {
+__global__ __launch_bounds__(256) void fuxi_patchify_rows_kernel(const float* __restrict__ x, T* __restrict__ P, int CT, int H, int W, int ph, int Hp,
+                                                                 int Wp, int Kpad, int G, int ldt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* tile = reinterpret_cast<T*>(smem);          // [XB][Kpad]
-  const int XB = 64 / pw;
-  const int chunks = (Wp + XB - 1) / XB;
-  const int y = blockIdx.x / chunks, x0 = (blockIdx.x % chunks) * XB;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int xl = lane / pw, px = lane - xl * pw;
-  const bool ok = x0 + xl < Wp;
-  const int nseg = C * Tn * ph;                  // (c, t, py) image-row segments
-  for (int i = threadIdx.x; i < XB * (Kpad - K); i += 256) tile[(i / (Kpad - K)) * Kpad + K + i % (Kpad - K)] = Elem<T>::from_f(0.f);
-  const float* src = x + (int64_t)(y * ph) * W + (int64_t)(x0 + xl) * pw + px;
-#pragma unroll 4
-  for (int sg = wave; sg < nseg; sg += 4) {
-    const int py = sg % ph, ct = sg / ph;
-    const float v = ok ? src[((int64_t)ct * H + py) * W] : 0.f;
-    tile[xl * Kpad + sg * pw + px] = Elem<T>::from_f(v);
+  T* tile = reinterpret_cast<T*>(smem);          // [Wp][ldt], ldt = G ph 4 + 8 bytes of padding
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nchunk = (CT + G - 1) / G;
+  const int y = blockIdx.x / nchunk, ct0 = (blockIdx.x % nchunk) * G;
+  const int rows = G * ph;
+  for (int i = threadIdx.x; i < rows * Wp; i += 256) {
+    const int r = i / Wp, xp = i - r * Wp;
+    const int ctl = r / ph, py = r - ctl * ph, ct = ct0 + ctl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ct < CT) v = *reinterpret_cast<const float4*>(x + ((int64_t)ct * H + y * ph + py) * W + xp * 4);
+    T* dst = tile + xp * ldt + r * 4;
+    dst[0] = Elem<T>::from_f(v.x); dst[1] = Elem<T>::from_f(v.y); dst[2] = Elem<T>::from_f(v.z); dst[3] = Elem<T>::from_f(v.w);
   }
   __syncthreads();
-  const int nx = min(XB, Wp - x0);
-  const int64_t total16 = (int64_t)nx * Kpad * (int)sizeof(T) / 16;
-  uint4* dst = reinterpret_cast<uint4*>(P + ((int64_t)y * Wp + x0) * Kpad);
-  const uint4* st = reinterpret_cast<const uint4*>(tile);
-  for (int64_t i = threadIdx.x; i < total16; i += 256) dst[i] = st[i];
+  const int k0 = ct0 * ph * 4, pieces = rows * 4 / VEC;
+  for (int i = threadIdx.x; i < Wp * pieces; i += 256) {
+    const int xp = i / pieces, pc = i - xp * pieces;
+    const int k = k0 + pc * VEC;
+    if (k < Kpad) {
+      const uint2* sp = reinterpret_cast<const uint2*>(tile + xp * ldt + pc * VEC);   // rows are 8-byte aligned
+      const uint2 lo = sp[0], hi = sp[1];
+      *reinterpret_cast<uint4*>(P + ((int64_t)y * Wp + xp) * Kpad + k) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+  }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void fuxi_unpatchify_lds_kernel(const T* __restrict__ F, int64_t ldf, float* __restrict__ out, int C, int ph, int pw,
@@ -335,15 +337,12 @@ struct FuxiModel : FuxiBase {
     const int dim = d.dim;
     const int64_t Mp = (int64_t)Hp * Wp, Md = (int64_t)Hd * Wd;
     // CubeEmbedding
-    const size_t pat_lds = (size_t)(64 / std::max(1, std::min(d.pw, 64))) * K0p * sizeof(T);
-    if (64 % d.pw == 0 && pat_lds <= 72 * 1024 && (K0p * sizeof(T)) % 16 == 0) {
-      const int xb = 64 / d.pw;
-      static uint64_t attr_done_mask = 0;
-      if (!attr_done_on_device(attr_done_mask)) {
-        WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fuxi_patchify_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-        attr_mark_device(attr_done_mask);
-      }
-      hipLaunchKernelGGL(fuxi_patchify_lds_kernel<T>, dim3(Hp * cdiv(Wp, xb)), dim3(256), pat_lds, s, x, P, d.C_in, d.frames, d.H, d.W, d.ph, d.pw, Hp, Wp, K0, K0p);
+    const int G = std::max(1, 128 / (d.ph * 4 * (int)sizeof(T)));             // (c, t) planes per workgroup: 128 bytes of every patch row
+    const int ldt = G * d.ph * 4 + 8 / (int)sizeof(T);
+    const size_t pat_lds = (size_t)Wp * ldt * sizeof(T);
+    if (d.pw == 4 && d.W % 4 == 0 && (G * d.ph * 4 * (int)sizeof(T)) % 16 == 0 && pat_lds <= 64 * 1024) {
+      const int CT = d.C_in * d.frames;
+      hipLaunchKernelGGL(fuxi_patchify_rows_kernel<T>, dim3(Hp * cdiv(CT, G)), dim3(256), pat_lds, s, x, P, CT, d.H, d.W, d.ph, Hp, Wp, K0p, G, ldt);
     } else {
       hipLaunchKernelGGL(fuxi_patchify_kernel<T>, dim3(2048), dim3(256), 0, s, x, P, d.C_in, d.frames, d.H, d.W, d.ph, d.pw, Hp, Wp, K0, K0p);
     }
