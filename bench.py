@@ -144,7 +144,7 @@ def main():
         # HBM traffic of the same kernel from the PMC passes of tools/collect_profiles.sh (rocprofv3 cannot run inside
         # this process; the summary is committed next to the kernel-stats it was collected with)
         traffic = None
-        tname = next((n for n in ("pmc_traffic_r02.json", "pmc_traffic_r01.json") if os.path.isfile(os.path.join(ROOT, "profiles", n))), None)
+        tname = next((n for n in ("pmc_traffic_r03.json", "pmc_traffic_r01.json") if os.path.isfile(os.path.join(ROOT, "profiles", n))), None)
         if args.config == "C3" and args.precision == "bf16" and tname:
             kern = json.load(open(os.path.join(ROOT, "profiles", tname)))["kernels"]
             fam = [kern[k] for k in ("wx::conv_gemm_dma_kernel", "wx::gemm_stream_kernel") if k in kern]
