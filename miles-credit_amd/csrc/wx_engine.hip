@@ -1167,10 +1167,10 @@ class Engine : public EngineBase {
       // LayerNorm-folded 1x1 layers with many rows and K >= 512 (to_qkv, FeedForward layer 1 of stages 2-3): the persistent
       // 128 x 256-tile kernel; measured per shape against the 128 x 128 kernel in tools/gemm_stream_probe
       const bool one = w.kh == 1 && w.kw == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && in_h == out_h && in_w == out_w;
-      // residual layers with N = 512 (to_out, FeedForward layer 2 of stage 2): 160 x 128 tiles, two workgroups per CU
+      // residual layers with N = 512 / 1024 (to_out, FeedForward layer 2 of stages 2 and 3): 160 x 128 tiles, two workgroups per CU
       // (47.9 vs 58.3 us on layer 2, 21.0 vs 23.2 us on to_out; bitwise equal to the 128 x 128 kernel's output)
       if (use_stream && use_dma && w.wt_kb >= 0 && one && !rs && res && act == 0 && out_mode == 0 && want_stats && fuse_ln && !want_gn &&
-          !dbg_flags && w.n == 512 && w.bias >= 0 && (int64_t)out_h * out_w >= stream_min_rows &&
+          !dbg_flags && (w.n == 512 || w.n == 1024) && w.bias >= 0 && (int64_t)out_h * out_w >= stream_min_rows &&
           stream_gemm_ok((int64_t)out_h * out_w, w.n, w.cin, 128)) {
         StreamGemmParams q;
         std::memset(&q, 0, sizeof(q));
