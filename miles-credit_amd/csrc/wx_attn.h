@@ -104,11 +104,14 @@ __device__ __forceinline__ void attn_lds_barrier() { asm volatile("s_waitcnt lgk
 #ifndef WX_ATTN_VLDS
 #define WX_ATTN_VLDS 1
 #endif
+#ifndef WX_ATTN_PAIR
+#define WX_ATTN_PAIR 0   // 1: two query blocks per loop iteration in the 100-token bf16 kernel (see the query loop)
+#endif
 #ifndef WX_ATTN_MFMA_SOFTMAX
 #define WX_ATTN_MFMA_SOFTMAX 1   // bf16: max subtraction and row sum on the matrix pipe (see the query loop)
 #endif
 constexpr int attn_min_waves(int nkf, int dh, int elem, bool sw) {
-  return (elem == 2 && nkf <= 8 && dh <= 32) ? (sw && nkf >= 7 ? 3 : WX_ATTN_MINW) : 1;   // the Swin-mode extras spill at 128 registers
+  return (elem == 2 && nkf <= 8 && dh <= 32) ? ((sw || WX_ATTN_PAIR) && nkf >= 7 ? 3 : WX_ATTN_MINW) : 1;   // the Swin-mode extras spill at 128 registers
 }
 // SW: the Swin-mode features (kind 3 token map, seam mask, cosine attention, per-block q scaling).  A template switch, not a
 // run-time one: the mask test used to split the score loop into one basic block per key fragment, and hipcc schedules inside
@@ -334,6 +337,133 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
       for (int s = 0; s < QK_SUBS; ++s) dst[s] = attn_ld16(qkv_b + qo + s * 64 + g * 16);
     }
   };
+  // PAIR (bf16, 100- / 128-token windows): two query blocks walk the softmax chain side by side.  The chain of one block is a
+  // string of dependent latencies (bias gather: two LDS round trips; score MFMA; 14 dependent v_max3; two cross-lane shuffles; MFMA;
+  // v_exp; four dependent PV MFMAs) that only other waves could fill; a second, independent block in the SAME wave fills it without
+  // costing LDS.  The price is registers: 28 more live scores -> three waves per SIMD instead of four (attn_min_waves).
+  constexpr bool PAIR = WX_ATTN_PAIR && sizeof(T) == 2 && BT && !SW && !SPLIT && DH == 32 && NKF >= 7 && NKF <= 8 && VTR && WX_ATTN_MFMA_SOFTMAX;
+  if constexpr (PAIR) {
+    struct QS {
+      float sv[NKF][4];
+      float mx;
+      int query, qpix;
+      bool qok;
+      f32x4_t o0, o1, osum;
+    };
+    auto scores = [&](QS& q, int qb_, const uint4& qfrag) __attribute__((always_inline)) {
+      q.query = qb_ * 16 + li;
+      q.qpix = tok_of(qb_);
+      q.qok = token_ok(q.query);
+      const int aq = max(s_bk[q.query], 0) + 4 * ((p.wsz - 1) * (2 * p.wsz - 1) + (p.wsz - 1));
+      const char* tbb = reinterpret_cast<const char*>(s_tb) + aq;
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+        const int4 bk = *reinterpret_cast<const int4*>(s_bk + j * 16 + g * 4);
+        f32x4_t a = {*reinterpret_cast<const float*>(tbb - bk.x), *reinterpret_cast<const float*>(tbb - bk.y),
+                     *reinterpret_cast<const float*>(tbb - bk.z), *reinterpret_cast<const float*>(tbb - bk.w)};
+        a = mma_sub<T>(kf[j][0], qfrag, a);
+        q.sv[j][0] = a[0]; q.sv[j][1] = a[1]; q.sv[j][2] = a[2]; q.sv[j][3] = a[3];
+      }
+      q.mx = -3.0e38f;
+    };
+    auto finish_max = [&](QS& q) __attribute__((always_inline)) {
+      q.mx = fmaxf(q.mx, __shfl_xor(q.mx, 16));
+      q.mx = fmaxf(q.mx, __shfl_xor(q.mx, 32));
+    };
+    auto expo = [&](QS& q) __attribute__((always_inline)) {
+      const unsigned mneg = pack_bf16x2(-q.mx, 0.f) & 0xffffu;
+      const uint4 a_one = make_uint4(g == 0 ? 0x3f80u : 0u, 0u, 0u, 0u), b_m = make_uint4(g == 0 ? mneg : 0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+        f32x4_t a = {q.sv[j][0], q.sv[j][1], q.sv[j][2], q.sv[j][3]};
+        a = mma_sub<T>(a_one, b_m, a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q.sv[j][r] = __builtin_amdgcn_exp2f(a[r]);
+      }
+    };
+    auto pv2 = [&](QS& qa, QS& qb2, bool two) __attribute__((always_inline)) {   // both blocks share the V fragments of a key step
+      qa.o0 = qa.o1 = qa.osum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      qb2.o0 = qb2.o1 = qb2.osum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      int vo = 0;
+      asm volatile("" : "+v"(vo));
+      const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+#pragma unroll
+      for (int b = 0; b < NKB; ++b) {
+        const uint4 v0 = read_vf(0, b, vo), v1 = read_vf(1, b, vo);
+        auto pf_of = [&](QS& q) {
+          float lo[4], hi[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            lo[r] = q.sv[2 * b][r];
+            hi[r] = (2 * b + 1 < NKF) ? q.sv[(2 * b + 1 < NKF) ? 2 * b + 1 : 0][r] : 0.f;
+          }
+          return make_uint4(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]));
+        };
+        const uint4 pa = pf_of(qa);
+        qa.o0 = mma_sub<T>(v0, pa, qa.o0);
+        qa.o1 = mma_sub<T>(v1, pa, qa.o1);
+        qa.osum = mma_sub<T>(ones, pa, qa.osum);
+        if (two) {
+          const uint4 pb = pf_of(qb2);
+          qb2.o0 = mma_sub<T>(v0, pb, qb2.o0);
+          qb2.o1 = mma_sub<T>(v1, pb, qb2.o1);
+          qb2.osum = mma_sub<T>(ones, pb, qb2.osum);
+        }
+      }
+    };
+    auto store_o = [&](QS& q) __attribute__((always_inline)) {
+      const float inv = __builtin_amdgcn_rcpf(q.osum[0]);
+      T* orow = out + (size_t)__umul24((unsigned)q.qpix, (unsigned)p.ld_out) + head * D + pair_rows16_channel(g);
+      const uint2 lo = make_uint2(pack_bf16x2(q.o0[0] * inv, q.o0[1] * inv), pack_bf16x2(q.o0[2] * inv, q.o0[3] * inv));
+      const uint2 hi = make_uint2(pack_bf16x2(q.o1[0] * inv, q.o1[1] * inv), pack_bf16x2(q.o1[2] * inv, q.o1[3] * inv));
+      const uint4 w = pair_rows16(lo, hi);
+      if (q.qok) attn_st16(orow, w);
+    };
+    uint4 qn0[1], qn1[1];
+    load_q(0, qn0);
+    load_q(1, qn1);
+    int qb = 0;
+    for (; qb + 1 < nqb; qb += 2) {
+      QS A, B;
+      const uint4 fa = qn0[0], fb = qn1[0];
+      load_q(qb + 2, qn0);
+      load_q(qb + 3, qn1);
+      scores(A, qb, fa);
+      scores(B, qb + 1, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(A.mx) : "v"(A.sv[j][0]), "v"(A.sv[j][1]));
+        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(B.mx) : "v"(B.sv[j][0]), "v"(B.sv[j][1]));
+        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(A.mx) : "v"(A.sv[j][2]), "v"(A.sv[j][3]));
+        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(B.mx) : "v"(B.sv[j][2]), "v"(B.sv[j][3]));
+      }
+      finish_max(A);
+      finish_max(B);
+      expo(A);
+      expo(B);
+      pv2(A, B, true);
+      store_o(A);
+      store_o(B);
+    }
+    if (qb < nqb) {   // odd block count: the last block alone
+      QS A, B;
+      scores(A, qb, qn0[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < NKF; ++j) {
+        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(A.mx) : "v"(A.sv[j][0]), "v"(A.sv[j][1]));
+        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(A.mx) : "v"(A.sv[j][2]), "v"(A.sv[j][3]));
+      }
+      finish_max(A);
+      expo(A);
+      pv2(A, B, false);
+      store_o(A);
+    }
+    return;
+  }
   constexpr int QSTEP = SPLIT ? 4 : 1;
   uint4 qnext[QK_SUBS];
   load_q(SPLIT ? wave : 0, qnext);
