@@ -1001,6 +1001,15 @@ inline void launch_conv_gemm(const ConvGemmParams& p, const void* zero_page, hip
     const int64_t tiles = (int64_t)cdiv(p.out_h * p.out_w, 128) * cdiv(p.n, p.n >= 96 ? 128 : 64);
     (void)ktot_bytes;
     bool kb64 = row_bytes % 128 != 0 || tiles >= 512;
+    // k x k convolutions on big maps walk a deep K per tile (9 C / 16 C elements): there the longer K step wins although the launch has
+    // tiles to spare (round 3, per class on C3: 3 x 3 at 80 000 / 320 000 rows 122 -> 109 / 121 -> 115 us, CrossEmbed k = 4 at 320 000 rows
+    // 110 -> 89 us, merged ConvTranspose-k4 parity convs 261 -> 244 us; FuXi's 3 x 3 convs at 51 200 rows: forward 13.0 -> 11.9 ms).  Smaller
+    // maps and the 1 x 1 / k = 2 layers lose with it (3 x 3 at 20 000 rows 118 -> 128 us) and keep the rule above.
+    {
+      const int taps = p.kh * p.kw;
+      const int64_t rows = (int64_t)p.out_h * p.out_w;
+      if (row_bytes % 128 == 0 && ((taps >= 9 && p.stride == 1 && rows >= 50000) || (taps >= 4 && rows >= 200000))) kb64 = false;
+    }
     if (gemm_cfg == 1 && row_bytes % 128 == 0) kb64 = false;
     if (gemm_cfg == 2) kb64 = true;
     if (p.n >= 96 && gemm_cfg != 3) {
