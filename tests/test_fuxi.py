@@ -76,20 +76,83 @@ def test_host_spectral_norm_fold_matches_the_oracle():
 
 
 def test_config_mirrors_the_reference_constructor():
-    cfg = FuxiConfig.from_model_conf(dict(image_height=640, patch_height=4, image_width=1280, patch_width=4, levels=15, frames=2, frame_patch_size=2,
-                                          dim=1024, num_groups=32, channels=4, surface_channels=7, num_heads=8, depth=16, window_size=7,
-                                          use_spectral_norm=True, interp=True, padding_conf={"activate": False}, post_conf={"activate": False},
-                                          proj_drop=0, attn_drop=0, drop_path=0, type="fuxi"))
-    assert (cfg.in_chans, cfg.out_chans) == (67, 67) and cfg.patches == (160, 320) and cfg.stage_feat == (84, 161)
+    # the model section of the reference's config/gen_1/arXiv_2024/fuxi_6h_single_step.yml, verbatim (pad_lon / pad_lat are swallowed by the
+    # reference class's **kwargs; they are ignored here too)
+    cfg = FuxiConfig.from_model_conf(dict(type="fuxi", frames=2, image_height=640, image_width=1280, levels=16, channels=4, surface_channels=7,
+                                          input_only_channels=3, output_only_channels=0, patch_height=4, patch_width=4, frame_patch_size=2,
+                                          dim=1024, num_groups=32, num_heads=8, window_size=7, depth=16, pad_lon=80, pad_lat=80,
+                                          use_spectral_norm=True))
+    assert (cfg.in_chans, cfg.out_chans) == (74, 71) and cfg.patches == (160, 320) and cfg.stage_feat == (84, 161)
     assert cfg == named_fuxi_config("F6H")
     spec = cfg.state_spec()
-    assert spec["cube_embedding.proj.weight"] == (1024, 67, 2, 4, 4) and "cube_embedding.proj.weight_orig" not in spec   # Conv3d is not wrapped
+    assert spec["cube_embedding.proj.weight"] == (1024, 74, 2, 4, 4) and "cube_embedding.proj.weight_orig" not in spec   # Conv3d is not wrapped
     assert spec["u_transformer.up.conv.weight_orig"] == (2048, 1024, 2, 2) and spec["u_transformer.up.conv.weight_u"] == (1024,)
-    assert spec["fc.weight_orig"] == (67 * 16, 1024)
+    assert spec["fc.weight_orig"] == (71 * 16, 1024)
     for bad in (dict(padding_conf={"activate": True}), dict(post_conf={"activate": True}), dict(use_noise=True), dict(drop_path=0.1),
-                dict(frame_patch_size=1), dict(image_height=642), dict(patch_height=5), dict(not_a_key=1)):
+                dict(frame_patch_size=1), dict(image_height=642), dict(patch_height=5)):
         with pytest.raises(ValueError):
             FuxiConfig.from_model_conf({**dict(image_height=64, patch_height=4, image_width=64, patch_width=4, frames=2, frame_patch_size=2), **bad})
+
+
+def test_registry_class_state_dict_round_trip():
+    """wxengine.fuxi_model.FuxiHIPModel on the CPU: constructor vocabulary, reference key names, torch load_state_dict semantics
+    (strict lists, size mismatch, DDP prefix); no engine is built before the first forward."""
+    from wxengine.fuxi_model import FuxiHIPModel
+    cfg = named_fuxi_config("FT0")
+    kw = {f: getattr(cfg, f) for f in cfg.__dataclass_fields__ if f != "meta_hidden"}
+    m = FuxiHIPModel(precision="bf16", meta_hidden=cfg.meta_hidden, **kw)
+    assert isinstance(m, torch.nn.Module) and m._impl is None
+    sd = {k: torch.from_numpy(v) for k, v in synth_fuxi_state_dict(cfg).items()}
+    assert list(m.state_dict().keys()) == list(cfg.state_spec().keys())
+    r = m.load_state_dict({"module." + k: v for k, v in sd.items()})
+    assert not r.missing_keys and not r.unexpected_keys
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    with pytest.raises(RuntimeError, match="Missing key"):
+        m.load_state_dict({k: v for k, v in sd.items() if k != "fc.bias"})
+    r = m.load_state_dict({k: v for k, v in sd.items() if k != "fc.bias"}, strict=False)
+    assert r.missing_keys == ["fc.bias"]
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        m.load_state_dict({**sd, "fc.bias": torch.zeros(3)})
+    from wxengine.engine import WXEngineError
+    with pytest.raises(WXEngineError):
+        m(torch.zeros(1, cfg.in_chans, cfg.frames, cfg.image_height, cfg.image_width))     # host tensor: no CPU fallback
+
+
+@pytest.mark.reference
+def test_load_model_builds_the_fuxi_class_through_the_real_registry(tmp_path):
+    """credit.models.load_model(conf) with `type: fuxi_hip` on the reference's own fuxi_6h_single_step.yml through a `custom_models` file."""
+    import sys
+    import textwrap
+    import yaml
+    import oracle_stub
+    oracle_stub.install()
+    import importlib
+    import credit.models as cm
+    from credit.models.base_model import BaseModel
+    import wxengine.fuxi_model as fm
+    if not issubclass(fm.FuxiHIPModel, BaseModel):
+        importlib.reload(fm)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    custom = tmp_path / "my_fuxi.py"
+    custom.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path[:0] = [{os.path.join(root, 'miles-credit_amd')!r}]
+        from wxengine.fuxi_model import register
+        register("fuxi_hip")
+    """))
+    with open("/root/reference/config/gen_1/arXiv_2024/fuxi_6h_single_step.yml") as f:
+        conf = yaml.safe_load(f)
+    assert conf["model"]["type"] == "fuxi"
+    conf["model"]["type"] = "fuxi_hip"
+    conf["custom_models"] = [str(custom)]
+    m = cm.load_model(conf)
+    assert isinstance(m, fm.FuxiHIPModel) and isinstance(m, BaseModel)
+    assert m.cfg == named_fuxi_config("F6H")
+    keys = m.state_dict()
+    assert keys["cube_embedding.proj.weight"].shape == (1024, 74, 2, 4, 4)
+    assert sum(v.numel() for v in keys.values()) == sum(int(np.prod(s)) for s in m.cfg.state_spec().values())
+    cm._MODEL_REGISTRY.pop("fuxi_hip", None)
 
 
 # ---- GPU ------------------------------------------------------------------------------------------------------------------------------
@@ -133,6 +196,26 @@ def test_hip_fuxi_vs_reference_golden(name, prec):
 
 
 @pytest.mark.gpu
+def test_registry_class_forward_is_the_engine_forward():
+    """FuxiHIPModel (the nn.Module / BaseModel surface) -> the same bits as FuxiHIP, and new weights reach the engine."""
+    from wxengine.fuxi_model import FuxiHIPModel
+    cfg, sd, x, g = case("FT1")
+    kw = {f: getattr(cfg, f) for f in cfg.__dataclass_fields__}
+    m = FuxiHIPModel(precision="bf16", **kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    xd = torch.from_numpy(x).cuda()
+    y = m(xd)
+    assert torch.equal(y, build(cfg, sd, "bf16")(xd))
+    ref = torch.from_numpy(g["y"])
+    assert ((y[0, :, 0].cpu() - ref).norm() / ref.norm()).item() <= 2e-2
+    sd2 = dict(sd)
+    sd2["fc.bias"] = sd["fc.bias"] + 1.0
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    y2 = m(xd)
+    assert (y2 - y).abs().mean().item() > 0.5          # the bias moved every output pixel by 1
+
+
+@pytest.mark.gpu
 def test_hip_fuxi_rejects_what_it_does_not_implement():
     from wxengine.engine import WXEngineError
     from wxengine.fuxi import FuxiHIP
@@ -160,7 +243,7 @@ def test_hip_fuxi_rejects_what_it_does_not_implement():
 
 @pytest.mark.gpu
 def test_fuxi_6h_full_size_properties_and_throughput():
-    """BASELINE config 5's model (260 M parameters, 67 x 2 x 640 x 1280 in, 51,200 patch tokens, 13,524 stage tokens): finite output of
+    """BASELINE config 5's model (the reference's fuxi_6h_single_step.yml: 266 M parameters, 74 x 2 x 640 x 1280 in, 51,200 patch tokens, 13,524 stage tokens): finite output of
     the right size, bit-identical repeats, the stage's zero padding really is invisible to the valid region's statistics, bf16 close
     to fp32-free invariants -- plus the timing line DESIGN.md quotes.  (No full-size golden: the oracle needs minutes and ~10 GB.)"""
     from wxengine.fuxi import FuxiHIP
@@ -171,7 +254,7 @@ def test_fuxi_6h_full_size_properties_and_throughput():
     x = torch.randn(1, cfg.in_chans, cfg.frames, cfg.image_height, cfg.image_width, generator=torch.Generator().manual_seed(4)).cuda()
     y = m(x)
     torch.cuda.synchronize()
-    assert y.shape == (1, 67, 1, 640, 1280) and torch.isfinite(y).all()
+    assert y.shape == (1, 71, 1, 640, 1280) and torch.isfinite(y).all()
     assert 0.05 < y.abs().mean().item() < 50.0
     y2 = m(x)
     assert torch.equal(y, y2)
