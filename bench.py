@@ -260,8 +260,8 @@ def main():
 
     config5 = None
     if rank == 0 and world == 1 and args.config == "C3" and args.precision == "bf16" and not args.no_config2:
-        # BASELINE config 5 (second architecture): the FuXi-6h 0.25-degree forward (fuxi.py:509-530's example: 640 x 1280, patch 4, 2 frames,
-        # 67 channels, dim 1024, 8 heads, 7 x 7 windows, depth 16; 261 M parameters) through wx_fuxi_*: CubeEmbedding, DownBlock, the Swin
+        # BASELINE config 5 (second architecture): the FuXi-6h 0.25-degree forward (the model section of the reference's fuxi_6h_single_step.yml:
+        # 640 x 1280, patch 4, 2 frames, 74 channels in / 71 out, dim 1024, 8 heads, 7 x 7 windows, depth 16; 266 M parameters) through wx_fuxi_*: CubeEmbedding, DownBlock, the Swin
         # stage on 84 x 161 padded tokens, UpBlock, fc, patch -> pixel.  Keyed synthetic weights.  The stage is the engine's V2-Cr stage
         # (pinned to credit/models/swin.py); the reference instantiates timm's class there, which is not vendored.
         from wxengine.fuxi import FuxiHIP, named_fuxi_config, synth_fuxi_state_dict
