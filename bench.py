@@ -170,6 +170,14 @@ def main():
                                      "peak": 8000.0, "unit": "GB/s", "frac": round(a_gbs / 8000.0, 4),
                                      "launches_per_step": att[0]["launches"] // nprof,
                                      "avg_launch_us": round(1e3 * att[0]["ms"] / max(att[0]["launches"], 1), 2)}
+        # stage 0 runs the one-launch attention sub-block (LN + to_qkv + attention + to_out + residual; q|k|v never reach HBM): its
+        # only HBM traffic is the stream in and out, so its GB/s says how little it moves, not how well -- it is issue-bound
+        blk = [r for r in rows if r["name"] == "attn_block"]
+        if blk and blk[0]["ms"] > 0:
+            roofline["attention_block"] = {"kernel": "wx::attn_block_kernel", "launches_per_step": blk[0]["launches"] // nprof,
+                                           "avg_launch_us": round(1e3 * blk[0]["ms"] / max(blk[0]["launches"], 1), 2),
+                                           "hbm_bytes_per_launch": round(blk[0]["bytes"] / max(blk[0]["launches"], 1)),
+                                           "tflops": round(blk[0]["flops"] / (blk[0]["ms"] * 1e-3) / 1e12, 1)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
