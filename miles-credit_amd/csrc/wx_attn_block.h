@@ -105,23 +105,36 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
 #pragma unroll
     for (int it = 0; it < NKF; ++it)
       xv[it] = attn_ld16(xg + __umul24((unsigned)token_pixel(it * 16 + r0), row_bytes) + piece * 16);
+    // LayerNorm statistics of a row from the registers it passes through: (sum, sum of squares) per lane, folded over the row's PR lanes
+    // with DPP row shifts (an inclusive scan: the row's LAST lane ends up with the totals; no LDS round trip as a shuffle would need),
+    // variance = E[x^2] - mean^2 in fp32 -- the form every other producer of LayerNorm partials in the engine uses
 #pragma unroll
     for (int it = 0; it < NKF; ++it) {
       const int row = it * 16 + r0;
       float v[8];
       unpack16<T>(xv[it], v);
-      float s = 0.f;
+      float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[e];
-#pragma unroll
-      for (int o = 1; o < PR; o <<= 1) s += __shfl_xor(s, o);
-      const float mean = s * (1.0f / C);
-      float q = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) q += (v[e] - mean) * (v[e] - mean);
-#pragma unroll
-      for (int o = 1; o < PR; o <<= 1) q += __shfl_xor(q, o);
-      if (piece == 0) s_stat[row] = make_float2(mean, rsqrtf(q * (1.0f / C) + 1e-5f));
+      for (int e = 0; e < 8; ++e) { s += v[e]; q += v[e] * v[e]; }
+      auto shr_add = [](float a, int ctrl) -> float {   // a + (a of the lane `n` places to the left in its 16-lane row, 0 beyond the row)
+        if (ctrl == 1) return a + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x111, 0xf, 0xf, true));
+        if (ctrl == 2) return a + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x112, 0xf, 0xf, true));
+        if (ctrl == 4) return a + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x114, 0xf, 0xf, true));
+        return a + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x118, 0xf, 0xf, true));
+      };
+      s = shr_add(s, 1); q = shr_add(q, 1);
+      s = shr_add(s, 2); q = shr_add(q, 2);
+      s = shr_add(s, 4); q = shr_add(q, 4);
+      s = shr_add(s, 8); q = shr_add(q, 8);
+      if constexpr (PR == 32) {   // two DPP rows per token row: lane 15's totals join lane 31's
+        s += __shfl_up(s, 16);
+        q += __shfl_up(q, 16);
+      }
+      if (piece == PR - 1) {
+        const float mean = s * (1.0f / C);
+        const float var = fmaxf(q * (1.0f / C) - mean * mean, 0.f);
+        s_stat[row] = make_float2(mean, rsqrtf(var + 1e-5f));
+      }
       attn_st16(tile + row * RB + ((piece ^ (row & 15)) << 4), xv[it]);
     }
   }
@@ -178,17 +191,36 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
     if (PREF && m < 2) load_w(m + 1, wn, csn, bbn);
     int xo = 0;
     asm volatile("" : "+v"(xo));   // the x fragments are re-read from LDS for q, k and v: shared, they would be 4 KS NKF live registers
+    // the x fragments of token block tb + 1 are requested before the MFMAs of block tb (the loop is otherwise a chain: LDS round trip ->
+    // 2 x KS dependent MFMAs -> fold epilogue)
+    uint4 xf[KS], xn[KS];
+    float2 st_n;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = attn_ld16(tile + xo + li * RB + (((ks * 4 + g) ^ li) << 4));
+    st_n = s_stat[li];
 #pragma unroll
     for (int tb = 0; tb < NKF; ++tb) {
       const int row = tb * 16 + li;
+      const float2 st = st_n;
+      if (PREF && tb + 1 < NKF) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xn[ks] = attn_ld16(tile + xo + (row + 16) * RB + (((ks * 4 + g) ^ li) << 4));
+        st_n = s_stat[row + 16];
+      }
       f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const uint4 xf = attn_ld16(tile + xo + row * RB + (((ks * 4 + g) ^ li) << 4));
-        acc[0] = mma_sub<T>(wf[0][ks], xf, acc[0]);
-        acc[1] = mma_sub<T>(wf[1][ks], xf, acc[1]);
+        acc[0] = mma_sub<T>(wf[0][ks], xf[ks], acc[0]);
+        acc[1] = mma_sub<T>(wf[1][ks], xf[ks], acc[1]);
       }
-      const float2 st = s_stat[row];
+      if constexpr (PREF) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = xn[ks];
+      } else if (tb + 1 < NKF) {   // C = 256: 32 more live registers spill; the fragments are read where they are used
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = attn_ld16(tile + xo + (row + 16) * RB + (((ks * 4 + g) ^ li) << 4));
+        st_n = s_stat[row + 16];
+      }
       const float ms = -st.x * st.y;     // rstd * (acc - mean * cs) + b = rstd * acc + (ms * cs + b)
       float v0[4], v1[4];
       v0[0] = st.y * acc[0][0] + (ms * cs[0].x + bb[0].x); v0[1] = st.y * acc[0][1] + (ms * cs[0].y + bb[0].y);
