@@ -104,6 +104,9 @@ __device__ __forceinline__ void attn_lds_barrier() { asm volatile("s_waitcnt lgk
 #ifndef WX_ATTN_VLDS
 #define WX_ATTN_VLDS 1
 #endif
+#ifndef WX_ATTN_PERMLANE_MAX
+#define WX_ATTN_PERMLANE_MAX 1   // softmax row maximum across the four key groups through v_permlane16/32_swap instead of two LDS shuffles
+#endif
 #ifndef WX_ATTN_PAIR
 #define WX_ATTN_PAIR 0   // 1: two query blocks per loop iteration in the 100-token bf16 kernel (see the query loop)
 #endif
@@ -366,10 +369,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
       }
       q.mx = -3.0e38f;
     };
-    auto finish_max = [&](QS& q) __attribute__((always_inline)) {
-      q.mx = fmaxf(q.mx, __shfl_xor(q.mx, 16));
-      q.mx = fmaxf(q.mx, __shfl_xor(q.mx, 32));
-    };
+    auto finish_max = [&](QS& q) __attribute__((always_inline)) { q.mx = max_over_rows(q.mx); };
     auto expo = [&](QS& q) __attribute__((always_inline)) {
       const unsigned mneg = pack_bf16x2(-q.mx, 0.f) & 0xffffu;
       const uint4 a_one = make_uint4(g == 0 ? 0x3f80u : 0u, 0u, 0u, 0u), b_m = make_uint4(g == 0 ? mneg : 0u, 0u, 0u, 0u);
@@ -553,8 +553,11 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
         asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][2]), "v"(sv[j][3]));
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if constexpr (WX_ATTN_PERMLANE_MAX) mx = max_over_rows(mx);
+    else {
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+    }
     AT_TICK(q1);
     float sum = 0.f;
     if constexpr (sizeof(T) == 2 && WX_ATTN_MFMA_SOFTMAX) {

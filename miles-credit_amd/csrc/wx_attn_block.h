@@ -294,8 +294,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
         asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][0]), "v"(sv[j][1]));
         asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][2]), "v"(sv[j][3]));
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = max_over_rows(mx);
       const unsigned mneg = pack_bf16x2(-mx, 0.f) & 0xffffu;
       const uint4 a_one = make_uint4(g == 0 ? 0x3f80u : 0u, 0u, 0u, 0u), b_m = make_uint4(g == 0 ? mneg : 0u, 0u, 0u, 0u);
 #pragma unroll

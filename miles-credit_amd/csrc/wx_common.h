@@ -218,6 +218,18 @@ __device__ __forceinline__ uint4 pair_rows16(uint2 a, uint2 b) {
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 0" : "+v"(a.x), "+v"(b.x), "+v"(a.y), "+v"(b.y));
   return make_uint4(a.x, a.y, b.x, b.y);
 }
+// max over the four lanes that share lane & 15 (the 16-lane rows g = 0..3 of a wave), result in all four -- the softmax row maximum of
+// the attention kernels -- WITHOUT the LDS: two copies of the value go through v_permlane16_swap (row 1 <-> row 0, row 3 <-> row 2 between
+// the copies: afterwards the copies hold rows (0, 0, 2, 2) and (1, 1, 3, 3)) and v_permlane32_swap (lower / upper half), a max after each.
+// A __shfl_xor pair costs two ds_bpermute round trips (~100 cycles each) on the kernel's critical chain.  Needs every lane active.
+__device__ __forceinline__ float max_over_rows(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+  a = fmaxf(a, b);
+  b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
 // channel offset of that 16-byte piece relative to fragment A's first channel
 __device__ __forceinline__ int pair_rows16_channel(int g) { return 16 * (g & 1) + 4 * (g & ~1); }
 
