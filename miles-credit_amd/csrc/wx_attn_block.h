@@ -7,8 +7,8 @@
 // channels a sub-block moves per token.  Here a workgroup owns one window (short: a contiguous wsz x wsz block, long: the dilated
 // grid) and one WAVE owns one head (dim_head = 32, C / 32 waves), and nothing but x crosses HBM:
 //
-//   prologue  the window's token rows (<= 112 x C) -> LDS, slot-swizzled; LayerNorm statistics per token (two-pass, fp32)
-//             from the registers the rows pass through
+//   prologue  the window's token rows (<= 112 x C) -> LDS, slot-swizzled; LayerNorm statistics per token (sum and sum of squares in
+//             fp32, folded over the row's lanes with DPP row shifts) from the registers the rows pass through
 //   project   q^T, k^T, v^T [32 x tokens] = W' rows of this head (A, straight from L2) . x rows (B, from the LDS tile), LayerNorm
 //             folded in the accumulator: rstd * (acc - mean * colsum) + bias (wx_gemm.h's fold).  The accumulator layout
 //             (4 consecutive head channels of one token per lane) IS an MFMA operand layout once q and k use the SAME channel
@@ -21,6 +21,8 @@
 //             8 bytes per lane) -> x in place
 //
 // LDS: tile 16 NKF x 2C bytes + one 8 KB V image per head + bias table: 66 KB (C = 128, two workgroups per CU) / 128 KB (C = 256).
+// Where it runs: wx_engine.hip `attn_block_ok` (default: only where it measured faster than window_attn + the fused feed-forward's head
+// and tail -- C = 128, 100-token windows, >= 2048 windows; DESIGN.md 6c has the per-phase cycle counts and the reasons).
 #pragma once
 #include "wx_attn.h"
 
