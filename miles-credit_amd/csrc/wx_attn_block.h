@@ -31,6 +31,9 @@ namespace wx {
 #ifndef WX_AB_QUNROLL
 #define WX_AB_QUNROLL 1
 #endif
+#ifndef WX_AB_PAIR
+#define WX_AB_PAIR 1   // two query blocks per iteration of the attention loop (windows of >= 49 tokens)
+#endif
 
 struct AttnBlockParams {
   bf16_t* x;            // residual stream [H * W][ld], updated in place (a token belongs to exactly one window)
@@ -263,8 +266,131 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
   };
   const int nqb = (N + 15) / 16;
-  // a rolled loop (unrolled, hipcc interleaves the blocks and needs > 256 registers); the block's query fragment is picked with
-  // constant indices only, so qf[] stays in registers
+  // Two query blocks walk the softmax chain side by side (NKF >= 4): at the two waves per SIMD this kernel's LDS allows, a block's chain of
+  // dependent latencies (bias gather, score MFMA, 14 dependent v_max3, MFMA, v_exp, four dependent PV MFMAs) is exposed; a second,
+  // independent block in the same wave fills it.  (The stand-alone kernel loses with this -- it costs its fourth wave, DESIGN.md 6c -- here
+  // the register maximum is set by the projection phase, so the pairing is free.)  The block's query fragment is picked with constant
+  // indices only, so qf[] stays in registers.
+  constexpr bool PAIR = WX_AB_PAIR && C == 128 && NKF >= 4 && NKF <= 7;   // (C = 256 and 128-token windows spill with it)
+  struct QS {
+    float sv[NKF][4];
+    float mx;
+    int query;
+    f32x4_t o0, o1, osum;
+  };
+  auto pick_q = [&](int qb_) __attribute__((always_inline)) -> uint4 {
+    uint4 q = qf[0];
+#pragma unroll
+    for (int j = 1; j < NKF; ++j) {
+      q.x = (j == qb_) ? qf[j].x : q.x; q.y = (j == qb_) ? qf[j].y : q.y;
+      q.z = (j == qb_) ? qf[j].z : q.z; q.w = (j == qb_) ? qf[j].w : q.w;
+    }
+    return q;
+  };
+  auto scores = [&](QS& q, int qb_) __attribute__((always_inline)) {
+    q.query = qb_ * 16 + li;
+    const uint4 qcur = pick_q(qb_);
+    const int aq = max(s_bk[q.query], 0) + 4 * ((p.wsz - 1) * (2 * p.wsz - 1) + (p.wsz - 1));
+    const char* tbb = reinterpret_cast<const char*>(s_tb) + aq;
+#pragma unroll
+    for (int j = 0; j < NKF; ++j) {
+      const int4 bk = *reinterpret_cast<const int4*>(s_bk + j * 16 + g * 4);
+      f32x4_t a = {*reinterpret_cast<const float*>(tbb - bk.x), *reinterpret_cast<const float*>(tbb - bk.y),
+                   *reinterpret_cast<const float*>(tbb - bk.z), *reinterpret_cast<const float*>(tbb - bk.w)};
+      a = mma_sub<T>(kf[j], qcur, a);
+      q.sv[j][0] = a[0]; q.sv[j][1] = a[1]; q.sv[j][2] = a[2]; q.sv[j][3] = a[3];
+    }
+    q.mx = -3.0e38f;
+  };
+  auto expo = [&](QS& q) __attribute__((always_inline)) {
+    q.mx = max_over_rows(q.mx);
+    const unsigned mneg = pack_bf16x2(-q.mx, 0.f) & 0xffffu;
+    const uint4 a_one = make_uint4(g == 0 ? 0x3f80u : 0u, 0u, 0u, 0u), b_m = make_uint4(g == 0 ? mneg : 0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int j = 0; j < NKF; ++j) {
+      f32x4_t a = {q.sv[j][0], q.sv[j][1], q.sv[j][2], q.sv[j][3]};
+      a = mma_sub<T>(a_one, b_m, a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q.sv[j][r] = __builtin_amdgcn_exp2f(a[r]);
+    }
+  };
+  auto pf_of = [&](QS& q, int b) __attribute__((always_inline)) -> uint4 {
+    float lo[4], hi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lo[r] = q.sv[2 * b][r];
+      hi[r] = (2 * b + 1 < NKF) ? q.sv[(2 * b + 1 < NKF) ? 2 * b + 1 : 0][r] : 0.f;
+    }
+    return make_uint4(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]));
+  };
+  auto store_o = [&](QS& q) __attribute__((always_inline)) {   // o[query][head * 32 + df * 16 + 4 g + r] -> the tile, swizzled like the x rows
+    const float inv = __builtin_amdgcn_rcpf(q.osum[0]);
+    const uint2 w0 = make_uint2(pack_bf16x2(q.o0[0] * inv, q.o0[1] * inv), pack_bf16x2(q.o0[2] * inv, q.o0[3] * inv));
+    const uint2 w1 = make_uint2(pack_bf16x2(q.o1[0] * inv, q.o1[1] * inv), pack_bf16x2(q.o1[2] * inv, q.o1[3] * inv));
+    const int pc = head * 4 + (g >> 1);
+    *reinterpret_cast<uint2*>(tile + q.query * RB + ((pc ^ (q.query & 15)) << 4) + (g & 1) * 8) = w0;
+    *reinterpret_cast<uint2*>(tile + q.query * RB + (((pc + 2) ^ (q.query & 15)) << 4) + (g & 1) * 8) = w1;
+  };
+  const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  if constexpr (PAIR) {
+    if (!AB_SKIP(1)) {
+      int qb = 0;
+#pragma unroll 1
+      for (; qb + 1 < nqb; qb += 2) {
+        QS A, B;
+        scores(A, qb);
+        scores(B, qb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NKF; ++j) {
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(A.mx) : "v"(A.sv[j][0]), "v"(A.sv[j][1]));
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(B.mx) : "v"(B.sv[j][0]), "v"(B.sv[j][1]));
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(A.mx) : "v"(A.sv[j][2]), "v"(A.sv[j][3]));
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(B.mx) : "v"(B.sv[j][2]), "v"(B.sv[j][3]));
+        }
+        expo(A);
+        expo(B);
+        A.o0 = A.o1 = A.osum = B.o0 = B.o1 = B.osum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        int vo = 0;
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int b = 0; b < NKB; ++b) {   // both blocks share the V fragments of a key step
+          const uint4 v0 = read_vf(0, b, vo), v1 = read_vf(1, b, vo);
+          const uint4 pa = pf_of(A, b), pb = pf_of(B, b);
+          A.o0 = mma_sub<T>(v0, pa, A.o0); B.o0 = mma_sub<T>(v0, pb, B.o0);
+          A.o1 = mma_sub<T>(v1, pa, A.o1); B.o1 = mma_sub<T>(v1, pb, B.o1);
+          A.osum = mma_sub<T>(ones, pa, A.osum); B.osum = mma_sub<T>(ones, pb, B.osum);
+        }
+        store_o(A);
+        store_o(B);
+      }
+      if (qb < nqb) {   // odd block count: the last block alone
+        QS A;
+        scores(A, qb);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NKF; ++j) {
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(A.mx) : "v"(A.sv[j][0]), "v"(A.sv[j][1]));
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(A.mx) : "v"(A.sv[j][2]), "v"(A.sv[j][3]));
+        }
+        expo(A);
+        A.o0 = A.o1 = A.osum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        int vo = 0;
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int b = 0; b < NKB; ++b) {
+          const uint4 pa = pf_of(A, b);
+          A.o0 = mma_sub<T>(read_vf(0, b, vo), pa, A.o0);
+          A.o1 = mma_sub<T>(read_vf(1, b, vo), pa, A.o1);
+          A.osum = mma_sub<T>(ones, pa, A.osum);
+        }
+        store_o(A);
+      }
+    }
+  } else {
+  // one block per iteration, rolled (unrolled, hipcc interleaves the blocks and needs > 256 registers)
   if (!AB_SKIP(1))
 #pragma unroll WX_AB_QUNROLL
   for (int qb = 0; qb < nqb; ++qb) {
@@ -332,6 +458,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
         *reinterpret_cast<uint2*>(tile + query * RB + ((piece ^ (query & 15)) << 4) + (g & 1) * 8) = w;
       }
     }
+  }
   }
   // ---- out-projection + bias + residual: this wave's 32 output channels ---------------------------------------------------------------
   // Wout rows, bias and the residual rows (x again: L2 hits, 8 bytes per lane and fragment) are requested before the barrier
