@@ -130,6 +130,7 @@ def test_fused_feed_forward_kernel_on_small_maps(name, monkeypatch):
     WX_FF_MIN_WGS=0 forces it onto the small maps so that its every variant (plain, +out-proj, +out-proj+qkv) is also checked
     against the oracle at sizes the oracle finishes in seconds, ragged last tiles included."""
     monkeypatch.setenv("WX_FF_MIN_WGS", "0")
+    monkeypatch.setenv("WX_ATTN_BLOCK", "0")   # (on these small maps the one-launch attention block would take the out-projection and to_qkv)
     cfg = named_config(name)
     sd = synth_state_dict(cfg)
     eng = WXEngine(cfg, "bf16", 0)
@@ -142,6 +143,7 @@ def test_fused_feed_forward_kernel_on_small_maps(name, monkeypatch):
     assert "out_ff_qkv_fused" in names and "out_ff_fused" in names
     check(y, O.forward(cfg, sd, x).numpy(), "bf16")
     monkeypatch.delenv("WX_FF_MIN_WGS")
+    monkeypatch.delenv("WX_ATTN_BLOCK")
     eng2 = WXEngine(cfg, "bf16", 0)
     eng2.load_state_dict(sd)
     eng2.finalize()
