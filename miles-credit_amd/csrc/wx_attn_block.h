@@ -1,4 +1,4 @@
-// The attention BLOCK of the wide-and-shallow stages (C = 128 / 256, bf16 engine) as ONE launch:
+// The attention BLOCK of the wide-and-shallow stages (C = 32 .. 256, bf16 engine) as ONE launch:
 //
 //   x <- x + Wout . attn( Wqkv' . LN(x) ) + bo          credit/models/crossformer.py:247-316 (Attention.forward) inside the
 //                                                        residual of Transformer.forward (:351-356)
@@ -50,7 +50,7 @@ struct AttnBlockParams {
 };
 
 template <int C, int NKF>
-__global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(const AttnBlockParams p) {
+__global__ __launch_bounds__(2 * C, C == 256 ? 1 : 2) void attn_block_kernel(const AttnBlockParams p) {
   typedef bf16_t T;
   constexpr int HEADS = C / 32, NT = 64 * HEADS;
   constexpr int TBN = 1024;
@@ -59,9 +59,10 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
   constexpr int KS = C / 32;            // k steps of the projections
   constexpr int RB = C * 2;             // tile row bytes
   constexpr int PR = C / 8;             // 16-byte pieces per row
+  constexpr int SWZ = PR < 16 ? PR - 1 : 15;   // slot swizzle mask: piece ^ (row & SWZ) stays inside the row
   constexpr int VSUB = NKB * 32 * 32;   // bytes of one 16-channel sub-image of V
   constexpr int VT_BYTES = 2 * VSUB;
-  constexpr bool PREF = C == 128;       // next matrix's weight rows requested one matrix ahead (C = 256: 64 more registers -> spills)
+  constexpr bool PREF = C <= 128;       // next matrix's weight rows requested one matrix ahead (C = 256: 64 more registers -> spills)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tile = smem;                                         // [NP][RB]: x rows, later the attention output
   char* vimg = smem + NP * RB;                               // [HEADS][VT_BYTES]
@@ -127,10 +128,12 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
         if (ctrl == 4) return a + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x114, 0xf, 0xf, true));
         return a + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x118, 0xf, 0xf, true));
       };
+      // log2(PR) steps: every lane ends up with the sum over the PR lanes ending at it, so the LAST lane of a token row holds exactly that
+      // row's totals also when several token rows share a 16-lane DPP row (C = 32 / 64: PR = 4 / 8)
       s = shr_add(s, 1); q = shr_add(q, 1);
       s = shr_add(s, 2); q = shr_add(q, 2);
-      s = shr_add(s, 4); q = shr_add(q, 4);
-      s = shr_add(s, 8); q = shr_add(q, 8);
+      if constexpr (PR >= 8) { s = shr_add(s, 4); q = shr_add(q, 4); }
+      if constexpr (PR >= 16) { s = shr_add(s, 8); q = shr_add(q, 8); }
       if constexpr (PR == 32) {   // two DPP rows per token row: lane 15's totals join lane 31's
         s += __shfl_up(s, 16);
         q += __shfl_up(q, 16);
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
         const float var = fmaxf(q * (1.0f / C) - mean * mean, 0.f);
         s_stat[row] = make_float2(mean, rsqrtf(var + 1e-5f));
       }
-      attn_st16(tile + row * RB + ((piece ^ (row & 15)) << 4), xv[it]);
+      attn_st16(tile + row * RB + ((piece ^ (row & SWZ)) << 4), xv[it]);
     }
   }
   {
@@ -150,8 +153,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
       const int e = tid + i * NT;
       s_tb[e] = e < side * side ? tbv[i] : -1.0e30f;
     }
-    if (tid < NP) {
-      const int t = tid;
+    for (int t = tid; t < NP; t += NT) {
       const int ty = (int)(((unsigned)t * mg_x) >> 16), tx = t - ty * p.wsz;
       s_bk[t] = t < N ? 4 * (ty * side + tx) : -2048;
     }
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
     uint4 xf[KS], xn[KS];
     float2 st_n;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[ks] = attn_ld16(tile + xo + li * RB + (((ks * 4 + g) ^ li) << 4));
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = attn_ld16(tile + xo + li * RB + (((ks * 4 + g) ^ (li & SWZ)) << 4));
     st_n = s_stat[li];
 #pragma unroll
     for (int tb = 0; tb < NKF; ++tb) {
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
       const float2 st = st_n;
       if (PREF && tb + 1 < NKF) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xn[ks] = attn_ld16(tile + xo + (row + 16) * RB + (((ks * 4 + g) ^ li) << 4));
+        for (int ks = 0; ks < KS; ++ks) xn[ks] = attn_ld16(tile + xo + (row + 16) * RB + (((ks * 4 + g) ^ (li & SWZ)) << 4));
         st_n = s_stat[row + 16];
       }
       f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
         for (int ks = 0; ks < KS; ++ks) xf[ks] = xn[ks];
       } else if (tb + 1 < NKF) {   // C = 256: 32 more live registers spill; the fragments are read where they are used
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xf[ks] = attn_ld16(tile + xo + (row + 16) * RB + (((ks * 4 + g) ^ li) << 4));
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = attn_ld16(tile + xo + (row + 16) * RB + (((ks * 4 + g) ^ (li & SWZ)) << 4));
         st_n = s_stat[row + 16];
       }
       const float ms = -st.x * st.y;     // rstd * (acc - mean * cs) + b = rstd * acc + (ms * cs + b)
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
   // independent block in the same wave fills it.  (The stand-alone kernel loses with this -- it costs its fourth wave, DESIGN.md 6c -- here
   // the register maximum is set by the projection phase, so the pairing is free.)  The block's query fragment is picked with constant
   // indices only, so qf[] stays in registers.
-  constexpr bool PAIR = WX_AB_PAIR && C == 128 && NKF >= 4 && NKF <= 7;   // (C = 256 and 128-token windows spill with it)
+  constexpr bool PAIR = WX_AB_PAIR && C <= 128 && NKF >= 4 && NKF <= 7;   // (C = 256 and 128-token windows spill with it)
   struct QS {
     float sv[NKF][4];
     float mx;
@@ -328,8 +330,8 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
     const uint2 w0 = make_uint2(pack_bf16x2(q.o0[0] * inv, q.o0[1] * inv), pack_bf16x2(q.o0[2] * inv, q.o0[3] * inv));
     const uint2 w1 = make_uint2(pack_bf16x2(q.o1[0] * inv, q.o1[1] * inv), pack_bf16x2(q.o1[2] * inv, q.o1[3] * inv));
     const int pc = head * 4 + (g >> 1);
-    *reinterpret_cast<uint2*>(tile + q.query * RB + ((pc ^ (q.query & 15)) << 4) + (g & 1) * 8) = w0;
-    *reinterpret_cast<uint2*>(tile + q.query * RB + (((pc + 2) ^ (q.query & 15)) << 4) + (g & 1) * 8) = w1;
+    *reinterpret_cast<uint2*>(tile + q.query * RB + ((pc ^ (q.query & SWZ)) << 4) + (g & 1) * 8) = w0;
+    *reinterpret_cast<uint2*>(tile + q.query * RB + (((pc + 2) ^ (q.query & SWZ)) << 4) + (g & 1) * 8) = w1;
   };
   const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
   if constexpr (PAIR) {
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
       for (int df = 0; df < 2; ++df) {
         const uint2 w = make_uint2(pack_bf16x2(oacc[df][0] * inv, oacc[df][1] * inv), pack_bf16x2(oacc[df][2] * inv, oacc[df][3] * inv));
         const int piece = head * 4 + df * 2 + (g >> 1);
-        *reinterpret_cast<uint2*>(tile + query * RB + ((piece ^ (query & 15)) << 4) + (g & 1) * 8) = w;
+        *reinterpret_cast<uint2*>(tile + query * RB + ((piece ^ (query & SWZ)) << 4) + (g & 1) * 8) = w;
       }
     }
   }
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
         f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const uint4 of = attn_ld16(tile + row * RB + (((ks * 4 + g) ^ li) << 4));
+          const uint4 of = attn_ld16(tile + row * RB + (((ks * 4 + g) ^ (li & SWZ)) << 4));
           acc[0] = mma_sub<T>(wo[0][ks], of, acc[0]);
           acc[1] = mma_sub<T>(wo[1][ks], of, acc[1]);
         }
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(2 * C, C == 128 ? 2 : 1) void attn_block_kernel(con
 }
 
 inline bool attn_block_supported(int c, int wsz) {
-  if (c != 128 && c != 256) return false;
+  if (c != 32 && c != 64 && c != 128 && c != 256) return false;
   const int nkf = attn_nkf_tokens(wsz * wsz);
   return wsz >= 3 && (nkf == 1 || nkf == 2 || nkf == 4 || nkf == 7 || nkf == 8);
 }
@@ -543,7 +545,9 @@ inline void launch_attn_block(int c, const AttnBlockParams& p, hipStream_t strea
   if (!attn_block_supported(c, p.wsz) || (p.kind != 0 && p.kind != 1)) throw std::runtime_error("attention block: unsupported shape");
   const int nkf = attn_nkf_tokens(p.wsz * p.wsz);
 #define WX_AB(CC, NN) launch_attn_block_v<CC, NN>(p, stream)
-  if (c == 128) { switch (nkf) { case 1: WX_AB(128, 1); break; case 2: WX_AB(128, 2); break; case 4: WX_AB(128, 4); break; case 7: WX_AB(128, 7); break; default: WX_AB(128, 8); } }
+  if (c == 32) { switch (nkf) { case 1: WX_AB(32, 1); break; case 2: WX_AB(32, 2); break; case 4: WX_AB(32, 4); break; case 7: WX_AB(32, 7); break; default: WX_AB(32, 8); } }
+  else if (c == 64) { switch (nkf) { case 1: WX_AB(64, 1); break; case 2: WX_AB(64, 2); break; case 4: WX_AB(64, 4); break; case 7: WX_AB(64, 7); break; default: WX_AB(64, 8); } }
+  else if (c == 128) { switch (nkf) { case 1: WX_AB(128, 1); break; case 2: WX_AB(128, 2); break; case 4: WX_AB(128, 4); break; case 7: WX_AB(128, 7); break; default: WX_AB(128, 8); } }
   else { switch (nkf) { case 1: WX_AB(256, 1); break; case 2: WX_AB(256, 2); break; case 4: WX_AB(256, 4); break; case 7: WX_AB(256, 7); break; default: WX_AB(256, 8); } }
 #undef WX_AB
 }

@@ -830,8 +830,8 @@ class Engine : public EngineBase {
   int attn_block = 2;           // WX_ATTN_BLOCK: LN + to_qkv + window attention + to_out + residual as ONE launch (wx_attn_block.h), bf16 engine.
                                 // 0 never; 1 wherever the kernel exists (C in {128, 256}); 2 (default) only where it measured faster than the
                                 // fused feed-forward chain on MI355X: C = 128 with 100-token windows on >= 2048 windows (C3 stage 0: 165 + 136 us
-                                // against 91 + 218 us per sub-block, and 0.5 GB less HBM traffic each) and on maps of <= 8192 tokens, where three
-                                // launch-bound kernels become one (1-degree model +2-3 %); slower in between
+                                // against 91 + 218 us per sub-block, and 0.5 GB less HBM traffic each) and on maps of <= 32768 tokens, where three
+                                // launch-bound kernels become one (1-degree model +5 %); slower in between
   int ff_min_wgs = 256;         // fused feed-forward only when it yields at least this many workgroups (WX_FF_MIN_WGS)
   float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
@@ -1262,7 +1262,7 @@ class Engine : public EngineBase {
     if (sizeof(T) != 2 || !attn_block || band_on || attn_kind_override >= 0 || a.bias_tb < 0) return false;
     if (attn_block == 2) {
       const bool big_s0 = cfg.dim[s] == 128 && attn_nkf(a.wsz) == 7 && (int64_t)(sh[s] / a.wsz) * (sw[s] / a.wsz) >= 2048;
-      const bool small_map = (int64_t)sh[s] * sw[s] <= 8192;   // launch-bound maps (1-degree model): one launch instead of three
+      const bool small_map = (int64_t)sh[s] * sw[s] <= 32768;   // launch-bound maps (1-degree model): one launch instead of three
       if (!big_s0 && !small_map) return false;
     }
     return a.wsz > 1 && attn_block_supported(cfg.dim[s], a.wsz) && (a.kind == 0 || a.kind == 1) && a.qkv.cin == cfg.dim[s] && a.out.cin == cfg.dim[s];

@@ -127,7 +127,7 @@ def test_persistent_gemm_forced_on_small_maps(name):
 @pytest.mark.parametrize("name", ["T1", "T5", "C1", "RT"])
 def test_attention_block_kernel_opt_in(name):
     """`attn_block_kernel` (wx_attn_block.h: LayerNorm + to_qkv + window attention + to_out + residual in one launch, q|k|v never in
-    memory) runs by default only where it measured faster (stage 0 of the 0.25-degree model and launch-bound maps of <= 8192 tokens,
+    memory) runs by default only where it measured faster (stage 0 of the 0.25-degree model and launch-bound maps of <= 32768 tokens,
     WX_ATTN_BLOCK=2); WX_ATTN_BLOCK=1 forces it wherever it exists, =0 turns it off.  Its parity is pinned here on every window shape the small configs offer: T1 / T5 5 x 5 windows, short and long (dilated), C = 128
     and 256; C1 3 x 3 short and 4 x 4 long at C = 128 / 256; RT 4 x 4 at C = 128 / 256 -- per block against the CPU oracle (bf16 gate)
     and against the engine with it off; the profile proves which path ran.  (C3's 10 x 10 windows: test_attention_block_full_size.)"""
