@@ -46,6 +46,7 @@ struct AttnBlockParams {
   const float* tb;      // position-bias generating table [(2 wsz - 1)^2], x log2 e
   int H, W, wsz, kind;  // kind 0 short, 1 long (dilated)
   unsigned long long* trace = nullptr;   // tools/attn_block_probe only (WX_ATTN_TRACE builds): [workgroups * waves][8] phase ticks
+  float2* stat_out = nullptr;           // [H*W][C / 32] LayerNorm partials (sum, sum sq) of the sub-block's output rows, or nullptr
   int dbg = 0;                           // probe ablations: 1 skip the attention loop, 2 skip the projections, 4 skip the out-projection
 };
 
@@ -505,6 +506,19 @@ __global__ __launch_bounds__(2 * C, C == 256 ? 1 : 2) void attn_block_kernel(con
           char* xrow = xg + __umul24((unsigned)tokpix[tb], row_bytes) + (n0 + g * 4) * 2;
           *reinterpret_cast<uint2*>(xrow) = y0;
           *reinterpret_cast<uint2*>(xrow + 32) = y1;
+          if (p.stat_out) {   // LayerNorm partials of the ROUNDED outputs for the next sub-block: one (sum, sum sq) per pixel and 32-channel slot
+            float s1 = 0.f, s2 = 0.f;
+            const uint32_t yw[4] = {y0.x, y0.y, y1.x, y1.y};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float a = bf(yw[e], 0), b = bf(yw[e], 1);
+              s1 += a + b;
+              s2 += a * a + b * b;
+            }
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (g == 0) p.stat_out[(size_t)tokpix[tb] * HEADS + wave] = make_float2(s1, s2);
+          }
         }
       }
     }

@@ -1141,7 +1141,7 @@ class Engine : public EngineBase {
     if (gemm_par) {   // the four parity convs of a ConvTranspose k4 s2 p1 (out_mode 2): one launch when the fast path takes it
       const ConvW* gp = gemm_par;
       gemm_par = nullptr;
-      if (merge_parity && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr) && !dbg_flags && w.n <= 64) {
+      if (merge_parity && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr) && !dbg_flags && w.n <= 128) {
         p.n_par = 4;
         for (int q = 0; q < 4; ++q) p.wt_par[q] = wt_dev + gp[q].wt;
         const double fl4 = 4.0 * 2.0 * m * w.n * w.kh * w.kw * w.cin_true;
@@ -1280,8 +1280,9 @@ class Engine : public EngineBase {
         bp.wout = reinterpret_cast<const bf16_t*>(wt_dev + a.out.wt); bp.bo = f_dev + a.out.bias;
         bp.tb = f_dev + a.bias_tb; bp.H = h; bp.W = w; bp.wsz = a.wsz; bp.kind = a.kind;
         const double n = (double)a.wsz * a.wsz;
+        bp.stat_out = fuse_ln && !dbg_flags ? statpart : nullptr;
         timed("attn_block", 8.0 * m * c * c + 4.0 * m * n * c, 2.0 * m * c * sizeof(T), [&] { launch_attn_block(c, bp, cur_stream); });
-        stat_tiles_ready = 0;
+        stat_tiles_ready = bp.stat_out ? c / 32 : 0;
         capture(dbg_name, x, h, w, c, ld, w);
         return;
       }

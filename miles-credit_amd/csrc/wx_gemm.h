@@ -1012,7 +1012,7 @@ inline void launch_conv_gemm(const ConvGemmParams& p, const void* zero_page, hip
     }
     if (gemm_cfg == 1 && row_bytes % 128 == 0) kb64 = false;
     if (gemm_cfg == 2) kb64 = true;
-    if (p.n >= 96 && gemm_cfg != 3) {
+    if ((p.n >= 96 || (p.n_par == 4 && p.n > 64)) && gemm_cfg != 3) {   // merged parity convs need ONE N-tile per parity: 65..128 channels take BN = 128
       if (kb64) launch_conv_gemm_dma<T, 128, 64>(p, zero_page, stream);
       else launch_conv_gemm_dma<T, 128, 128>(p, zero_page, stream);
     } else {
