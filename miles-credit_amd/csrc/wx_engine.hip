@@ -813,6 +813,10 @@ class Engine : public EngineBase {
   bool merge_parity = !getenv("WX_NO_MERGE_PARITY");
   const ConvW* gemm_par = nullptr;   // set around a gemm() call: the four parity weight sets of a ConvTranspose k4
   bool split_k = !getenv("WX_NO_SPLIT_K");
+  int skinny_max = getenv("WX_SKINNY_MAX") ? atoi(getenv("WX_SKINNY_MAX")) : 8;          // K ranges per tile (0 / 1: off)
+  int skinny_steps = getenv("WX_SKINNY_STEPS") ? std::max(1, atoi(getenv("WX_SKINNY_STEPS"))) : 2;   // 128-byte K steps per range, at least
+  int skinny_min_nk = getenv("WX_SKINNY_MIN_NK") ? atoi(getenv("WX_SKINNY_MIN_NK")) : 16;
+  int skinny_tiles = getenv("WX_SKINNY_TILES") ? atoi(getenv("WX_SKINNY_TILES")) : 32;
   float* splitk_buf = nullptr;
   size_t splitk_bytes = 0;
   bool embed_split = !getenv("WX_NO_EMBED_SPLIT");
@@ -1224,8 +1228,23 @@ class Engine : public EngineBase {
         p.k_splits = S;
       }
     }
+    // ... and for the deep-K 1 x 1 layers of the transformer blocks on maps of a few hundred pixels (1-degree grid, stages 2 - 3:
+    // 4 - 12 tiles, each walking 16 - 32 K steps alone on its CU at 0.57 us per step): K ranges of >= skinny_steps steps over up to
+    // skinny_max workgroups per tile; the finish kernel applies the whole epilogue (LayerNorm fold, GELU, residual, LN partials)
+    if (split_k && skinny_max >= 2 && use_dma && !p.partial && out_mode == 0 && !p.gn_out && w.kh == 1 && w.kw == 1 && stride == 1 &&
+        w.n % 64 == 0 && (w.cin * (int)sizeof(T)) % 128 == 0 && conv_gemm_is_dma<T>(p, zero_page) && !dbg_flags) {
+      const int64_t tiles = (int64_t)cdiv((int64_t)out_h * out_w, 128) * conv_gemm_n_tiles(w.n);
+      const int nk = w.cin * (int)sizeof(T) / 128;
+      const int S = std::min(skinny_max, nk / skinny_steps);
+      if (tiles <= skinny_tiles && nk >= skinny_min_nk && S >= 2) {
+        const size_t need = (size_t)S * out_h * out_w * w.n * sizeof(float);
+        if (need > splitk_bytes) { splitk_buf = (float*)dalloc(need); splitk_bytes = need; }
+        p.partial = splitk_buf;
+        p.k_splits = S;
+      }
+    }
     timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream, gemm_cfg); });
-    last_stat_slots = conv_gemm_n_tiles(w.n);
+    last_stat_slots = p.partial ? conv_gemm_finish_slots(w.n) : conv_gemm_n_tiles(w.n);
     return made_stats;
   }
   void upsample2x(const T* in, int h, int w, int64_t in_ld, int c) {

@@ -640,7 +640,12 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
     }
     // step ks+1 must have landed; with 3 stages step ks+2 (just issued) may stay in flight
     WX_TICK(tk1);
-    if (NST == 3 && ks + 2 < ks_hi) dma_wait_allow<PER_STEP>(); else dma_wait_all();
+    {
+      const int ahead = ks_hi - ks - 2;   // steps beyond ks+1 that are already issued (at most NST - 2 of them)
+      if (NST >= 4 && ahead >= 2) dma_wait_allow<2 * PER_STEP>();
+      else if (NST >= 3 && ahead >= 1) dma_wait_allow<PER_STEP>();
+      else dma_wait_all();
+    }
     WX_TICK(tk2);
     __syncthreads();  // ... for every wave, and everyone is done reading `cur`
     WX_TICK(tk3);
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
     cur_i = (cur_i + 1 == NST) ? 0 : cur_i + 1;
     nxt_i = (nxt_i + 1 == NST) ? 0 : nxt_i + 1;
   }
-  if (NST == 3) { dma_wait_all(); __syncthreads(); }  // nothing of the ring is in flight when the tile is reused
+  if (NST >= 3) { dma_wait_all(); __syncthreads(); }  // nothing of the ring is in flight when the tile is reused
 
   trace_stamp(p, 2);
 #ifdef WX_GEMM_TRACE
@@ -892,20 +897,54 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   }
 }
 
-// split-K finish: out[m][n] = T(sum_y partial[y][m][n] + bias[n]); fixed order, 4 channels per thread
+// split-K finish: out[m][n] = T(epilogue(sum_y partial[y][m][n])), the sum in fixed order.  One wave per output row and 256-channel chunk
+// (4 channels per lane); the epilogue is the main kernel's: LayerNorm fold (rstd * (sum - mean * colsum) + bias), GELU, residual, and --
+// for the next LayerNorm -- the row's (sum, sum sq) of the ROUNDED outputs, one partial per chunk: stat_out[m][cdiv(n, 256)].
+inline int conv_gemm_finish_slots(int n) { return cdiv(n, 256); }
 template <typename T>
 __global__ __launch_bounds__(256) void conv_gemm_finish_kernel(const ConvGemmParams p) {
-  const int M = p.out_h * p.out_w, nq = p.n / 4;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)M * nq) return;
-  const int m = (int)(idx / nq), n = (int)(idx - (int64_t)m * nq) * 4;
-  float4 acc = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int y = 0; y < p.k_splits; ++y) {
-    const float4 v = *reinterpret_cast<const float4*>(p.partial + ((int64_t)y * M + m) * p.n + n);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  const int M = p.out_h * p.out_w, chunks = (p.n + 255) / 256;
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // wave-uniform
+  if (unit >= (int64_t)M * chunks) return;
+  const int m = (int)(unit / chunks), c = (int)(unit - (int64_t)m * chunks), n = c * 256 + lane * 4;
+  float s1 = 0.f, s2 = 0.f;
+  if (n < p.n) {
+    const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc = p.rowstat ? make_float4(0.f, 0.f, 0.f, 0.f) : b4;
+    for (int y = 0; y < p.k_splits; ++y) {
+      const float4 v = *reinterpret_cast<const float4*>(p.partial + ((int64_t)y * M + m) * p.n + n);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float v[4] = {acc.x, acc.y, acc.z, acc.w};
+    if (p.rowstat) {
+      const float2 st = row_stats(p, m);
+      const float4 cs = *reinterpret_cast<const float4*>(p.colsum + n);
+      v[0] = st.y * (v[0] - st.x * cs.x) + b4.x;
+      v[1] = st.y * (v[1] - st.x * cs.y) + b4.y;
+      v[2] = st.y * (v[2] - st.x * cs.z) + b4.z;
+      v[3] = st.y * (v[3] - st.x * cs.w) + b4.w;
+    }
+    if (p.act == 1) gelu4<T>(v);
+    if (p.res) {
+      float r[4];
+      load4<T>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.res_ld + n, r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    store4<T>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.out_ld + n, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float f = Elem<T>::to_f(Elem<T>::from_f(v[e]));
+      s1 += f;
+      s2 += f * f;
+    }
   }
-  float v[4] = {acc.x, acc.y, acc.z, acc.w};
-  store4<T>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.out_ld + n, v);
+  if (p.stat_out) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) p.stat_out[(int64_t)m * chunks + c] = make_float2(s1, s2);
+  }
 }
 
 template <typename T, int BM, int BN, int KB, bool ONE, int NST, bool TAPIN = false>
@@ -924,8 +963,8 @@ inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_pag
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, p.partial ? p.k_splits : 1), dim3(BM * 2), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
   WX_HIP(hipGetLastError());
   if (p.partial) {
-    const int64_t work = (int64_t)M * (p.n / 4);
-    hipLaunchKernelGGL(conv_gemm_finish_kernel<T>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, stream, p);
+    const int64_t waves = (int64_t)M * conv_gemm_finish_slots(p.n);
+    hipLaunchKernelGGL(conv_gemm_finish_kernel<T>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, stream, p);
     WX_HIP(hipGetLastError());
   }
 }
@@ -963,6 +1002,11 @@ inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page,
   const bool one = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_y == 0 && p.pad_x == 0 && p.in_h == p.out_h &&
                    p.in_w == p.out_w;
   const bool three = KB == 64 && (p.dbg & 128);  // experiment switch: 3-stage ring, 3 workgroups/CU
+  // launches of at most one workgroup per two CUs (the 1-degree grid's deep stages: 4 - 48 tiles) are bound by the latency of ONE
+  // stage in flight per CU (0.75 us per 128-byte K step measured); a 4-stage ring keeps three in flight -- LDS is free there
+  static const int deep_max = getenv("WX_GEMM_DEEP_TILES") ? atoi(getenv("WX_GEMM_DEEP_TILES")) : 128;
+  const bool deep = KB == 128 && !three && !(p.dbg & 512) &&
+                    (int64_t)cdiv(p.out_h * p.out_w, 128) * (p.n_par == 4 ? 4 : cdiv(p.n, BN)) * (p.partial ? p.k_splits : 1) <= deep_max;
   if (one) {
     if constexpr (KB == 64 && BN == 128 && sizeof(T) == 2) {
       if ((p.dbg & 512) && !p.gn_out) {  // experiment switch: 256-row tiles
@@ -971,11 +1015,14 @@ inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page,
       }
     }
     if (three) launch_conv_gemm_dma_v<T, 128, BN, KB, true, (KB == 64 ? 3 : 2)>(p, zero_page, stream);
+    else if (deep) launch_conv_gemm_dma_v<T, 128, BN, KB, true, (KB == 128 ? 4 : 2)>(p, zero_page, stream);
     else launch_conv_gemm_dma_v<T, 128, BN, KB, true, 2>(p, zero_page, stream);
   } else if (p.cin * (int)sizeof(T) / KB >= 8) {
-    launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2, true>(p, zero_page, stream);
+    if (deep) launch_conv_gemm_dma_v<T, 128, BN, KB, false, (KB == 128 ? 4 : 2), true>(p, zero_page, stream);
+    else launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2, true>(p, zero_page, stream);
   } else {
-    launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2, false>(p, zero_page, stream);
+    if (deep) launch_conv_gemm_dma_v<T, 128, BN, KB, false, (KB == 128 ? 4 : 2), false>(p, zero_page, stream);
+    else launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2, false>(p, zero_page, stream);
   }
 }
 
