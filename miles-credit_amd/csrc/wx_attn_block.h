@@ -532,10 +532,11 @@ __global__ __launch_bounds__(2 * C, C == 256 ? 1 : 2) void attn_block_kernel(con
 #endif
 }
 
-inline bool attn_block_supported(int c, int wsz) {
+// 2 x 2 windows (4 real tokens in a 16-token fragment) only where the launch count matters more than the padding (`tiny`: launch-bound maps)
+inline bool attn_block_supported(int c, int wsz, bool tiny = false) {
   if (c != 32 && c != 64 && c != 128 && c != 256) return false;
   const int nkf = attn_nkf_tokens(wsz * wsz);
-  return wsz >= 3 && (nkf == 1 || nkf == 2 || nkf == 4 || nkf == 7 || nkf == 8);
+  return wsz >= (tiny ? 2 : 3) && (nkf == 1 || nkf == 2 || nkf == 4 || nkf == 7 || nkf == 8);
 }
 
 template <int C, int NKF>
@@ -556,7 +557,7 @@ inline void launch_attn_block_v(const AttnBlockParams& p, hipStream_t stream) {
 inline void launch_attn_block(int c, const AttnBlockParams& p, hipStream_t stream) {
   if ((int64_t)p.H * p.W >= (1 << 24) || p.ld * 2 >= (1 << 24) || (int64_t)p.H * p.W * p.ld * 2 >= (int64_t(1) << 32))
     throw std::runtime_error("attention block: map too large for 24-bit pixel / 32-bit byte addressing");
-  if (!attn_block_supported(c, p.wsz) || (p.kind != 0 && p.kind != 1)) throw std::runtime_error("attention block: unsupported shape");
+  if (!attn_block_supported(c, p.wsz, true) || (p.kind != 0 && p.kind != 1)) throw std::runtime_error("attention block: unsupported shape");
   const int nkf = attn_nkf_tokens(p.wsz * p.wsz);
 #define WX_AB(CC, NN) launch_attn_block_v<CC, NN>(p, stream)
   if (c == 32) { switch (nkf) { case 1: WX_AB(32, 1); break; case 2: WX_AB(32, 2); break; case 4: WX_AB(32, 4); break; case 7: WX_AB(32, 7); break; default: WX_AB(32, 8); } }

@@ -60,7 +60,10 @@ struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1, bias_tb = -1; int w
 struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1, pack_pp = -1; const AttnL* next = nullptr; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset; pack_pre: the same preceded by the attention's Wout blocks
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
 struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmbed branch (wx_embed.h)
-struct StageL { std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks; };
+struct StageL {
+  std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks;
+  ConvW merged;   // launch-bound maps: every CrossEmbed branch zero-padded into the largest kernel's window, one convolution of all output channels
+};
 struct UpL { ConvW convt, convps, sharp, upc, c1, c2; int64_t g1 = -1, b1 = -1, g2 = -1, b2 = -1; int cin = 0, cout = 0; };
 
 
@@ -490,6 +493,37 @@ class Engine : public EngineBase {
     if (has_bias || ln_b) cw.bias = push_f(bias);
     return cw;
   }
+  // All branches of one CrossEmbed (crossformer.py:128-152: kernel k, stride s, padding (k - s) / 2 -- every branch is centred on the same
+  // window) as ONE convolution with the largest kernel: branch b's taps sit at offset (kmax - k_b) / 2 inside it, zeros around them
+  // (exact: the added products are 0 * x).  Output channels in the reference's concatenation order.
+  ConvW make_embed_merged(int s, const std::vector<int>& ks, const std::vector<int>& cos, int cin, int cpad) {
+    const int kmax = ks.back();
+    int n = 0;
+    for (int co : cos) n += co;
+    const int64_t k = (int64_t)kmax * kmax * cpad;
+    std::vector<double> rows((size_t)n * k, 0.0);
+    std::vector<float> bias(n, 0.f);
+    int o0 = 0;
+    for (size_t b = 0; b < ks.size(); ++b) {
+      const std::string bp = embed_key(s, (int)b);
+      const std::vector<double> w = folded(bp, false);
+      const HostTensor& bt = need(bp + ".bias");
+      const int kb = ks[b], d = (kmax - kb) / 2;
+      for (int o = 0; o < cos[b]; ++o) {
+        for (int c = 0; c < cin; ++c)
+          for (int y = 0; y < kb; ++y)
+            for (int x = 0; x < kb; ++x)
+              rows[(size_t)(o0 + o) * k + ((int64_t)(y + d) * kmax + (x + d)) * cpad + c] = w[(((int64_t)o * cin + c) * kb + y) * kb + x];
+        bias[o0 + o] = bt.data[o];
+      }
+      o0 += cos[b];
+    }
+    ConvW cw;
+    cw.n = n; cw.cin = cpad; cw.cin_true = cin; cw.kh = kmax; cw.kw = kmax;
+    cw.wt = push_w(rows, n, k);
+    cw.bias = push_f(bias);
+    return cw;
+  }
   // Stage-0 branch for embed_patch_kernel: [chunk][ky][kx/4][n-frag][tap g][out 16][CC channels]
   PatchW make_patch(const std::string& p, int n, int cin, int cpad, int k) {
     const std::vector<double> w = folded(p, false);
@@ -702,15 +736,22 @@ class Engine : public EngineBase {
       const int cin = dims[s], cout = dims[s + 1];
       const int cpad = s == 0 ? cpad0 : cin;
       int acc = 0;
+      std::vector<int> cos;
       for (size_t b = 0; b < ks.size(); ++b) {
         const int co = (b + 1 < ks.size()) ? (int)(cout / (1 << (b + 1))) : cout - acc;
         acc += co;
+        cos.push_back(co);
         const std::string bp = embed_key(s, (int)b);
         const bool patch_ok = s == 0 && cfg.embed_strides[0] == 2 && co % 4 == 0 && ks.back() == 32 &&
                               ((ks[b] == 32 && co <= 16) || (ks[b] == 16 && co <= 16) || (ks[b] == 8 && co <= 32));
         st.patch.push_back(patch_ok ? make_patch(bp, co, cin, cpad, ks[b]) : PatchW());
         st.embed.push_back(make_conv(bp, 0, co, cin, cpad, ks[b], ks[b], true, nullptr, nullptr));
         st.embed_k.push_back(ks[b]);
+      }
+      {   // one launch for the whole CrossEmbed where launches, not FLOPs, are the cost (stages 1-3 of the 1-degree grid)
+        bool same_parity = ks.size() >= 2 && embed_merge && s >= 1;
+        for (int kk : ks) same_parity = same_parity && ((ks.back() - kk) % 2 == 0) && kk >= cfg.embed_strides[s];
+        if (same_parity && small_map_tokens(s) && sh[s] > 0) st.merged = make_embed_merged(s, ks, cos, cin, cpad);
       }
       for (int d = 0; d < cfg.depth[s]; ++d) {
         const std::string p = "layers." + std::to_string(s) + ".1.layers." + std::to_string(d);
@@ -813,6 +854,7 @@ class Engine : public EngineBase {
   bool merge_parity = !getenv("WX_NO_MERGE_PARITY");
   const ConvW* gemm_par = nullptr;   // set around a gemm() call: the four parity weight sets of a ConvTranspose k4
   bool split_k = !getenv("WX_NO_SPLIT_K");
+  bool embed_merge = !getenv("WX_NO_EMBED_MERGE");
   int skinny_max = getenv("WX_SKINNY_MAX") ? atoi(getenv("WX_SKINNY_MAX")) : 8;          // K ranges per tile (0 / 1: off)
   int skinny_steps = getenv("WX_SKINNY_STEPS") ? std::max(1, atoi(getenv("WX_SKINNY_STEPS"))) : 2;   // 128-byte K steps per range, at least
   int skinny_min_nk = getenv("WX_SKINNY_MIN_NK") ? atoi(getenv("WX_SKINNY_MIN_NK")) : 16;
@@ -1215,7 +1257,7 @@ class Engine : public EngineBase {
     if (blk_hidden) throw StateError("k-blocked hidden tensor requested but the GEMM fell back to the row-major kernel");
     // split-K for plain deep-K launches that cannot fill the chip (stage-3 CrossEmbed k = 4: 160 tiles walking K = 8192; every
     // CrossEmbed GEMM of the 1-degree grid): 128 x 128 tiles x S K-ranges, fp32 partial sums, fixed-order finish kernel
-    if (split_k && use_dma && !rs && !res && act == 0 && out_mode == 0 && !p.stat_out && !p.gn_out && w.n % 128 == 0 &&
+    if (split_k && use_dma && !rs && !res && act == 0 && out_mode == 0 && !p.gn_out && w.n % 128 == 0 &&
         (w.cin * (int)sizeof(T)) % 128 == 0 && conv_gemm_is_dma<T>(p, zero_page)) {
       const int64_t tiles = (int64_t)cdiv((int64_t)out_h * out_w, 128) * (w.n / 128);
       const int nk = w.kh * w.kw * (w.cin * (int)sizeof(T) / 128);
@@ -1277,14 +1319,16 @@ class Engine : public EngineBase {
   // qkv_ready: the previous fused feed-forward kernel already wrote this attention's q|k|v into `scratch`
   // the whole attention sub-block in one launch?  (bf16 engine, C = 128 / 256, unsharded maps; q|k|v and the attention output never
   // exist in memory on this path: a debug run captures the sub-block's output only)
+  bool small_map_tokens(int s) const { return (int64_t)sh[s] * sw[s] <= 32768; }
   bool attn_block_ok(const AttnL& a, int s) const {
     if (sizeof(T) != 2 || !attn_block || band_on || attn_kind_override >= 0 || a.bias_tb < 0) return false;
     if (attn_block == 2) {
       const bool big_s0 = cfg.dim[s] == 128 && attn_nkf(a.wsz) == 7 && (int64_t)(sh[s] / a.wsz) * (sw[s] / a.wsz) >= 2048;
-      const bool small_map = (int64_t)sh[s] * sw[s] <= 32768;   // launch-bound maps (1-degree model): one launch instead of three
+      const bool small_map = small_map_tokens(s);   // launch-bound maps (1-degree model): one launch instead of three
       if (!big_s0 && !small_map) return false;
     }
-    return a.wsz > 1 && attn_block_supported(cfg.dim[s], a.wsz) && (a.kind == 0 || a.kind == 1) && a.qkv.cin == cfg.dim[s] && a.out.cin == cfg.dim[s];
+    return a.wsz > 1 && attn_block_supported(cfg.dim[s], a.wsz) &&   // (2 x 2 windows lose even on launch-bound maps: 37 us against 26 for the three launches)
+           (a.kind == 0 || a.kind == 1) && a.qkv.cin == cfg.dim[s] && a.out.cin == cfg.dim[s];
   }
   void attention(const AttnL& a, int s, const std::string& dbg_name, bool defer_out = false, bool qkv_ready = false) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
@@ -1332,7 +1376,10 @@ class Engine : public EngineBase {
   bool ff_big_enough() const {
     if (cur_stage < 0 || cur_stage > 3) return true;
     const int64_t m = (int64_t)sh[cur_stage] * sw[cur_stage];
-    return cdiv(m, cfg.dim[cur_stage] == 128 ? 128 : 64) >= ff_min_wgs;
+    // C = 128 on a launch-bound map (1-degree grid stage 1: 45 workgroups): one launch instead of two wins from 40 workgroups on
+    // (724 -> 729 steps/s); C = 256 at 23 workgroups loses (710)
+    if (cfg.dim[cur_stage] == 128) return cdiv(m, 128) >= std::min(ff_min_wgs, 40);
+    return cdiv(m, 64) >= ff_min_wgs;
   }
   bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on && ff_big_enough(); }
   bool ff_takes_out(const FFL& f, const AttnL& a) const { return ff_takes_out(f) && !attn_block_ok(a, cur_stage); }
@@ -1392,18 +1439,29 @@ class Engine : public EngineBase {
   }
   // gn_acc over m_count pixels (the whole map) -> per-channel affine; applied to the m rows at x
   void gn_finalize_apply(const T* x, int c, int64_t m, int64_t m_count, int64_t g_off, int64_t b_off, const T* res, int64_t res_ld, T* out,
-                         int64_t out_ld) {
+                         int64_t out_ld, int fold_tiles = 0) {
     constexpr int VEC = 16 / (int)sizeof(T);
     const int64_t total = m * (c / VEC);
-    const int ablocks = (int)std::min<int64_t>(2048, (total + 255) / 256);   // one resident round: every workgroup derives the affine once
+    int ablocks = (int)std::min<int64_t>(2048, (total + 255) / 256);   // one resident round: every workgroup derives the affine once
+    if (fold_tiles > 0) ablocks = std::min(ablocks, 256);              // ... and, folding the partials itself, reads tiles x C x 8 bytes first
+    const size_t lds = 2 * c * sizeof(float) + (fold_tiles > 0 ? 2 * c * sizeof(double) : 0);
     timed("gn_apply", 0.0, (double)m * c * sizeof(T) * (res ? 3.0 : 2.0), [&] {
-      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(ablocks), dim3(256), 2 * c * sizeof(float), cur_stream, x, (int64_t)c, c, m, gn_acc, f_dev + g_off,
-                         f_dev + b_off, cfg.dim[0], (double)m_count, 1e-5f, res, res_ld, out, out_ld);
+      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(ablocks), dim3(256), lds, cur_stream, x, (int64_t)c, c, m, gn_acc, f_dev + g_off,
+                         f_dev + b_off, cfg.dim[0], (double)m_count, 1e-5f, res, res_ld, out, out_ld, fold_tiles > 0 ? gnpart : nullptr, fold_tiles);
       WX_HIP(hipGetLastError());
     });
   }
+  int gn_fold_max_tiles = getenv("WX_GN_FOLD_TILES") ? atoi(getenv("WX_GN_FOLD_TILES")) : 16;   // 12 tiles: 13 -> 9 us; 45 tiles: 13 -> 17 us (the serial fold in every workgroup)
   void group_norm_silu(const T* x, int c, int64_t m, int64_t g_off, int64_t b_off, const T* res, int64_t res_ld, T* out,
                        int64_t out_ld, bool have_partials) {
+    if (have_partials) {   // few tiles: the apply kernel folds the partials itself (one launch instead of two)
+      const int tiles = gn_tile_off > 0 ? gn_tile_off : (int)cdiv(m, 128);
+      if (tiles <= gn_fold_max_tiles) {
+        gn_tile_off = 0;
+        gn_finalize_apply(x, c, m, m, g_off, b_off, res, res_ld, out, out_ld, tiles);
+        return;
+      }
+    }
     gn_local_stats(x, c, m, have_partials);
     gn_finalize_apply(x, c, m, m, g_off, b_off, res, res_ld, out, out_ld);
   }
@@ -1434,6 +1492,14 @@ class Engine : public EngineBase {
     const int64_t ld = stream_ld(s);
     if (sh[s] <= 0) return;
     int choff = 0;
+    if (s >= 1 && st.merged.wt >= 0 && embed_merge && !band_on) {
+      const int k = st.embed_k.back(), stv = cfg.embed_strides[s], pd = (k - stv) / 2;
+      // ... which also leaves the LayerNorm partials of its rows for the stage's first sub-block
+      const bool made = gemm("gemm_embed", st.merged, in, in_h, sw[s - 1], in_ld_s, stv, pd + in_row0, pd, sh[s], sw[s], x, ld, nullptr, 0, nullptr, 0,
+                             0, 0, 0, 0, true);
+      stat_tiles_ready = made ? last_stat_slots : 0;
+      return;
+    }
     for (size_t b = 0; b < st.embed.size(); ++b) {
       const int k = st.embed_k[b], stv = cfg.embed_strides[s], pd = (k - stv) / 2;
       if (s == 0 && st.patch[b].wt >= 0 && use_patch && st.embed_k.back() == 32 && st.patch.back().wt >= 0) {
