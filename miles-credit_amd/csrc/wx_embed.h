@@ -36,15 +36,16 @@ struct EmbedPatchParams {
   const void* wt32;    // [chunks][32][8][64 lanes] x 16 B
   const void* wt16;    // [chunks][16][4][64 lanes] x 16 B   (or nullptr: branch not fused)
   const void* wt8;     // [chunks][8][2][2 frags][64 lanes] x 16 B   (or nullptr)
-  const float* bias32; // [16] (zero padded)
-  const float* bias16; // [16]
-  const float* bias8;  // [32]
-  void* out32;         // stage-0 stream, already offset to each branch's first channel
-  void* out16;
-  void* out8;
+  // The accumulators of one pixel form a 64-wide row [k32: 16 | k16: 16 | k8: 32] of sixteen 4-channel slots.  slot_tab[q] (a float
+  // holding an integer) is the stream channel slot q is stored to, or -1; bias64[64] the bias per accumulator row.  Slots a branch
+  // does not fill may carry channels of the k = 4 branch, whose taps sit zero-padded in the middle of that branch's window
+  // (engine: make_patch `extra` rows) -- on the 1-degree model (8 + 8 + 16 spare rows = the 32 channels of k = 4) the separate
+  // k = 4 convolution launch (48 us) disappears.
+  const float* slot_tab;   // [16]
+  const float* bias64;     // [64]
+  void* out_row;           // stage-0 stream, channel 0
   int64_t out_ld;
   int out_h, out_w;
-  int n32, n16, n8;    // real channels per branch (multiples of 4; <= 16, 16, 32)
   int dbg;
   int row0;            // first output row of this launch (the launcher may split the map into two launches)
   // chunk split (small maps, launch_embed_patch): blockIdx.y takes the channel chunks [y * chunk_per, (y + 1) * chunk_per) and
@@ -292,37 +293,26 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
     }
     return;
   }
-  // ---- epilogue: + bias, 4 consecutive channels per lane ---------------------------------------------
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 b32 = *reinterpret_cast<const float4*>(p.bias32 + g * 4);
-  const float4 b16 = f16 ? *reinterpret_cast<const float4*>(p.bias16 + g * 4) : z4;
-  const float4 b8a = f8 ? *reinterpret_cast<const float4*>(p.bias8 + g * 4) : z4;
-  const float4 b8b = f8 ? *reinterpret_cast<const float4*>(p.bias8 + 16 + g * 4) : z4;
-  T* __restrict__ o32 = reinterpret_cast<T*>(p.out32);
-  T* __restrict__ o16 = reinterpret_cast<T*>(p.out16);
-  T* __restrict__ o8 = reinterpret_cast<T*>(p.out8);
+  // ---- epilogue: + bias, 4 consecutive channels per lane, each 4-channel slot to the stream channel the table names ----------------------
+  T* __restrict__ orow = reinterpret_cast<T*>(p.out_row);
+  int sc[4];
+  float4 bq[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    sc[a] = (int)p.slot_tab[a * 4 + g];
+    bq[a] = *reinterpret_cast<const float4*>(p.bias64 + a * 16 + g * 4);
+  }
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     const int oy = oy0 + RPW * wave + (f >> 1), ox = ox0 + (f & 1) * 16 + li;
     if (oy >= p.out_h || ox >= p.out_w) continue;
     const int64_t pix = ((int64_t)oy * p.out_w + ox) * p.out_ld;
-    if (g * 4 < p.n32) {
-      float v[4] = {a32[f][0] + b32.x, a32[f][1] + b32.y, a32[f][2] + b32.z, a32[f][3] + b32.w};
-      store4<T>(o32 + pix + g * 4, v);
-    }
-    if (f16 && g * 4 < p.n16) {
-      float v[4] = {a16[f][0] + b16.x, a16[f][1] + b16.y, a16[f][2] + b16.z, a16[f][3] + b16.w};
-      store4<T>(o16 + pix + g * 4, v);
-    }
-    if (f8) {
-      if (g * 4 < p.n8) {
-        float v[4] = {a8[0][f][0] + b8a.x, a8[0][f][1] + b8a.y, a8[0][f][2] + b8a.z, a8[0][f][3] + b8a.w};
-        store4<T>(o8 + pix + g * 4, v);
-      }
-      if (16 + g * 4 < p.n8) {
-        float v[4] = {a8[1][f][0] + b8b.x, a8[1][f][1] + b8b.y, a8[1][f][2] + b8b.z, a8[1][f][3] + b8b.w};
-        store4<T>(o8 + pix + 16 + g * 4, v);
-      }
+    const f32x4_t av[4] = {a32[f], a16[f], a8[0][f], a8[1][f]};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (sc[a] < 0) continue;
+      float v[4] = {av[a][0] + bq[a].x, av[a][1] + bq[a].y, av[a][2] + bq[a].z, av[a][3] + bq[a].w};
+      store4<T>(orow + pix + sc[a], v);
     }
   }
 }
@@ -340,14 +330,11 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const EmbedPatchParam
     const float4 v = *reinterpret_cast<const float4*>(p.partial + ((int64_t)y * npix + pix) * 64 + q);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
-  const int grp = q >> 4, c = q & 15;    // grp 0: k32, 1: k16, 2 / 3: k8 channels 0..15 / 16..31
-  const float* bias = grp == 0 ? p.bias32 : grp == 1 ? p.bias16 : p.bias8;
-  void* outp = grp == 0 ? p.out32 : grp == 1 ? p.out16 : p.out8;
-  const int n = grp == 0 ? p.n32 : grp == 1 ? p.n16 : p.n8;
-  const int cc = grp == 3 ? 16 + c : c;
-  if (!bias || !outp || cc >= n) return;
-  float v[4] = {acc.x + bias[cc], acc.y + bias[cc + 1], acc.z + bias[cc + 2], acc.w + bias[cc + 3]};
-  store4<T>(reinterpret_cast<T*>(outp) + pix * p.out_ld + cc, v);
+  const int ch = (int)p.slot_tab[q >> 2];   // stream channel of this 4-channel slot, or -1
+  if (ch < 0) return;
+  const float4 b = *reinterpret_cast<const float4*>(p.bias64 + q);
+  float v[4] = {acc.x + b.x, acc.y + b.y, acc.z + b.z, acc.w + b.w};
+  store4<T>(reinterpret_cast<T*>(p.out_row) + pix * p.out_ld + ch, v);
 }
 
 template <typename T, int NW, int TH>

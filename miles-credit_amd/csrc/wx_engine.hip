@@ -62,6 +62,8 @@ struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
 struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmbed branch (wx_embed.h)
 struct StageL {
   std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks;
+  bool ride4 = false;                            // stage 0: the k = 4 branch rides in the LDS-patch kernel's spare accumulator rows
+  int64_t patch_tab = -1, patch_bias64 = -1;     // float-arena offsets of EmbedPatchParams::slot_tab / bias64
   ConvW merged;   // launch-bound maps: every CrossEmbed branch zero-padded into the largest kernel's window, one convolution of all output channels
 };
 struct UpL { ConvW convt, convps, sharp, upc, c1, c2; int64_t g1 = -1, b1 = -1, g2 = -1, b2 = -1; int cin = 0, cout = 0; };
@@ -525,29 +527,39 @@ class Engine : public EngineBase {
     return cw;
   }
   // Stage-0 branch for embed_patch_kernel: [chunk][ky][kx/4][n-frag][tap g][out 16][CC channels]
-  PatchW make_patch(const std::string& p, int n, int cin, int cpad, int k) {
+  // `extra`: channels [x0, x0 + xn) of the smaller kernel `xkey` (size xk) as accumulator rows n .. n + xn - 1, their taps zero-padded
+  // into the middle of this k x k window (same centre: crossformer.py:128-152 padding (k - stride) / 2) -- see EmbedPatchParams::slot_tab
+  PatchW make_patch(const std::string& p, int n, int cin, int cpad, int k, const std::string& xkey = "", int xk = 0, int x0 = 0, int xn = 0) {
     const std::vector<double> w = folded(p, false);
     constexpr int CC = 16 / (int)sizeof(T);
     const int chunks = cpad / CC, k4n = k / 4, nfr = (k == 8) ? 2 : 1;  // fragment counts the kernel is built for
     std::vector<double> rows((size_t)chunks * k * k4n * nfr * 64 * CC, 0.0);
+    auto at = [&](int ch, int ky, int kx, int o, int e) -> double& {
+      return rows[(((((size_t)ch * k + ky) * k4n + kx / 4) * nfr + o / 16) * 64 + (kx % 4) * 16 + (o % 16)) * CC + e];
+    };
     for (int ch = 0; ch < chunks; ++ch)
       for (int ky = 0; ky < k; ++ky)
-        for (int k4 = 0; k4 < k4n; ++k4)
-          for (int g = 0; g < 4; ++g)
-            for (int o = 0; o < n; ++o)
+        for (int kx = 0; kx < k; ++kx)
+          for (int o = 0; o < n; ++o)
+            for (int e = 0; e < CC; ++e) {
+              const int c = ch * CC + e;
+              if (c < cin) at(ch, ky, kx, o, e) = w[(((int64_t)o * cin + c) * k + ky) * k + kx];
+            }
+    if (xn > 0) {
+      const std::vector<double> wx = folded(xkey, false);
+      const int d = (k - xk) / 2;
+      for (int ch = 0; ch < chunks; ++ch)
+        for (int ky = 0; ky < xk; ++ky)
+          for (int kx = 0; kx < xk; ++kx)
+            for (int o = 0; o < xn; ++o)
               for (int e = 0; e < CC; ++e) {
                 const int c = ch * CC + e;
-                if (c >= cin) continue;
-                rows[(((((size_t)ch * k + ky) * k4n + k4) * nfr + o / 16) * 64 + g * 16 + (o % 16)) * CC + e] =
-                    w[(((int64_t)o * cin + c) * k + ky) * k + (k4 * 4 + g)];
+                if (c < cin) at(ch, ky + d, kx + d, n + o, e) = wx[(((int64_t)(x0 + o) * cin + c) * xk + ky) * xk + kx];
               }
+    }
     PatchW pw;
     pw.n = n;
     pw.wt = push_w(rows, 1, (int64_t)rows.size());
-    std::vector<float> bias(32, 0.f);
-    const HostTensor& b = need(p + ".bias");
-    for (int o = 0; o < n; ++o) bias[o] = b.data[o];
-    pw.bias = push_f(bias);
     return pw;
   }
   // ConvTranspose2d k2 s2: W[ci][co][dy][dx] -> rows n = (dy*2+dx)*cout + co, K = ci; bias expanded x4
@@ -741,12 +753,57 @@ class Engine : public EngineBase {
         const int co = (b + 1 < ks.size()) ? (int)(cout / (1 << (b + 1))) : cout - acc;
         acc += co;
         cos.push_back(co);
+      }
+      // stage 0 on the LDS-patch kernel (wx_embed.h): branches k = 32 / 16 / 8 in its accumulator row [16 | 16 | 32]; the k = 4 branch
+      // rides in the rows they leave empty when it fits (1-degree model: 8 + 8 + 16 spare rows = its 32 channels)
+      std::vector<bool> pok(ks.size(), false);
+      int cap[3] = {16, 16, 32}, used[3] = {0, 0, 0}, bidx[3] = {-1, -1, -1}, b4 = -1;
+      for (size_t b = 0; b < ks.size(); ++b) {
+        pok[b] = s == 0 && cfg.embed_strides[0] == 2 && cos[b] % 4 == 0 && ks.back() == 32 &&
+                 ((ks[b] == 32 && cos[b] <= 16) || (ks[b] == 16 && cos[b] <= 16) || (ks[b] == 8 && cos[b] <= 32));
+        if (pok[b]) { const int j = ks[b] == 32 ? 0 : ks[b] == 16 ? 1 : 2; used[j] = cos[b]; bidx[j] = (int)b; }
+        if (ks[b] == 4) b4 = (int)b;
+      }
+      int ride[3] = {0, 0, 0}, ride0[3] = {0, 0, 0};   // k = 4 channels [ride0, ride0 + ride) in the spare rows of branch j
+      if (s == 0 && embed_ride4 && b4 >= 0 && cos[b4] % 4 == 0 && bidx[0] >= 0 && bidx[1] >= 0 && bidx[2] >= 0 &&
+          (cap[0] - used[0]) + (cap[1] - used[1]) + (cap[2] - used[2]) >= cos[b4]) {
+        int left = cos[b4], at4 = 0;
+        for (int j = 0; j < 3; ++j) {
+          ride[j] = std::min(left, cap[j] - used[j]); ride0[j] = at4;
+          at4 += ride[j]; left -= ride[j];
+        }
+        st.ride4 = true;
+      }
+      std::vector<int> choffs;
+      { int o = 0; for (int co : cos) { choffs.push_back(o); o += co; } }
+      for (size_t b = 0; b < ks.size(); ++b) {
         const std::string bp = embed_key(s, (int)b);
-        const bool patch_ok = s == 0 && cfg.embed_strides[0] == 2 && co % 4 == 0 && ks.back() == 32 &&
-                              ((ks[b] == 32 && co <= 16) || (ks[b] == 16 && co <= 16) || (ks[b] == 8 && co <= 32));
-        st.patch.push_back(patch_ok ? make_patch(bp, co, cin, cpad, ks[b]) : PatchW());
-        st.embed.push_back(make_conv(bp, 0, co, cin, cpad, ks[b], ks[b], true, nullptr, nullptr));
+        const int j = ks[b] == 32 ? 0 : ks[b] == 16 ? 1 : 2;
+        if (pok[b] && st.ride4 && ride[j] > 0) st.patch.push_back(make_patch(bp, cos[b], cin, cpad, ks[b], embed_key(s, b4), 4, ride0[j], ride[j]));
+        else st.patch.push_back(pok[b] ? make_patch(bp, cos[b], cin, cpad, ks[b]) : PatchW());
+        st.embed.push_back(make_conv(bp, 0, cos[b], cin, cpad, ks[b], ks[b], true, nullptr, nullptr));
         st.embed_k.push_back(ks[b]);
+      }
+      if (s == 0 && bidx[0] >= 0) {   // slot table + bias row of the patch kernel's 64-wide accumulator row
+        std::vector<float> tab(16, -1.f), bias64(64, 0.f);
+        const int row0[3] = {0, 16, 32};
+        for (int j = 0; j < 3; ++j) {
+          if (bidx[j] < 0) continue;
+          const HostTensor& bt = need(embed_key(s, bidx[j]) + ".bias");
+          for (int r = 0; r < used[j]; ++r) {
+            bias64[row0[j] + r] = bt.data[r];
+            if (r % 4 == 0) tab[(row0[j] + r) / 4] = (float)(choffs[bidx[j]] + r);
+          }
+          if (st.ride4) {
+            const HostTensor& b4t = need(embed_key(s, b4) + ".bias");
+            for (int r = 0; r < ride[j]; ++r) {
+              bias64[row0[j] + used[j] + r] = b4t.data[ride0[j] + r];
+              if (r % 4 == 0) tab[(row0[j] + used[j] + r) / 4] = (float)(choffs[b4] + ride0[j] + r);
+            }
+          }
+        }
+        st.patch_tab = push_f(tab);
+        st.patch_bias64 = push_f(bias64);
       }
       {   // one launch for the whole CrossEmbed where launches, not FLOPs, are the cost (stages 1-3 of the 1-degree grid)
         bool same_parity = ks.size() >= 2 && embed_merge && s >= 1;
@@ -855,6 +912,7 @@ class Engine : public EngineBase {
   const ConvW* gemm_par = nullptr;   // set around a gemm() call: the four parity weight sets of a ConvTranspose k4
   bool split_k = !getenv("WX_NO_SPLIT_K");
   bool embed_merge = !getenv("WX_NO_EMBED_MERGE");
+  bool embed_ride4 = !getenv("WX_NO_EMBED_RIDE4");
   int skinny_max = getenv("WX_SKINNY_MAX") ? atoi(getenv("WX_SKINNY_MAX")) : 8;          // K ranges per tile (0 / 1: off)
   int skinny_steps = getenv("WX_SKINNY_STEPS") ? std::max(1, atoi(getenv("WX_SKINNY_STEPS"))) : 2;   // 128-byte K steps per range, at least
   int skinny_min_nk = getenv("WX_SKINNY_MIN_NK") ? atoi(getenv("WX_SKINNY_MIN_NK")) : 16;
@@ -1502,12 +1560,15 @@ class Engine : public EngineBase {
     }
     for (size_t b = 0; b < st.embed.size(); ++b) {
       const int k = st.embed_k[b], stv = cfg.embed_strides[s], pd = (k - stv) / 2;
-      if (s == 0 && st.patch[b].wt >= 0 && use_patch && st.embed_k.back() == 32 && st.patch.back().wt >= 0) {
+      const bool patch_on = s == 0 && use_patch && st.embed_k.back() == 32 && st.patch.back().wt >= 0 && st.patch_tab >= 0;
+      if (patch_on && k == 4 && st.ride4) { choff += st.embed[b].n; continue; }   // computed by the patch kernel's spare accumulator rows
+      if (patch_on && st.patch[b].wt >= 0) {
         if (k != 32) { choff += st.embed[b].n; continue; }  // rides along in the fused launch issued with k = 32
         EmbedPatchParams ep;
         std::memset(&ep, 0, sizeof(ep));
         ep.xin = in; ep.xin_planar = in_planar; ep.Hb = in_h; ep.Wb = Wp + 2 * halo; ep.cpad = cpad0; ep.org = halo - 15;
         ep.out_ld = ld; ep.out_h = sh[0]; ep.out_w = sw[0]; ep.dbg = dbg_flags;
+        ep.slot_tab = f_dev + st.patch_tab; ep.bias64 = f_dev + st.patch_bias64; ep.out_row = x;
         double fl = 0.0;
         int off = 0;
         for (size_t j = 0; j < st.embed.size(); ++j) {
@@ -1515,9 +1576,11 @@ class Engine : public EngineBase {
           const int kj = st.embed_k[j];
           if (pw.wt >= 0) {
             fl += 2.0 * sh[0] * sw[0] * pw.n * kj * kj * C_in;
-            if (kj == 32) { ep.wt32 = wt_dev + pw.wt; ep.bias32 = f_dev + pw.bias; ep.out32 = x + off; ep.n32 = pw.n; }
-            if (kj == 16) { ep.wt16 = wt_dev + pw.wt; ep.bias16 = f_dev + pw.bias; ep.out16 = x + off; ep.n16 = pw.n; }
-            if (kj == 8) { ep.wt8 = wt_dev + pw.wt; ep.bias8 = f_dev + pw.bias; ep.out8 = x + off; ep.n8 = pw.n; }
+            if (kj == 32) ep.wt32 = wt_dev + pw.wt;
+            if (kj == 16) ep.wt16 = wt_dev + pw.wt;
+            if (kj == 8) ep.wt8 = wt_dev + pw.wt;
+          } else if (kj == 4 && st.ride4) {
+            fl += 2.0 * sh[0] * sw[0] * st.embed[j].n * kj * kj * C_in;
           }
           off += st.embed[j].n;
         }
