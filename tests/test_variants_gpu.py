@@ -67,6 +67,35 @@ def test_merged_parity_convs_bit_identical(prec):
     assert torch.equal(_forward(merged, x), _forward(separate, x))
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_launch_count_reducers_on_small_maps(prec):
+    """1-degree grid (launch-bound: ~5 us of dispatch floor per kernel): (a) one convolution per CrossEmbed of stages 1-3, the k = 2
+    branch zero-padded into the k = 4 window; (b) the stage-0 k = 4 branch in the spare accumulator rows of the LDS-patch kernel;
+    (c) the GroupNorm partial fold inside the apply kernel.  Each against the engine with the reducer off: the added products are
+    exact zeros and the folds keep a fixed order, so only the grouping of fp32 sums changes."""
+    cfg = named_config("C1")
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    on = _engine("C1", prec, {})
+    off = _engine("C1", prec, {"WX_NO_EMBED_MERGE": "1", "WX_NO_EMBED_RIDE4": "1", "WX_GN_FOLD_TILES": "0"})
+    on.profile(2)
+    off.profile(2)
+    y_on, y_on2, y_off = _forward(on, x), _forward(on, x), _forward(off, x)
+    assert torch.equal(y_on, y_on2)
+    scale = float(y_off.abs().max())
+    if prec == "fp32":
+        err = float((y_on - y_off).abs().max())
+        assert err <= 2e-5 * scale, f"reducers on vs off (fp32): {err:.3e} of {scale:.3e}"
+    else:
+        l2 = float(torch.linalg.norm((y_on - y_off).double()) / torch.linalg.norm(y_off.double()))
+        assert l2 <= 1e-2, f"reducers on vs off (bf16) rel-L2 {l2:.3e}"
+    c_on = {r["name"]: r["launches"] for r in on.profile_read()}
+    c_off = {r["name"]: r["launches"] for r in off.profile_read()}
+    for s in (1, 2, 3):   # (two forwards were profiled on `on`, one on `off`)
+        assert c_on[f"gemm_embed.s{s}"] == 2 * 1 and c_off[f"gemm_embed.s{s}"] == 2
+    assert "gemm_embed.s0" not in c_on and c_off.get("gemm_embed.s0", 0) == 1
+    assert sum(v for k, v in c_on.items() if k.startswith("gn_stats")) < 2 * sum(v for k, v in c_off.items() if k.startswith("gn_stats"))
+
+
 @pytest.mark.parametrize("name", ["T5", "C1"])
 def test_persistent_gemm_forced_on_small_maps(name):
     """`gemm_stream_kernel` (wx_gemm_stream.h) only takes C >= 512 layers with >= 4096 rows by itself, i.e. only the 0.25-degree model.
