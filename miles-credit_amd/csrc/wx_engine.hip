@@ -54,6 +54,7 @@ struct ConvW {          // one repacked GEMM operand in the weight arena
   int64_t bias = -1;    // float-arena offsets (-1 = absent)
   int64_t colsum = -1;
   int cin_true = 0;     // unpadded channels (flop accounting)
+  double flop_frac = 1.0;   // share of the dense n x kh x kw x cin products that are the model's (merged CrossEmbed: the rest multiply padded zeros)
   int64_t wt_kb = -1;   // bf16 engine, 1x1 layers with n % 256 == 0: second copy, k-blocked [cin/32][n][32] (wx_gemm_stream.h)
 };
 struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1, bias_tb = -1; int wsz = 0, kind = 0; };
@@ -522,6 +523,9 @@ class Engine : public EngineBase {
     }
     ConvW cw;
     cw.n = n; cw.cin = cpad; cw.cin_true = cin; cw.kh = kmax; cw.kw = kmax;
+    double real = 0.0;
+    for (size_t b = 0; b < ks.size(); ++b) real += (double)cos[b] * ks[b] * ks[b];
+    cw.flop_frac = real / ((double)n * kmax * kmax);
     cw.wt = push_w(rows, n, k);
     cw.bias = push_f(bias);
     return cw;
@@ -808,7 +812,10 @@ class Engine : public EngineBase {
       {   // one launch for the whole CrossEmbed where launches, not FLOPs, are the cost (stages 1-3 of the 1-degree grid)
         bool same_parity = ks.size() >= 2 && embed_merge && s >= 1;
         for (int kk : ks) same_parity = same_parity && ((ks.back() - kk) % 2 == 0) && kk >= cfg.embed_strides[s];
-        if (same_parity && small_map_tokens(s) && sh[s] > 0) st.merged = make_embed_merged(s, ks, cos, cin, cpad);
+        // launch-bound = the merged GEMM itself is tiny (1-degree grid: 0.75 G products per stage); the 0.25-degree stages 2-3 pass the
+        // token test but are 42 G products each, where the padding costs more than the launch (107 / 123 us against 96 / 100 for the pair)
+        const double products = (double)sh[s] * sw[s] * cout * ks.back() * ks.back() * cin;
+        if (same_parity && small_map_tokens(s) && products <= 4e9 && sh[s] > 0) st.merged = make_embed_merged(s, ks, cos, cin, cpad);
       }
       for (int d = 0; d < cfg.depth[s]; ++d) {
         const std::string p = "layers." + std::to_string(s) + ".1.layers." + std::to_string(d);
@@ -1258,7 +1265,7 @@ class Engine : public EngineBase {
              cout, q >> 1, q & 1, want_stats, want_gn);
       return false;
     }
-    const double flops = 2.0 * m * w.n * w.kh * w.kw * w.cin_true;
+    const double flops = 2.0 * m * w.n * w.kh * w.kw * w.cin_true * w.flop_frac;
     const double bytes = (m * w.n * (res ? 2.0 : 1.0) + (double)in_h * in_w * w.cin_true + (double)w.n * w.kh * w.kw * w.cin) * sizeof(T);
     bool made_stats = false;
     if (want_stats && fuse_ln && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr)) {

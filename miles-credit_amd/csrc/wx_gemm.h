@@ -1002,9 +1002,10 @@ inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page,
   const bool one = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_y == 0 && p.pad_x == 0 && p.in_h == p.out_h &&
                    p.in_w == p.out_w;
   const bool three = KB == 64 && (p.dbg & 128);  // experiment switch: 3-stage ring, 3 workgroups/CU
-  // launches of at most one workgroup per two CUs (the 1-degree grid's deep stages: 4 - 48 tiles) are bound by the latency of ONE
-  // stage in flight per CU (0.75 us per 128-byte K step measured); a 4-stage ring keeps three in flight -- LDS is free there
-  static const int deep_max = getenv("WX_GEMM_DEEP_TILES") ? atoi(getenv("WX_GEMM_DEEP_TILES")) : 128;
+  // experiment switch (WX_GEMM_DEEP_TILES=n: launches of <= n tiles on a 4-stage ring, three K stages in flight per CU).  OFF: on the
+  // 1-degree grid's deep stages (4 - 48 tiles, 0.57 us per 128-byte K step) it changed nothing (699 vs 702 steps/s) -- a lone
+  // workgroup's K step is bound by its own ds_read -> MFMA chain, not by the stage in flight; those launches are split over K instead
+  static const int deep_max = getenv("WX_GEMM_DEEP_TILES") ? atoi(getenv("WX_GEMM_DEEP_TILES")) : 0;
   const bool deep = KB == 128 && !three && !(p.dbg & 512) &&
                     (int64_t)cdiv(p.out_h * p.out_w, 128) * (p.n_par == 4 ? 4 : cdiv(p.n, BN)) * (p.partial ? p.k_splits : 1) <= deep_max;
   if (one) {
