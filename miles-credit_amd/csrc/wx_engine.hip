@@ -920,6 +920,7 @@ class Engine : public EngineBase {
   bool split_k = !getenv("WX_NO_SPLIT_K");
   bool embed_merge = !getenv("WX_NO_EMBED_MERGE");
   bool embed_ride4 = !getenv("WX_NO_EMBED_RIDE4");
+  bool stat_share = !getenv("WX_NO_EMBED_STATS");
   int skinny_max = getenv("WX_SKINNY_MAX") ? atoi(getenv("WX_SKINNY_MAX")) : 8;          // K ranges per tile (0 / 1: off)
   int skinny_steps = getenv("WX_SKINNY_STEPS") ? std::max(1, atoi(getenv("WX_SKINNY_STEPS"))) : 2;   // 128-byte K steps per range, at least
   int skinny_min_nk = getenv("WX_SKINNY_MIN_NK") ? atoi(getenv("WX_SKINNY_MIN_NK")) : 16;
@@ -1232,6 +1233,15 @@ class Engine : public EngineBase {
 
   // ------------------------------------------------------------------ launch helpers
   // returns true when the launch also produced LayerNorm partials for its output rows (want_stats)
+  // K ranges of the plain split-K rule (gemm() below) for a bias-only convolution of `rows` output pixels; 1 = not split
+  int plain_split_ways(const ConvW& w, int64_t rows) const {
+    if (!split_k || !use_dma || w.n % 128 != 0 || (w.cin * (int)sizeof(T)) % 128 != 0) return 1;
+    const int64_t tiles = cdiv(rows, (int64_t)128) * (w.n / 128);
+    const int nk = w.kh * w.kw * (w.cin * (int)sizeof(T) / 128);
+    int S = (int)std::min<int64_t>(8, 512 / std::max<int64_t>(tiles, 1));
+    S = std::min(S, nk / 16);   // at least 16 K steps per range
+    return (tiles <= 200 && S >= 2) ? S : 1;
+  }
   bool gemm(const char* cls, const ConvW& w, const T* in, int in_h, int in_w, int64_t in_ld, int stride, int pad_y,
             int pad_x, int out_h, int out_w, T* out, int64_t out_ld, const float2* rs, int act, const T* res,
             int64_t res_ld, int out_mode = 0, int cout = 0, int py = 0, int px = 0, bool want_stats = false,
@@ -1270,6 +1280,7 @@ class Engine : public EngineBase {
     bool made_stats = false;
     if (want_stats && fuse_ln && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr)) {
       p.stat_out = statpart;
+      p.stat_stride = stat_share_stride; p.stat_slot0 = stat_share_slot0;
       made_stats = true;
     }
     if (want_gn && fuse_ln && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr)) {
@@ -1322,13 +1333,9 @@ class Engine : public EngineBase {
     if (blk_hidden) throw StateError("k-blocked hidden tensor requested but the GEMM fell back to the row-major kernel");
     // split-K for plain deep-K launches that cannot fill the chip (stage-3 CrossEmbed k = 4: 160 tiles walking K = 8192; every
     // CrossEmbed GEMM of the 1-degree grid): 128 x 128 tiles x S K-ranges, fp32 partial sums, fixed-order finish kernel
-    if (split_k && use_dma && !rs && !res && act == 0 && out_mode == 0 && !p.gn_out && w.n % 128 == 0 &&
-        (w.cin * (int)sizeof(T)) % 128 == 0 && conv_gemm_is_dma<T>(p, zero_page)) {
-      const int64_t tiles = (int64_t)cdiv((int64_t)out_h * out_w, 128) * (w.n / 128);
-      const int nk = w.kh * w.kw * (w.cin * (int)sizeof(T) / 128);
-      int S = (int)std::min<int64_t>(8, 512 / std::max<int64_t>(tiles, 1));
-      S = std::min(S, nk / 16);   // at least 16 K steps per range
-      if (tiles <= 200 && S >= 2) {
+    if (!rs && !res && act == 0 && out_mode == 0 && !p.gn_out && conv_gemm_is_dma<T>(p, zero_page)) {
+      const int S = plain_split_ways(w, (int64_t)out_h * out_w);
+      if (S >= 2) {
         const size_t need = (size_t)S * out_h * out_w * w.n * sizeof(float);
         if (need > splitk_bytes) { splitk_buf = (float*)dalloc(need); splitk_bytes = need; }
         p.partial = splitk_buf;
@@ -1480,6 +1487,7 @@ class Engine : public EngineBase {
     stat_tiles_ready = st ? last_stat_slots : 0;
     capture(dbg_name, x, h, w, c, ld, w);
   }
+  int stat_share_stride = 0, stat_share_slot0 = 0;   // LN partials of several launches into one row of `statpart` (cross_embed)
   int gn_tile_off = 0;      // tiles already written to gnpart by earlier launches of the same conv (gn_accum)
   bool gn_accum = false;
   void gn_local_stats(const T* x, int c, int64_t m, bool have_partials) {   // -> gn_acc[2c] (sum, sum sq) in fp64
@@ -1565,6 +1573,18 @@ class Engine : public EngineBase {
       stat_tiles_ready = made ? last_stat_slots : 0;
       return;
     }
+    // stages 1-3: every branch's epilogue (or split-K finish) leaves the LayerNorm partials of ITS channel range in the shared row of
+    // `statpart` -- the stage's first sub-block then needs no ln_stats launch (slot counts are predicted here and checked after each launch)
+    int slots[8] = {0}, total_slots = 0;
+    bool share = s >= 1 && fuse_ln && use_dma && !band_on && !dbg_flags && stat_share && st.embed.size() <= 8;
+    for (size_t b = 0; share && b < st.embed.size(); ++b) {
+      const ConvW& w = st.embed[b];
+      slots[b] = plain_split_ways(w, (int64_t)sh[s] * sw[s]) > 1 ? conv_gemm_finish_slots(w.n) : conv_gemm_n_tiles(w.n);
+      total_slots += slots[b];
+    }
+    share = share && total_slots <= 8;
+    bool all_made = share;
+    int slot_at = 0;
     for (size_t b = 0; b < st.embed.size(); ++b) {
       const int k = st.embed_k[b], stv = cfg.embed_strides[s], pd = (k - stv) / 2;
       const bool patch_on = s == 0 && use_patch && st.embed_k.back() == 32 && st.patch.back().wt >= 0 && st.patch_tab >= 0;
@@ -1610,11 +1630,18 @@ class Engine : public EngineBase {
       } else if (s == 0)
         gemm("gemm_embed", st.embed[b], in, in_h, Wp + 2 * halo, cpad0, stv, pd - halo, pd - halo, sh[0], sw[0],
              x + choff, ld, nullptr, 0, nullptr, 0);
-      else
-        gemm("gemm_embed", st.embed[b], in, in_h, sw[s - 1], in_ld_s, stv, pd + in_row0, pd, sh[s], sw[s],
-             x + choff, ld, nullptr, 0, nullptr, 0);
+      else {
+        if (share) { stat_share_stride = total_slots; stat_share_slot0 = slot_at; }
+        const bool made = gemm("gemm_embed", st.embed[b], in, in_h, sw[s - 1], in_ld_s, stv, pd + in_row0, pd, sh[s], sw[s],
+                               x + choff, ld, nullptr, 0, nullptr, 0, 0, 0, 0, 0, share);
+        stat_share_stride = stat_share_slot0 = 0;
+        if (share && made && last_stat_slots != slots[b]) throw StateError("cross_embed: LayerNorm partial slots of a branch differ from the prediction");
+        all_made = all_made && made;
+        slot_at += slots[b];
+      }
       choff += st.embed[b].n;
     }
+    if (share) stat_tiles_ready = all_made ? total_slots : 0;
   }
   // a4-a7: the transformer blocks of stage s on the rows the stream currently holds
   void stage_blocks(int s) {

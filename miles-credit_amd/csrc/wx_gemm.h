@@ -37,6 +37,8 @@ struct ConvGemmParams {
   int stat_tiles;         // number of partials per row in `rowstat` (0 = final statistics)
   float stat_inv_c;       // 1 / channels, with stat_tiles > 0
   float2* stat_out;       // [M][n_tiles] partial (sum, sum sq) of THIS launch's output rows (fast path only), or nullptr
+  int stat_stride;        // 0: the row stride of stat_out is this launch's own slot count; else several launches share the rows
+  int stat_slot0;         //    (the branches of one CrossEmbed write disjoint channel ranges of a stream row): stride and first slot
   float2* gn_out;         // [m_tiles][n] per-channel (sum, sum sq) over each 128-row tile of the output (GroupNorm), or nullptr
   const float* colsum;    // [n] sum_c wt[n][c] (with rowstat)
   int act;             // 0 none, 1 exact GELU
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
           const int m = m_blk + ml0 + i * RPP;
-          if (m < M) p.stat_out[(int64_t)m * n_tiles + tile_n] = make_float2(s1[i], s2[i]);
+          if (m < M) p.stat_out[(int64_t)m * (p.stat_stride ? p.stat_stride : n_tiles) + p.stat_slot0 + tile_n] = make_float2(s1[i], s2[i]);
         }
       }
     }
@@ -943,7 +945,7 @@ __global__ __launch_bounds__(256) void conv_gemm_finish_kernel(const ConvGemmPar
   if (p.stat_out) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if (lane == 0) p.stat_out[(int64_t)m * chunks + c] = make_float2(s1, s2);
+    if (lane == 0) p.stat_out[(int64_t)m * (p.stat_stride ? p.stat_stride : chunks) + p.stat_slot0 + c] = make_float2(s1, s2);
   }
 }
 

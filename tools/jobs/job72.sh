@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
+B="python bench.py --steps 30 --warmup 4 --no-cpu-baseline --no-config2 --no-fp32 --no-roofline"
+P='import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], d["value"], d["ms_per_step"])'
+for i in 1 2 3; do
+$B 2>&1 | tail -1 | python -c "$P" new
+WX_ALLOW_STALE=1 WX_LIBRARY=$GRAFT_REPO_ROOT/miles-credit_amd/wxengine/libwxengine_prev.so $B 2>&1 | tail -1 | python -c "$P" prev
+done
+python tools/stage_classes.py C3 bf16 2>&1 | grep "ln_stats\|kernel time"
