@@ -52,6 +52,10 @@ struct EmbedPatchParams {
   // leaves its raw fp32 sums in partial[y][pixel][64] (k32 | k16 | k8 channels); embed_finish_kernel adds them in order
   float* partial;
   int chunk_per;
+  int part_rows;       // output rows [row0, row0 + part_rows) are the rows `partial` holds (a launch of part of the map keeps only its own)
+  // big maps: the last, partly filled round of 16-row tiles (0.25 degrees: 125 of 625 tiles) is launched with a two-way chunk split
+  // instead of as 8-row tiles -- tail_partial = a buffer of 2 x tail rows x out_w x 64 floats, or nullptr (launch_embed_patch)
+  float* tail_partial;
 };
 
 #ifndef WX_EMBED_TAIL_NW
@@ -280,12 +284,12 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
   }
 
   if (p.partial) {   // raw sums of this chunk range: [pixel][64] floats, lane (li, g) holds channels 4g..4g+3 of each 16-channel group
-    float* part = p.partial + (int64_t)blockIdx.y * p.out_h * p.out_w * 64;
+    float* part = p.partial + (int64_t)blockIdx.y * p.part_rows * p.out_w * 64;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int oy = oy0 + RPW * wave + (f >> 1), ox = ox0 + (f & 1) * 16 + li;
       if (oy >= p.out_h || ox >= p.out_w) continue;
-      float* q = part + ((int64_t)oy * p.out_w + ox) * 64 + g * 4;
+      float* q = part + ((int64_t)(oy - p.row0) * p.out_w + ox) * 64 + g * 4;
       *reinterpret_cast<float4*>(q) = make_float4(a32[f][0], a32[f][1], a32[f][2], a32[f][3]);
       *reinterpret_cast<float4*>(q + 16) = make_float4(a16[f][0], a16[f][1], a16[f][2], a16[f][3]);
       *reinterpret_cast<float4*>(q + 32) = make_float4(a8[0][f][0], a8[0][f][1], a8[0][f][2], a8[0][f][3]);
@@ -320,16 +324,17 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
 // chunk-split finish: out = bf16(sum_y partial[y] + bias), one thread per (pixel, 4 channels); fixed summation order
 template <typename T>
 __global__ __launch_bounds__(256) void embed_finish_kernel(const EmbedPatchParams p, int n_split) {
-  const int64_t npix = (int64_t)p.out_h * p.out_w;
+  const int64_t npix = (int64_t)p.part_rows * p.out_w;     // the rows [row0, row0 + part_rows) this launch computed
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= npix * 16) return;
-  const int64_t pix = idx >> 4;
+  const int64_t lpix = idx >> 4;
   const int q = (int)(idx & 15) * 4;     // channel 0..60 of the 64-wide partial row
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int y = 0; y < n_split; ++y) {
-    const float4 v = *reinterpret_cast<const float4*>(p.partial + ((int64_t)y * npix + pix) * 64 + q);
+    const float4 v = *reinterpret_cast<const float4*>(p.partial + ((int64_t)y * npix + lpix) * 64 + q);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
+  const int64_t pix = (int64_t)p.row0 * p.out_w + lpix;
   const int ch = (int)p.slot_tab[q >> 2];   // stream channel of this 4-channel slot, or -1
   if (ch < 0) return;
   const float4 b = *reinterpret_cast<const float4*>(p.bias64 + q);
@@ -349,12 +354,13 @@ inline void launch_embed_patch_part(EmbedPatchParams p, int row0, int rows, cons
     attr_mark_device(attr_done_mask);
   }
   p.row0 = row0;
+  p.part_rows = std::min(rows, p.out_h - row0);
   const int blocks = cdiv(rows, TH) * cdiv(p.out_w, 32);
   const int n_split = p.partial ? cdiv(p.cpad / (16 / (int)sizeof(T)), p.chunk_per) : 1;
   hipLaunchKernelGGL(kern, dim3(blocks, n_split), dim3(NT), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
   WX_HIP(hipGetLastError());
   if (p.partial) {
-    const int64_t work = (int64_t)p.out_h * p.out_w * 16;
+    const int64_t work = (int64_t)p.part_rows * p.out_w * 16;
     hipLaunchKernelGGL(embed_finish_kernel<T>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, stream, p, n_split);
     WX_HIP(hipGetLastError());
   }
@@ -365,6 +371,16 @@ inline void launch_embed_patch_part(EmbedPatchParams p, int row0, int rows, cons
 // small maps (fewer 16-row tiles than half the CUs): 4-row tiles, and the caller may add the chunk split
 inline bool embed_patch_small_map(int out_h, int out_w, int dbg, int n_cu = 256) {
   return !(dbg & 8192) && !(dbg & 256) && cdiv(out_h, 16) * cdiv(out_w, 32) < n_cu / 2;
+}
+// rows of the big-map tail that is launched with a two-way chunk split (0: the map has no such tail); the caller sizes tail_partial with it
+inline int embed_patch_tail_rows(int out_h, int out_w, int chunks, int n_cu = 256) {
+  const int tiles_x = cdiv(out_w, 32), tile_rows = cdiv(out_h, 16);
+  if (tile_rows * tiles_x < n_cu / 2 || chunks < 4) return 0;
+  const int full_rounds = (tile_rows * tiles_x) / n_cu;
+  const int r1 = (full_rounds * n_cu) / tiles_x;
+  const int rem = out_h - 16 * r1;
+  if (full_rounds < 1 || r1 >= tile_rows || rem <= 0 || cdiv(rem, 8) * tiles_x > n_cu) return 0;
+  return 2 * cdiv(rem, 16) * tiles_x <= n_cu ? rem : 0;
 }
 template <typename T>
 inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream, int n_cu = 256) {
@@ -383,6 +399,14 @@ inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page,
   const int rem = p.out_h - 16 * r1;
   if (!(p.dbg & 8192) && full_rounds >= 1 && r1 < tile_rows && rem > 0 && cdiv(rem, 8) * tiles_x <= n_cu) {
     launch_embed_patch_part<T, 8, 16>(p, 0, 16 * r1, zero_page, stream);
+    if (p.tail_partial && embed_patch_tail_rows(p.out_h, p.out_w, p.cpad / (16 / (int)sizeof(T)), n_cu) == rem) {
+      // the tail as 16-row tiles over HALF the channel chunks each (one round of <= 256 workgroups) + the fixed-order finish
+      EmbedPatchParams q = p;
+      q.partial = p.tail_partial;
+      q.chunk_per = cdiv(p.cpad / (16 / (int)sizeof(T)), 2);
+      launch_embed_patch_part<T, 8, 16>(q, 16 * r1, rem, zero_page, stream);
+      return;
+    }
     launch_embed_patch_part<T, WX_EMBED_TAIL_NW, 8>(p, 16 * r1, rem, zero_page, stream);
   } else {
     launch_embed_patch_part<T, 8, 16>(p, 0, p.out_h, zero_page, stream);

@@ -919,6 +919,9 @@ class Engine : public EngineBase {
   const ConvW* gemm_par = nullptr;   // set around a gemm() call: the four parity weight sets of a ConvTranspose k4
   bool split_k = !getenv("WX_NO_SPLIT_K");
   bool embed_merge = !getenv("WX_NO_EMBED_MERGE");
+  bool embed_tail_split = !getenv("WX_NO_EMBED_TAIL_SPLIT");
+  float* embed_tail = nullptr;
+  size_t embed_tail_bytes = 0;
   bool embed_ride4 = !getenv("WX_NO_EMBED_RIDE4");
   bool stat_share = !getenv("WX_NO_EMBED_STATS");
   int skinny_max = getenv("WX_SKINNY_MAX") ? atoi(getenv("WX_SKINNY_MAX")) : 8;          // K ranges per tile (0 / 1: off)
@@ -1623,6 +1626,14 @@ class Engine : public EngineBase {
           }
           ep.partial = embed_partial;
           ep.chunk_per = cdiv(chunks0, n_split);
+        } else if (embed_tail_split && !dbg_flags) {
+          // big maps: the partly filled last round of tiles (0.25 degrees: 125 of 625) runs as ONE round of half-chunk workgroups
+          const int tail = embed_patch_tail_rows(sh[0], sw[0], chunks0);
+          if (tail > 0) {
+            const size_t need = (size_t)2 * tail * sw[0] * 64 * sizeof(float);
+            if (need > embed_tail_bytes) { embed_tail = (float*)dalloc(need); embed_tail_bytes = need; }
+            ep.tail_partial = embed_tail;
+          }
         }
         timed("embed_patch", fl, (double)(in_h * Wp) * cpad0 * sizeof(T) + (double)sh[0] * sw[0] * 64 * sizeof(T), [&] {
           launch_embed_patch<T>(ep, zero_page, cur_stream);
