@@ -19,6 +19,9 @@
 // branches ride along: inside the central 16x16 (8x8) taps the same fragment also feeds the k=16 (k=8) weights,
 // adding their 236 GFLOP without a single extra LDS read.  Global/L2 traffic is the patch itself
 // (arithmetic intensity ~700 FLOP/B).
+// Round 3: (a) accumulator rows a model's branches leave empty carry channels of the k = 4 branch (slot_tab / bias64 below; the engine
+// repacks its 4 x 4 taps zero-padded into the host window) -- the 1-degree model then needs no separate k = 4 launch; (b) the partly
+// filled last round of tiles of a big map runs as half-chunk workgroups (tail_partial, launch_embed_patch).
 #pragma once
 #include "wx_common.h"
 #include "wx_gemm.h"
