@@ -45,6 +45,7 @@ struct AttnBlockParams {
   const float* bo;      // [C]
   const float* tb;      // position-bias generating table [(2 wsz - 1)^2], x log2 e
   int H, W, wsz, kind;  // kind 0 short, 1 long (dilated)
+  int pack = 1;         // 2 x 2 windows only: 4 windows share one 16-token fragment (block-diagonal bias: other windows' keys get -1e30)
   unsigned long long* trace = nullptr;   // tools/attn_block_probe only (WX_ATTN_TRACE builds): [workgroups * waves][8] phase ticks
   float2* stat_out = nullptr;           // [H*W][C / 32] LayerNorm partials (sum, sum sq) of the sub-block's output rows, or nullptr
   int dbg = 0;                           // probe ablations: 1 skip the attention loop, 2 skip the projections, 4 skip the out-projection
@@ -74,9 +75,11 @@ __global__ __launch_bounds__(2 * C, C == 256 ? 1 : 2) void attn_block_kernel(con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int head = wave;
-  const int N = p.wsz * p.wsz;
+  const int PK = p.pack;              // windows per workgroup (1, or 4 windows of 4 tokens)
+  const int NS = p.wsz * p.wsz;       // tokens per window
+  const int N = NS * PK;
   const int wins_x = p.W / p.wsz, wins_y = p.H / p.wsz;
-  const int win = blockIdx.x;
+  const int win = blockIdx.x * PK;
   const int wy0 = win / wins_x, wx0 = win - wy0 * wins_x;
   int CT, CL, BY, BX;
   if (p.kind == 0) { CT = p.W - p.wsz; CL = 1; BY = p.wsz * p.W; BX = p.wsz; }
@@ -84,10 +87,17 @@ __global__ __launch_bounds__(2 * C, C == 256 ? 1 : 2) void attn_block_kernel(con
   const unsigned mg_x = (65536u + (unsigned)p.wsz - 1u) / (unsigned)p.wsz;
   // token t of the window -> pixel; padded tokens alias the last one (their keys carry a -1e30 bias, their query rows are never stored)
   auto token_pixel = [&](int t) -> int {
-    const int tl = min(t, N - 1);
+    int tl = min(t, N - 1);
+    int wy = wy0, wx = wx0;
+    if (PK > 1) {   // token t = window (win + t / NS), position t % NS
+      const int sw = tl / NS, w = win + sw;
+      tl -= sw * NS;
+      wy = w / wins_x; wx = w - wy * wins_x;
+    }
     const int ty = (int)(((unsigned)tl * mg_x) >> 16);
-    return ty * CT + tl * CL + wy0 * BY + wx0 * BX;
+    return ty * CT + tl * CL + wy * BY + wx * BX;
   };
+  const int TOFF = PK > 1 ? 64 : 0;   // the bias table sits at s_tb[TOFF ..]: offsets between different windows (+-16 per window) stay inside the -1e30 fill
   char* __restrict__ xg = reinterpret_cast<char*>(p.x);
   const unsigned row_bytes = (unsigned)p.ld * 2u;
 
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(2 * C, C == 256 ? 1 : 2) void attn_block_kernel(con
   {
     const int side2 = (2 * p.wsz - 1) * (2 * p.wsz - 1);
 #pragma unroll
-    for (int i = 0; i < TBN / NT; ++i) tbv[i] = p.tb[min(tid + i * NT, side2 - 1)];
+    for (int i = 0; i < TBN / NT; ++i) tbv[i] = p.tb[min(max(tid + i * NT - TOFF, 0), side2 - 1)];
   }
   {
     const int piece = tid % PR, r0 = tid / PR;       // 16 rows per pass
@@ -152,11 +162,12 @@ __global__ __launch_bounds__(2 * C, C == 256 ? 1 : 2) void attn_block_kernel(con
 #pragma unroll
     for (int i = 0; i < TBN / NT; ++i) {
       const int e = tid + i * NT;
-      s_tb[e] = e < side * side ? tbv[i] : -1.0e30f;
+      s_tb[e] = (e >= TOFF && e - TOFF < side * side) ? tbv[i] : -1.0e30f;
     }
     for (int t = tid; t < NP; t += NT) {
-      const int ty = (int)(((unsigned)t * mg_x) >> 16), tx = t - ty * p.wsz;
-      s_bk[t] = t < N ? 4 * (ty * side + tx) : -2048;
+      const int sw = PK > 1 ? t / NS : 0, tl = t - sw * NS;
+      const int ty = (int)(((unsigned)tl * mg_x) >> 16), tx = tl - ty * p.wsz;
+      s_bk[t] = t < N ? 4 * (ty * side + tx) + 64 * sw : -2048;
     }
   }
   char* vt = vimg + wave * VT_BYTES;
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(2 * C, C == 256 ? 1 : 2) void attn_block_kernel(con
   auto scores = [&](QS& q, int qb_) __attribute__((always_inline)) {
     q.query = qb_ * 16 + li;
     const uint4 qcur = pick_q(qb_);
-    const int aq = max(s_bk[q.query], 0) + 4 * ((p.wsz - 1) * (2 * p.wsz - 1) + (p.wsz - 1));
+    const int aq = max(s_bk[q.query], 0) + 4 * ((p.wsz - 1) * (2 * p.wsz - 1) + (p.wsz - 1)) + 4 * TOFF;
     const char* tbb = reinterpret_cast<const char*>(s_tb) + aq;
 #pragma unroll
     for (int j = 0; j < NKF; ++j) {
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(2 * C, C == 256 ? 1 : 2) void attn_block_kernel(con
       }
       float sv[NKF][4];
       float mx = -3.0e38f;
-      const int aq = max(s_bk[query], 0) + 4 * ((p.wsz - 1) * (2 * p.wsz - 1) + (p.wsz - 1));
+      const int aq = max(s_bk[query], 0) + 4 * ((p.wsz - 1) * (2 * p.wsz - 1) + (p.wsz - 1)) + 4 * TOFF;
       const char* tbb = reinterpret_cast<const char*>(s_tb) + aq;
 #pragma unroll
       for (int j = 0; j < NKF; ++j) {
@@ -549,7 +560,7 @@ inline void launch_attn_block_v(const AttnBlockParams& p, hipStream_t stream) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_mark_device(attr_done_mask);
   }
-  const int n_win = (p.H / p.wsz) * (p.W / p.wsz);
+  const int n_win = (p.H / p.wsz) * (p.W / p.wsz) / p.pack;
   hipLaunchKernelGGL(kern, dim3((unsigned)n_win), dim3(2 * C), LDS, stream, p);
   WX_HIP(hipGetLastError());
 }
@@ -558,7 +569,8 @@ inline void launch_attn_block(int c, const AttnBlockParams& p, hipStream_t strea
   if ((int64_t)p.H * p.W >= (1 << 24) || p.ld * 2 >= (1 << 24) || (int64_t)p.H * p.W * p.ld * 2 >= (int64_t(1) << 32))
     throw std::runtime_error("attention block: map too large for 24-bit pixel / 32-bit byte addressing");
   if (!attn_block_supported(c, p.wsz, true) || (p.kind != 0 && p.kind != 1)) throw std::runtime_error("attention block: unsupported shape");
-  const int nkf = attn_nkf_tokens(p.wsz * p.wsz);
+  if (p.pack != 1 && !(p.pack == 4 && p.wsz == 2 && ((p.H / 2) * (p.W / 2)) % 4 == 0)) throw std::runtime_error("attention block: window packing needs 2 x 2 windows, a multiple of 4 of them");
+  const int nkf = attn_nkf_tokens(p.wsz * p.wsz * p.pack);
 #define WX_AB(CC, NN) launch_attn_block_v<CC, NN>(p, stream)
   if (c == 32) { switch (nkf) { case 1: WX_AB(32, 1); break; case 2: WX_AB(32, 2); break; case 4: WX_AB(32, 4); break; case 7: WX_AB(32, 7); break; default: WX_AB(32, 8); } }
   else if (c == 64) { switch (nkf) { case 1: WX_AB(64, 1); break; case 2: WX_AB(64, 2); break; case 4: WX_AB(64, 4); break; case 7: WX_AB(64, 7); break; default: WX_AB(64, 8); } }

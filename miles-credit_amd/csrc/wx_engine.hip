@@ -919,6 +919,7 @@ class Engine : public EngineBase {
   const ConvW* gemm_par = nullptr;   // set around a gemm() call: the four parity weight sets of a ConvTranspose k4
   bool split_k = !getenv("WX_NO_SPLIT_K");
   bool embed_merge = !getenv("WX_NO_EMBED_MERGE");
+  bool attn_pack2 = !getenv("WX_NO_ATTN_PACK2");
   bool embed_tail_split = !getenv("WX_NO_EMBED_TAIL_SPLIT");
   float* embed_tail = nullptr;
   size_t embed_tail_bytes = 0;
@@ -1402,7 +1403,10 @@ class Engine : public EngineBase {
       const bool small_map = small_map_tokens(s);   // launch-bound maps (1-degree model): one launch instead of three
       if (!big_s0 && !small_map) return false;
     }
-    return a.wsz > 1 && attn_block_supported(cfg.dim[s], a.wsz) &&   // (2 x 2 windows lose even on launch-bound maps: 37 us against 26 for the three launches)
+    // 2 x 2 windows: one 16-token fragment per window loses even on launch-bound maps (37 us against 26 for the three launches); four
+    // windows per fragment (AttnBlockParams::pack) win there
+    if (a.wsz == 2 && !(attn_pack2 && small_map_tokens(s) && ((sh[s] / 2) * (sw[s] / 2)) % 4 == 0)) return false;
+    return a.wsz > 1 && attn_block_supported(cfg.dim[s], a.wsz, true) &&
            (a.kind == 0 || a.kind == 1) && a.qkv.cin == cfg.dim[s] && a.out.cin == cfg.dim[s];
   }
   void attention(const AttnL& a, int s, const std::string& dbg_name, bool defer_out = false, bool qkv_ready = false) {
@@ -1417,6 +1421,7 @@ class Engine : public EngineBase {
         bp.wqkv = reinterpret_cast<const bf16_t*>(wt_dev + a.qkv.wt); bp.csq = f_dev + a.qkv.colsum; bp.bq = f_dev + a.qkv.bias;
         bp.wout = reinterpret_cast<const bf16_t*>(wt_dev + a.out.wt); bp.bo = f_dev + a.out.bias;
         bp.tb = f_dev + a.bias_tb; bp.H = h; bp.W = w; bp.wsz = a.wsz; bp.kind = a.kind;
+        bp.pack = a.wsz == 2 ? 4 : 1;
         const double n = (double)a.wsz * a.wsz;
         bp.stat_out = fuse_ln && !dbg_flags ? statpart : nullptr;
         timed("attn_block", 8.0 * m * c * c + 4.0 * m * n * c, 2.0 * m * c * sizeof(T), [&] { launch_attn_block(c, bp, cur_stream); });
