@@ -919,6 +919,8 @@ class Engine : public EngineBase {
   const ConvW* gemm_par = nullptr;   // set around a gemm() call: the four parity weight sets of a ConvTranspose k4
   bool split_k = !getenv("WX_NO_SPLIT_K");
   bool embed_merge = !getenv("WX_NO_EMBED_MERGE");
+  int ff_split_tiles = getenv("WX_FF_SPLIT_TILES") ? atoi(getenv("WX_FF_SPLIT_TILES")) : 32;   // pixel tiles, at most
+  int ff_split_max = getenv("WX_FF_SPLIT") ? atoi(getenv("WX_FF_SPLIT")) : 8;   // hidden ranges of the split fused FeedForward (0 / 1: off)
   bool attn_pack2 = !getenv("WX_NO_ATTN_PACK2");
   bool embed_tail_split = !getenv("WX_NO_EMBED_TAIL_SPLIT");
   float* embed_tail = nullptr;
@@ -1464,13 +1466,19 @@ class Engine : public EngineBase {
   bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on && ff_big_enough(); }
   bool ff_takes_out(const FFL& f, const AttnL& a) const { return ff_takes_out(f) && !attn_block_ok(a, cur_stage); }
   bool ff_makes_qkv(const FFL& f) const { return ff_takes_out(f) && fuse_qkv && f.pack_pp >= 0 && !band_on && !(f.next && attn_block_ok(*f.next, cur_stage)); }
+  bool ff_split_ok(const FFL& f, int s, const AttnL* pre) const {
+    const int c = cfg.dim[s];
+    const int64_t m = (int64_t)sh[s] * sw[s];
+    return sizeof(T) == 2 && ff_split_max >= 2 && !pre && f.pack >= 0 && fuse_ff && fuse_ln && !band_on && !dbg_flags &&
+           ff_fused_supported(c, 4 * c) && small_map_tokens(s) && cdiv(m, (int64_t)(c == 128 ? 128 : 64)) <= ff_split_tiles && f.w2.bias >= 0 && f.w1.colsum >= 0;
+  }
   void feedforward(const FFL& f, int s, const std::string& dbg_name, const AttnL* pre = nullptr) {
     const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
     T* x = stream_ptr(s);
     const int64_t ld = stream_ld(s);
     if constexpr (sizeof(T) == 2) {
-      if (f.pack >= 0 && fuse_ff && ff_big_enough()) {
-        FFParams fp;
+      if (f.pack >= 0 && fuse_ff && ff_big_enough() && !ff_split_ok(f, s, pre)) {
+        FFParams fp{};
         fp.x = reinterpret_cast<const bf16_t*>(x); fp.ld = ld; fp.out = reinterpret_cast<bf16_t*>(x); fp.out_ld = ld;
         const bool post = pre && ff_makes_qkv(f);
         fp.M = m; fp.hidden = 4 * c; fp.wpack = reinterpret_cast<const char*>(wt_dev + (post ? f.pack_pp : pre ? f.pack_pre : f.pack));
@@ -1481,6 +1489,36 @@ class Engine : public EngineBase {
         fp.stat_out = fuse_ln ? statpart : nullptr; fp.dbg = ff_dbg;
         timed(post ? "out_ff_qkv_fused" : pre ? "out_ff_fused" : "ff_fused", (post ? 24.0 : pre ? 18.0 : 16.0) * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] { launch_ff_fused(c, fp, zero_page, cur_stream, ff_variant); });
         stat_tiles_ready = fuse_ln ? 1 : 0;
+        capture(dbg_name, x, h, w, c, ld, w);
+        return;
+      }
+    }
+    if constexpr (sizeof(T) == 2) {
+      // launch-bound maps (1-degree grid, C = 128 / 256 stages of 23 - 45 pixel tiles): the fused block with the hidden dimension cut over
+      // blockIdx.y -- every workgroup streams 1/S of W1 | W2 instead of all of it -- and the split-K finish kernel behind it
+      // (+ b2 + residual, rounding, LayerNorm partials): two launches instead of ff1 + ff2 + finish
+      const int nch = 4 * c / 32;
+      if (ff_split_ok(f, s, pre)) {
+        const int S = std::min(ff_split_max, nch / 4);
+        const int ch_per = cdiv(nch, S), S_eff = cdiv(nch, ch_per);
+        const size_t need = (size_t)S_eff * m * c * sizeof(float);
+        if (need > splitk_bytes) { splitk_buf = (float*)dalloc(need); splitk_bytes = need; }
+        FFParams fp{};
+        fp.x = reinterpret_cast<const bf16_t*>(x); fp.ld = ld; fp.out = reinterpret_cast<bf16_t*>(x); fp.out_ld = ld;
+        fp.M = m; fp.hidden = 4 * c; fp.wpack = reinterpret_cast<const char*>(wt_dev + f.pack);
+        fp.cs1 = f_dev + f.w1.colsum; fp.b1 = f_dev + f.w1.bias; fp.b2 = f_dev + f.w2.bias;
+        fp.partial = splitk_buf; fp.ch_per = ch_per;
+        ConvGemmParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.out_h = h; q.out_w = w; q.n = c; q.partial = splitk_buf; q.k_splits = S_eff;
+        q.bias = f_dev + f.w2.bias; q.res = x; q.res_ld = ld; q.out = x; q.out_ld = ld; q.stat_out = statpart;
+        timed("ff_fused_split", 16.0 * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] {
+          launch_ff_fused_split(c, fp, zero_page, cur_stream);
+          const int64_t waves = (int64_t)m * conv_gemm_finish_slots(c);
+          hipLaunchKernelGGL(conv_gemm_finish_kernel<T>, dim3((unsigned)cdiv(waves, (int64_t)4)), dim3(256), 0, cur_stream, q);
+          WX_HIP(hipGetLastError());
+        });
+        stat_tiles_ready = conv_gemm_finish_slots(c);
         capture(dbg_name, x, h, w, c, ld, w);
         return;
       }

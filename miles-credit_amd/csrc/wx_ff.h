@@ -51,6 +51,11 @@ struct FFParams {
   const float* csq;     // [3C] column sums of the rounded gain-folded Wqkv rows
   const float* bq;      // [3C] folded bias (LayerNorm shift through Wqkv)
   unsigned long long* trace;  // tools/ff_probe only (WX_FF_TRACE builds): [workgroups*4][8] phase ticks
+  // SPLIT kernels (launch-bound maps: a few dozen pixel tiles, each streaming ALL of W1 / W2 through one CU): blockIdx.y takes the hidden
+  // chunks [y * ch_per, (y + 1) * ch_per) and leaves its raw fp32 y sums in partial[y][M][C]; conv_gemm_finish_kernel (wx_gemm.h) adds them
+  // in order and applies + b2 + residual, the rounding and the LayerNorm partials
+  float* partial;
+  int ch_per;
 };
 
 // k-slot permutation shared by x fragments, W1 and (through the accumulator layout) W2:
@@ -69,7 +74,7 @@ __device__ inline f32x4_t mma_f16(const uint4& a, const uint4& b, f32x4_t acc) {
 #ifndef WX_FF_TAIL_PIPE
 #define WX_FF_TAIL_PIPE 1   // software-pipelined to_qkv tail (0: the plain read -> multiply -> epilogue -> barrier order)
 #endif
-template <int C, int PXF, int OCC, int GP, bool PRE, bool POST>
+template <int C, int PXF, int OCC, int GP, bool PRE, bool POST, bool SPLIT = false>
 __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, const char* __restrict__ zero_page) {
   constexpr int KS = C / 32;          // GEMM1 k steps
   constexpr int MF = C / 16;          // GEMM2 output-channel fragments
@@ -102,7 +107,10 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
 #pragma unroll
     for (int i = 0; i < DMA_I; ++i) lds_dma16_s(wsrc + (int64_t)ch * CB + i * 4096, dst[i] + stage_off);
   };
-  issue(0, 0u);
+  static_assert(!SPLIT || (!PRE && !POST), "the hidden split exists for the plain block only");
+  const int ch_lo = SPLIT ? (int)blockIdx.y * p.ch_per : 0;
+  const int ch_hi = SPLIT ? min(nch, ch_lo + p.ch_per) : nch;
+  issue(ch_lo, (unsigned)((ch_lo & 1) * CB));
   float* s_b2 = s_par + 2 * p.hidden + 6 * C;   // [C] b2 | [C] bo at the very end of the parameter block (offset 2*hidden + 6C whether or not POST is built)
 #ifndef WX_FF_NOPARAM   // tools/ff_probe ablation: what the per-workgroup parameter staging costs
   for (int i = tid; i < p.hidden; i += 256) {
@@ -240,10 +248,10 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   row_statistics();
 
   FF_TICK(ff1);
-  for (int ch = 0; ch < nch; ++ch) {  // NPRE is even: the ring parity of chunk ch is ch & 1 either way
+  for (int ch = ch_lo; ch < ch_hi; ++ch) {  // NPRE is even: the ring parity of chunk ch is ch & 1 either way
     FF_TICK(tc0);
     const char* cur = smem + (ch & 1) * CB;
-    if (ch + 1 < nch + NPOST) issue(NPRE + ch + 1, (unsigned)(((ch + 1) & 1) * CB));
+    if (ch + 1 < ch_hi + NPOST) issue(NPRE + ch + 1, (unsigned)(((ch + 1) & 1) * CB));
     // GEMM1, K steps in batches of 4: the 8 fragment reads of a batch are all in flight before its first MFMA.
     // (`asm volatile("" ::: "memory")` pins only the LDS reads; MFMA / VALU remain free to interleave.  Left to
     // itself hipcc reuses one register quad and serialises read -> wait -> 2 MFMAs.)
@@ -343,6 +351,18 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
   asm volatile("" : "+v"(tid2));
   const int li2 = tid2 & 15, g2 = (tid2 >> 4) & 3;
   const int px0b = (blockIdx.x * 4 + (tid2 >> 6)) * PXW;
+  if constexpr (SPLIT) {   // raw sums: accumulator element (m, f, r) = channel 16 m + 4 g + r of pixel px0b + 16 f + li
+    float* part = p.partial + (int64_t)blockIdx.y * p.M * C;
+#pragma unroll
+    for (int f = 0; f < PXF; ++f) {
+      const int px = px0b + f * 16 + li2;
+      if (px >= p.M) continue;
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+        *reinterpret_cast<float4*>(part + (int64_t)px * C + m * 16 + 4 * g2) = make_float4(y[m][f][0], y[m][f][1], y[m][f][2], y[m][f][3]);
+    }
+    return;
+  }
 #pragma unroll
   for (int f = 0; f < PXF; ++f) {
     const int px = px0b + f * 16 + li2;
@@ -521,10 +541,10 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
 #endif
 }
 
-template <int C, int PXF, int OCC, int GP, bool PRE, bool POST>
+template <int C, int PXF, int OCC, int GP, bool PRE, bool POST, bool SPLIT = false>
 inline void launch_ff_fused_v(const FFParams& p, const void* zero_page, hipStream_t stream) {
   const int LDS = 2 * 128 * C + 8 * p.hidden + 24 * C + 8 * C;  // ring | cs1,b1 | csq,bq | b2,bo
-  auto kern = ff_fused_kernel<C, PXF, OCC, GP, PRE, POST>;
+  auto kern = ff_fused_kernel<C, PXF, OCC, GP, PRE, POST, SPLIT>;
   static int attr_lds[64] = {};   // per device: hipFuncSetAttribute applies to the current device only
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -534,10 +554,18 @@ inline void launch_ff_fused_v(const FFParams& p, const void* zero_page, hipStrea
     attr_lds[dev] = LDS;
   }
   const int tile = 4 * PXF * 16;
-  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(p.M, tile)), dim3(256), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
+  const unsigned ny = SPLIT ? (unsigned)cdiv(p.hidden / 32, p.ch_per) : 1u;
+  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(p.M, tile), ny), dim3(256), LDS, stream, p, reinterpret_cast<const char*>(zero_page));
   WX_HIP(hipGetLastError());
 }
 
+// hidden split (FFParams::partial): the plain block over blockIdx.y chunk ranges; the caller runs conv_gemm_finish_kernel behind it
+inline void launch_ff_fused_split(int c, const FFParams& p, const void* zero_page, hipStream_t stream) {
+  if (!p.partial || p.ch_per < 1 || p.o || p.qkv) throw std::runtime_error("ff_fused split: plain block with a partial buffer only");
+  if (c == 128) launch_ff_fused_v<128, 2, 2, 4, false, false, true>(p, zero_page, stream);
+  else if (c == 256) launch_ff_fused_v<256, 1, 2, 4, false, false, true>(p, zero_page, stream);
+  else throw std::runtime_error("ff_fused split: C must be 128 or 256");
+}
 inline bool ff_fused_supported(int c, int hidden) { return (c == 128 || c == 256) && hidden % 32 == 0 && hidden <= 2048; }
 
 // Register allocation decides these kernels: any scratch reload inside the chunk loop waits on vmcnt, i.e. on the weight
