@@ -706,7 +706,7 @@ class Engine : public EngineBase {
       const int64_t base = off + (npre + ch) * cb;
       for (int r = 0; r < 32; ++r)
         for (int sl = 0; sl < c / 8; ++sl) {
-          const int ks = sl / 4, g = sl % 4, phys = sl ^ (r & 15);
+          const int ks = sl / 4, g = sl % 4, phys = sl ^ (r & (c / 8 < 16 ? c / 8 - 1 : 15));   // (C = 64: 8 slots per row)
           for (int j = 0; j < 8; ++j)
             wt_host[base + (int64_t)r * c + phys * 8 + j] = wt_host[f.w1.wt + (int64_t)(ch * 32 + r) * c + 32 * ks + ff_perm(g, j)];
         }
@@ -735,6 +735,8 @@ class Engine : public EngineBase {
       if (ff_fused_supported(c, 4 * c)) {
         f.pack = pack_ff(f, c, 4 * c);
         if (prev) f.pack_pre = pack_ff(f, c, 4 * c, &prev->out);
+      } else if (ff_plain_supported(c, 4 * c)) {
+        f.pack = pack_ff(f, c, 4 * c);
       }
     }
     return f;
@@ -1460,7 +1462,7 @@ class Engine : public EngineBase {
     const int64_t m = (int64_t)sh[cur_stage] * sw[cur_stage];
     // C = 128 on a launch-bound map (1-degree grid stage 1: 45 workgroups): one launch instead of two wins from 40 workgroups on
     // (724 -> 729 steps/s); C = 256 at 23 workgroups loses (710)
-    if (cfg.dim[cur_stage] == 128) return cdiv(m, 128) >= std::min(ff_min_wgs, 40);
+    if (cfg.dim[cur_stage] == 128 || cfg.dim[cur_stage] == 64) return cdiv(m, 128) >= std::min(ff_min_wgs, 40);
     return cdiv(m, 64) >= ff_min_wgs;
   }
   bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on && ff_big_enough(); }

@@ -258,18 +258,20 @@ __global__ __launch_bounds__(256, OCC) void ff_fused_kernel(const FFParams p, co
     f32x4_t h[2][PXF];
 #pragma unroll
     for (int f = 0; f < PXF; ++f) h[0][f] = h[1][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int KB4 = KS < 4 ? KS : 4;            // K steps per batch (C = 64: two)
+    constexpr int SWZ1 = 4 * KS < 16 ? 4 * KS - 1 : 15;   // a W1 row has 4 KS 16-byte slots: the XOR swizzle stays inside it
 #pragma unroll
-    for (int k0 = 0; k0 < KS; k0 += 4) {
-      uint4 a0[4], a1[4];
+    for (int k0 = 0; k0 < KS; k0 += KB4) {
+      uint4 a0[KB4], a1[KB4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int so = (((k0 + k) * 4 + g) ^ li) * 16;
+      for (int k = 0; k < KB4; ++k) {
+        const int so = (((k0 + k) * 4 + g) ^ (li & SWZ1)) * 16;
         a0[k] = *reinterpret_cast<const uint4*>(cur + w1_off + so);
         a1[k] = *reinterpret_cast<const uint4*>(cur + w1_off + 16 * 2 * C + so);
       }
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < KB4; ++k)
 #pragma unroll
         for (int f = 0; f < PXF; ++f) {
           h[0][f] = mma_sub<bf16_t>(a0[k], xb[k0 + k][f], h[0][f]);
@@ -567,6 +569,7 @@ inline void launch_ff_fused_split(int c, const FFParams& p, const void* zero_pag
   else throw std::runtime_error("ff_fused split: C must be 128 or 256");
 }
 inline bool ff_fused_supported(int c, int hidden) { return (c == 128 || c == 256) && hidden % 32 == 0 && hidden <= 2048; }
+inline bool ff_plain_supported(int c, int hidden) { return ff_fused_supported(c, hidden) || (c == 64 && hidden == 256); }   // C = 64: no to_out / to_qkv variants
 
 // Register allocation decides these kernels: any scratch reload inside the chunk loop waits on vmcnt, i.e. on the weight
 // DMA in flight.  Measured on C3 (4 launches / stage, MI355X): C=128: <2 px-frags, 2 waves/SIMD, 4 GELU pairs> 0.549 ms
@@ -591,6 +594,9 @@ inline void launch_ff_fused(int c, const FFParams& p, const void* zero_page, hip
       case 2: launch_ff_fused_v<256, 2, 2, 2, false, false>(p, zero_page, stream); break;
       default: launch_ff_fused_v<256, 1, 2, 4, false, false>(p, zero_page, stream); break;
     }
+  } else if (c == 64) {   // plain block only (stage 0 of the 1-degree model: 180 workgroups, one launch instead of ff1 + ff2)
+    if (pre || post) throw std::runtime_error("ff_fused: C = 64 has the plain block only");
+    launch_ff_fused_v<64, 2, 2, 4, false, false>(p, zero_page, stream);
   } else {
     throw std::runtime_error("ff_fused: unsupported width");
   }
