@@ -921,6 +921,7 @@ class Engine : public EngineBase {
   const ConvW* gemm_par = nullptr;   // set around a gemm() call: the four parity weight sets of a ConvTranspose k4
   bool split_k = !getenv("WX_NO_SPLIT_K");
   bool embed_merge = !getenv("WX_NO_EMBED_MERGE");
+  bool ff_small_px64 = !(getenv("WX_FF_PX64") && getenv("WX_FF_PX64")[0] == '0');   // C = 128 plain block on 64-pixel tiles when the map yields < 128 tiles of 128 (1-degree stage 1: 21.5 -> 15.5 us)
   int ff_split_tiles = getenv("WX_FF_SPLIT_TILES") ? atoi(getenv("WX_FF_SPLIT_TILES")) : 32;   // pixel tiles, at most
   int ff_split_max = getenv("WX_FF_SPLIT") ? atoi(getenv("WX_FF_SPLIT")) : 8;   // hidden ranges of the split fused FeedForward (0 / 1: off)
   bool attn_pack2 = !getenv("WX_NO_ATTN_PACK2");
@@ -1489,7 +1490,7 @@ class Engine : public EngineBase {
         fp.o = pre ? reinterpret_cast<const bf16_t*>(attn_o) : nullptr; fp.ld_o = c; fp.bo = pre ? f_dev + pre->out.bias : nullptr;
         fp.cs1 = f_dev + f.w1.colsum; fp.b1 = f_dev + f.w1.bias; fp.b2 = f_dev + f.w2.bias;
         fp.stat_out = fuse_ln ? statpart : nullptr; fp.dbg = ff_dbg;
-        timed(post ? "out_ff_qkv_fused" : pre ? "out_ff_fused" : "ff_fused", (post ? 24.0 : pre ? 18.0 : 16.0) * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] { launch_ff_fused(c, fp, zero_page, cur_stream, ff_variant); });
+        timed(post ? "out_ff_qkv_fused" : pre ? "out_ff_fused" : "ff_fused", (post ? 24.0 : pre ? 18.0 : 16.0) * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] { launch_ff_fused(c, fp, zero_page, cur_stream, (c == 128 && !pre && ff_small_px64 && cdiv(m, 128) < 128) ? 3 : ff_variant); });
         stat_tiles_ready = fuse_ln ? 1 : 0;
         capture(dbg_name, x, h, w, c, ld, w);
         return;

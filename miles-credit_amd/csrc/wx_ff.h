@@ -584,6 +584,7 @@ inline void launch_ff_fused(int c, const FFParams& p, const void* zero_page, hip
     switch (variant) {
       case 1: launch_ff_fused_v<128, 2, 2, 8, false, false>(p, zero_page, stream); break;
       case 2: launch_ff_fused_v<128, 2, 3, 2, false, false>(p, zero_page, stream); break;
+      case 3: launch_ff_fused_v<128, 1, 2, 4, false, false>(p, zero_page, stream); break;   // 64 pixels per workgroup (launch-bound maps)
       default: launch_ff_fused_v<128, 2, 2, 4, false, false>(p, zero_page, stream); break;
     }
   } else if (c == 256) {
@@ -596,7 +597,7 @@ inline void launch_ff_fused(int c, const FFParams& p, const void* zero_page, hip
     }
   } else if (c == 64) {   // plain block only (stage 0 of the 1-degree model: 180 workgroups, one launch instead of ff1 + ff2)
     if (pre || post) throw std::runtime_error("ff_fused: C = 64 has the plain block only");
-    launch_ff_fused_v<64, 2, 2, 4, false, false>(p, zero_page, stream);
+    launch_ff_fused_v<64, 2, 2, 4, false, false>(p, zero_page, stream);   // (64 pixels per workgroup: +0.5 %, 256: -2 % on the 1-degree model)
   } else {
     throw std::runtime_error("ff_fused: unsupported width");
   }
