@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary BASELINE-config-2 (1-degree, 24-step rollout) measurement")
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary exact-f32 measurement (the mode whose outputs meet "
                                                             "the stated fp32 tolerance against the reference)")
+    ap.add_argument("--no-host-delivery", action="store_true", help="skip the PCIe-inclusive measurement (every step's output delivered to pinned host memory)")
     ap.add_argument("--per-step-calls", action="store_true", help="drive the loop with one wx_step call per step from Python "
                                                                   "instead of one wx_rollout call for the K steps")
     ap.add_argument("--latband", action="store_true",
@@ -68,6 +69,10 @@ def main():
     # WX_BENCH_BACKEND=gloo: functional check of the multi-process paths on a box with fewer GPUs than ranks (ranks then
     # share devices and timings mean nothing); the real runs use RCCL ("nccl"), one rank per GPU
     backend = os.environ.get("WX_BENCH_BACKEND", "nccl")
+    # started without torchrun: this process becomes the launcher of the N ranks (and exits with their code); `--gpus N` on a node
+    # with fewer GPUs fails loudly instead of running one rank (reference: rank discovery credit/distributed.py:193-292)
+    from wxengine.replicas import ensure_ranks
+    ensure_ranks(args.gpus, backend, [os.path.abspath(__file__), *sys.argv[1:]])
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
@@ -125,6 +130,40 @@ def main():
     elapsed = grp.timed(timed_work, torch.cuda.synchronize)
     x_cur, x_nxt = state["x"]
     finite = bool(torch.isfinite(y_phys).all().item())
+
+    host_delivery = None
+    if rank == 0 and world == 1 and not args.no_host_delivery:
+        # What the reference's loop does with every step's output (rollout_to_netcdf.py:289-301: y_pred_phys.cpu().numpy() handed to the
+        # writer pool): the PCIe-INCLUSIVE rate, never `value`.  Pinned ring + copy stream (wxengine.output.HostDelivery: step t computes
+        # while step t-1 crosses PCIe), and beside it the reference's own form -- a blocking pageable copy per step on the same engine.
+        from wxengine.output import HostDelivery
+        hd = HostDelivery(eng, x_cur, slots=2)
+        nh = max(2, min(args.steps, 20))
+        seen = []
+        hd.run(x_cur, [frcs[t % n_frc] for t in range(3)], lambda i, a: seen.append(float(a[0, 0, 0, 0])))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        hd.run(x_cur, [frcs[t % n_frc] for t in range(nh)], lambda i, a: seen.append(float(a[0, 0, 0, 0])))
+        torch.cuda.synchronize()
+        eh = time.perf_counter() - t1
+        nb = max(2, min(args.steps, 5))
+        xs_, xn_ = x_cur, x_nxt
+        eng.step(xs_, frcs[0], want_y=False, phys_out=y_phys, next_out=xn_)
+        y_phys.cpu().numpy()
+        t1 = time.perf_counter()
+        for t in range(nb):
+            eng.step(xs_, frcs[t % n_frc], want_y=False, phys_out=y_phys, next_out=xn_)
+            y_phys.cpu().numpy()
+            xs_, xn_ = xn_, xs_
+        eb = (time.perf_counter() - t1) / nb
+        host_delivery = {"value": round(nh / eh, 3), "unit": "forecast-steps/sec", "steps": nh, "ms_per_step": round(1e3 * eh / nh, 3),
+                         "output_MB_per_step": round(hd.bytes_per_step / 1e6, 1), "d2h_GBps": round(nh * hd.bytes_per_step / eh / 1e9, 2),
+                         "blocking_copy_per_step": {"value": round(1.0 / eb, 3), "ms_per_step": round(1e3 * eb, 3), "steps": nb,
+                                                    "what": "y_phys.cpu().numpy() after every step (rollout_to_netcdf.py:292), same engine"},
+                         "finite_outputs": bool(np.isfinite(seen).all()),
+                         "note": "PCIe-inclusive: every step's de-normalised output lands in pinned host memory (2-slot ring, copy stream "
+                                 "overlapped with the next step's compute; one wx_step call per step); PCIe Gen5 x16 = 63 GB/s spec"}
+        del hd
 
     roofline = None
     if rank == 0 and not args.no_roofline:
@@ -309,7 +348,7 @@ def main():
                        "parallelism": f"replicas over init times x{world} (no data-path collective)",
                        "loop": "one wx_step call per step" if args.per_step_calls else "wx_rollout (the K steps in one C-ABI call)",
                        "total_steps": total_steps, "params": cfg.num_params(), "finite_outputs": finite},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "fp32": fp32, "config2": config2, "config5": config5,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "fp32": fp32, "host_delivery": host_delivery, "config2": config2, "config5": config5,
         }
         print(json.dumps(out), flush=True)
     grp.close()

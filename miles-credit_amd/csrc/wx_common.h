@@ -53,7 +53,7 @@ inline uint16_t f2h_bits(float f) {
   const int32_t e = (int32_t)((u >> 23) & 0xff) - 127 + 15;
   uint32_t m = u & 0x7fffffu;
   if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0u));
-  if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (e >= 31) return (uint16_t)(sign | 0x7bffu);   // finite overflow saturates at +-65504 (the f16 operands of wx_ff.h must stay finite)
   if (e <= 0) {
     if (e < -10) return (uint16_t)sign;
     m |= 0x800000u;
@@ -66,6 +66,7 @@ inline uint16_t f2h_bits(float f) {
   uint32_t h = ((uint32_t)e << 10) | (m >> 13);
   const uint32_t rem = m & 0x1fffu;
   if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+  if (h >= 0x7c00u) h = 0x7bffu;   // a round-up out of the finite range saturates too
   return (uint16_t)(sign | h);
 }
 
@@ -162,6 +163,10 @@ __device__ inline void gelu_fast_pairs(f32x2_t* v) {
 // consumers that take the result as an f16 MFMA operand: 4.5 VALU + 2 transcendental per element instead of 7 + 2, and no f32 -> bf16
 // pack behind it.  f16 carries 11 significand bits against bf16's 8, so the hidden activations lose LESS than in the bf16 form; the
 // sigmoid saturates cleanly (exp2 overflows to inf -> rcp 0; underflows to 0 -> 1).
+// Range: the f32 -> f16 conversion is v_cvt_pkrtz_f16_f32 (round toward zero), which SATURATES at +-65504 instead of producing inf: a
+// pre-activation beyond the f16 range (possible with trained weights; the bf16 form of rounds 1-2 was finite there) becomes
+// x = -65504 -> -65504 * 0 = -0, or x = +65504 -> 65504 * 1, never -inf * 0 = NaN.  Round-toward-zero costs half an f16 ulp (2^-12
+// relative) against round-to-nearest -- 1/16 of the bf16 rounding this operand had before (tests: weight family "stress_hi").
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 template <int NP>
 __device__ inline void gelu_fast_pairs_f16(const f32x2_t* v, uint32_t* out) {
@@ -170,7 +175,7 @@ __device__ inline void gelu_fast_pairs_f16(const f32x2_t* v, uint32_t* out) {
   const f16x2_t c2 = {(_Float16)1.014263058e-03f, (_Float16)1.014263058e-03f}, c1 = {(_Float16)-1.067757239e-01f, (_Float16)-1.067757239e-01f},
                 c0 = {(_Float16)-2.301121342e+00f, (_Float16)-2.301121342e+00f}, one = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
-  for (int i = 0; i < NP; ++i) x[i] = __builtin_convertvector(v[i], f16x2_t);
+  for (int i = 0; i < NP; ++i) x[i] = __builtin_bit_cast(f16x2_t, __builtin_amdgcn_cvt_pkrtz(v[i].x, v[i].y));
 #pragma unroll
   for (int i = 0; i < NP; ++i) xc[i] = __builtin_elementwise_min(__builtin_elementwise_max(x[i], lo), hi);
 #pragma unroll

@@ -67,29 +67,42 @@ class PinnedOutputRing:
         return len(self._pending)
 
 
-def rollout_to_host(engine, x0: torch.Tensor, forcings, consume, slots: int = 2) -> int:
-    """The reference's loop (rollout_to_netcdf.py:274-310) with each step's physical-space output handed to
-    `consume(step_index, host_array [1, C_out, H, W])` -- e.g. the NetCDF worker pool -- from pinned memory: while the host
-    consumes step t-2 and step t-1 crosses PCIe, the engine computes step t.  `host_array` is a view of a ring slot, valid
-    until `consume` returns.  forcings[t] feeds the input of step t+2 (None on the last step).  Returns the number of steps."""
-    n = len(forcings)
-    cfg = engine.cfg
-    oh, ow = cfg.out_hw
-    dev = [torch.empty((1, cfg.base_output_channels, oh, ow), dtype=torch.float32, device=x0.device) for _ in range(slots)]
-    xb = [torch.empty_like(x0), torch.empty_like(x0)]
-    ring = PinnedOutputRing(tuple(dev[0].shape), slots, x0.device)
-    x, consumed = x0, 0
-    for t in range(n):
-        if len(ring) == slots:  # slot t % slots (pinned AND device buffer) is about to be reused: drain step t - slots
+class HostDelivery:
+    """The reference's loop (rollout_to_netcdf.py:274-310) with each step's physical-space output handed to the host from pinned
+    memory: while the host consumes step t-2 and step t-1 crosses PCIe, the engine computes step t.  Owns the pinned ring, the device
+    output slots and the ping-pong state buffers, so repeated runs (one per init time) allocate nothing."""
+
+    def __init__(self, engine, x_like: torch.Tensor, slots: int = 2):
+        cfg = engine.cfg
+        oh, ow = cfg.out_hw
+        self.engine, self.slots = engine, slots
+        self.dev = [torch.empty((1, cfg.base_output_channels, oh, ow), dtype=torch.float32, device=x_like.device) for _ in range(slots)]
+        self.xb = [torch.empty_like(x_like), torch.empty_like(x_like)]
+        self.ring = PinnedOutputRing(tuple(self.dev[0].shape), slots, x_like.device)
+        self.bytes_per_step = self.dev[0].numel() * 4
+
+    def run(self, x0: torch.Tensor, forcings, consume) -> int:
+        """`consume(step_index, host_array [1, C_out, H, W])` -- e.g. the NetCDF worker pool; `host_array` is a view of a ring slot,
+        valid until `consume` returns.  forcings[t] feeds the input of step t+2 (None on the last step).  Returns the number of steps."""
+        n = len(forcings)
+        ring, slots = self.ring, self.slots
+        x, consumed = x0, 0
+        for t in range(n):
+            if len(ring) == slots:  # slot t % slots (pinned AND device buffer) is about to be reused: drain step t - slots
+                consume(consumed, ring.pop())
+                consumed += 1
+            want_next = t < n - 1 or forcings[t] is not None
+            _y, yp, xn = self.engine.step(x, forcings[t], want_y=False, want_phys=True, want_next=want_next, phys_out=self.dev[t % slots],
+                                          next_out=self.xb[t % 2] if want_next else None)
+            ring.push(yp)
+            if xn is not None:
+                x = xn
+        while len(ring):
             consume(consumed, ring.pop())
             consumed += 1
-        want_next = t < n - 1 or forcings[t] is not None
-        _y, yp, xn = engine.step(x, forcings[t], want_y=False, want_phys=True, want_next=want_next, phys_out=dev[t % slots],
-                                 next_out=xb[t % 2] if want_next else None)
-        ring.push(yp)
-        if xn is not None:
-            x = xn
-    while len(ring):
-        consume(consumed, ring.pop())
-        consumed += 1
-    return n
+        return n
+
+
+def rollout_to_host(engine, x0: torch.Tensor, forcings, consume, slots: int = 2) -> int:
+    """One-shot form of HostDelivery.run (allocates the ring and the buffers for this call)."""
+    return HostDelivery(engine, x0, slots).run(x0, forcings, consume)

@@ -8,8 +8,76 @@ any rollout driver) brackets the timed region with a barrier on both sides and r
 from __future__ import annotations
 
 import os
+import socket
+import subprocess
+import sys
 import time
 from typing import Callable, List, Optional, Sequence
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv: Sequence[str], extra_env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
+    """Start `n` copies of `python argv...` on this node, one per rank, with the environment torchrun would give them (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT) -- what the reference gets from its launcher through
+    credit/distributed.py:193-292 (rank discovery from the environment).  Rank 0 inherits stdout (the one JSON line of bench.py); if any
+    rank fails the others are terminated (by PID) and the first non-zero exit code is returned."""
+    env0 = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n))
+    env0.update(extra_env or {})
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, *argv], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, t0 = 0, time.time()
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if rc != 0 or (timeout is not None and time.time() - t0 > timeout):
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            if rc == 0:
+                rc = 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def ensure_ranks(n_gpus: int, backend: str, argv: Optional[Sequence[str]] = None) -> None:
+    """`bench.py --gpus N` (or any driver) started WITHOUT a launcher: become the launcher.  With RANK already in the environment
+    (torchrun, or a child of this function) it only checks WORLD_SIZE against N.  Fails loudly -- never silently runs one rank -- when
+    the node has fewer GPUs than ranks (the RCCL backend needs one device per rank; WX_BENCH_BACKEND=gloo lets ranks share a device
+    for functional checks)."""
+    if "RANK" in os.environ:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != n_gpus:
+            raise SystemExit(f"--gpus {n_gpus} but the launcher started WORLD_SIZE={world} ranks")
+        return
+    if n_gpus <= 1:
+        return
+    if backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n_gpus:
+            raise SystemExit(f"--gpus {n_gpus}: this node has {have} GPU(s); one rank per GPU is required over RCCL "
+                             f"(set WX_BENCH_BACKEND=gloo for a functional check with shared devices)")
+    raise SystemExit(launch_ranks(n_gpus, list(argv if argv is not None else sys.argv)))
 
 
 class ReplicaGroup:
@@ -76,3 +144,32 @@ class ReplicaGroup:
         if self.dist is not None:
             self.dist.destroy_process_group()
             self.dist = None
+
+
+def _selftest(argv: Sequence[str]) -> None:
+    """`python -m wxengine.replicas --gpus N [--steps K]`: the harness alone (no engine, no GPU) through the same entry sequence as
+    bench.py -- ensure_ranks -> ReplicaGroup -> timed region -> rank 0 prints one JSON line.  tests/test_dist_cpu.py runs it."""
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    args = ap.parse_args(list(argv))
+    backend = os.environ.get("WX_BENCH_BACKEND", "nccl")
+    ensure_ranks(args.gpus, backend, ["-m", "wxengine.replicas", *argv])
+    grp = ReplicaGroup(backend=backend, n_expected=args.gpus)
+    done = []
+
+    def work():
+        for t in range(args.steps):
+            time.sleep(0.01 * (1 + grp.rank))
+            done.append(t)
+    elapsed = grp.timed(work, lambda: None)
+    if grp.rank == 0:
+        print(json.dumps({"n_gpus": grp.world, "steps": args.steps, "value": grp.throughput(len(done), elapsed),
+                          "mine": grp.my_share(list(range(5)))}), flush=True)
+    grp.close()
+
+
+if __name__ == "__main__":
+    _selftest(sys.argv[1:])

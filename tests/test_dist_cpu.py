@@ -1,7 +1,10 @@
 """world_size-2 gloo test of the N>1 path: the SAME harness object `bench.py --gpus N` times its rollout with
 (wxengine.replicas.ReplicaGroup: init-time sharding, barrier-bracketed region, MAX-over-ranks clock, aggregate throughput)."""
+import json
 import os
 import socket
+import subprocess
+import sys
 import time
 
 import torch.multiprocessing as mp
@@ -65,3 +68,41 @@ def test_single_process_identity(monkeypatch):
     e = grp.timed(lambda: calls.append("work"), lambda: calls.append("sync"))
     assert calls == ["sync", "work", "sync", "sync"] and e >= 0
     assert grp.throughput(40, 2.0) == 20.0
+
+
+_PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miles-credit_amd")
+
+
+def _run_selftest(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e.update(PYTHONPATH=_PKG + os.pathsep + e.get("PYTHONPATH", ""), **env)
+    return subprocess.run([sys.executable, "-m", "wxengine.replicas", *args], env=e, capture_output=True, text=True, timeout=180)
+
+
+def test_gpus_n_without_a_launcher_spawns_n_ranks():
+    """`--gpus 2` with RANK unset: the process becomes the launcher (wxengine.replicas.ensure_ranks, the first thing bench.py calls),
+    two gloo ranks run the harness, rank 0 prints ONE line with n_gpus = 2 -- not a silent single-rank run (missing #3)."""
+    r = _run_selftest(["--gpus", "2", "--steps", "3"], WX_BENCH_BACKEND="gloo")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["mine"] == [0, 2, 4] and out["value"] > 0
+
+
+def test_gpus_n_on_a_node_with_fewer_gpus_fails_loudly():
+    r = _run_selftest(["--gpus", "64"], WX_BENCH_BACKEND="nccl")   # no node has 64 GPUs
+    assert r.returncode != 0 and "--gpus 64" in r.stderr and "GPU(s)" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_world_size_mismatch_under_an_external_launcher_is_rejected():
+    r = _run_selftest(["--gpus", "4"], WX_BENCH_BACKEND="gloo", RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_PORT=str(_free_port()))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_a_failing_rank_takes_the_job_down():
+    from wxengine.replicas import launch_ranks
+    t0 = time.time()
+    rc = launch_ranks(2, ["-c", "import os, sys, time; sys.exit(3) if os.environ['RANK'] == '1' else time.sleep(60)"])
+    assert rc == 3 and time.time() - t0 < 30

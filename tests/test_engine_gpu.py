@@ -87,6 +87,56 @@ def test_c1_vs_oracle_and_reference_golden(name, prec):
     check(y[0, :, 0, ::s, ::s].numpy(), g["y"], prec)
 
 
+def _stress_engine(name, prec, family):
+    cfg = named_config(name)
+    eng = WXEngine(cfg, prec, 0)
+    eng.load_state_dict(synth_state_dict(cfg, family=family))
+    eng.finalize()
+    return cfg, eng
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["T0", "T1", "C1"])
+def test_stress_weights_vs_reference_golden(name, prec):
+    """Weight family "stress" (wxengine.synth.FAMILIES): softmax logits of +-40 and more, FeedForward pre-GELU magnitudes of ~1e2,
+    one-sign conv biases in front of the first LayerNorm and of every second GroupNorm.  SAME gates as the base family:
+    fp32 1e-4 * max|y|, bf16 rel-L2 2e-2.  Golden = the reference's fp32 CPU forward (tools/make_goldens.py --only stress)."""
+    cfg, eng = _stress_engine(name, prec, "stress")
+    y = eng.forward(torch.from_numpy(synth_input(cfg)).cuda()).cpu()
+    g = np.load(os.path.join(GOLD, f"model_{name}_stress.npz"))
+    s = int(g["stride"])
+    check(y[0, :, 0, ::s, ::s].numpy(), g["y"], prec)
+
+
+@pytest.mark.parametrize("name", ["T0", "T1", "C1"])
+def test_stress_hi_fp32_vs_reference_golden(name):
+    """Weight family "stress_hi": LayerNorm rows (stage 0) and GroupNorm groups with |mean| / sigma of 100-240 -- where a one-pass
+    variance sum(x^2)/C - mean^2 cancels -- and one FeedForward hidden unit per layer at 7e4.  fp32 engine, the stated fp32 gate."""
+    cfg, eng = _stress_engine(name, "fp32", "stress_hi")
+    y = eng.forward(torch.from_numpy(synth_input(cfg)).cuda()).cpu()
+    g = np.load(os.path.join(GOLD, f"model_{name}_stress_hi.npz"))
+    s = int(g["stride"])
+    check(y[0, :, 0, ::s, ::s].numpy(), g["y"], "fp32")
+
+
+@pytest.mark.parametrize("name", ["T0", "T1", "C1"])
+def test_stress_hi_bf16_stays_finite_and_bounded(name, monkeypatch):
+    """The same family on the bf16 engine.  A bf16 residual stream at |mean| / sigma = r carries r * 2^-8 / sqrt(12) of rounding noise
+    per normalised element BEFORE any kernel touches it (r = 100-200 here: 10-20 %), so the 2e-2 gate is out of reach by construction of
+    the storage format, not of a kernel; what must hold: finite output (the 7e4 hidden unit is beyond f16, which the fused FeedForward
+    kernels use for their hidden activations -- they saturate instead of producing inf * 0), and an error bounded by that noise."""
+    monkeypatch.setenv("WX_FF_MIN_WGS", "0")   # force the fused (f16-hidden) FeedForward kernels onto these small maps
+    cfg, eng = _stress_engine(name, "bf16", "stress_hi")
+    y = eng.forward(torch.from_numpy(synth_input(cfg)).cuda()).cpu()
+    assert torch.isfinite(y).all()
+    g = np.load(os.path.join(GOLD, f"model_{name}_stress_hi.npz"))
+    s = int(g["stride"])
+    ys = y[0, :, 0, ::s, ::s].numpy().astype(np.float64)
+    l2 = np.linalg.norm(ys - g["y"]) / np.linalg.norm(g["y"])
+    print(f"stress_hi {name} bf16 rel-L2 {l2:.3e}")
+    assert l2 <= 0.5
+
+
 def test_step_with_two_interleaved_sources():
     """wx_set_layout_groups: the next input is assembled per (source, field type) group -- prognostic channels of two sources
     come from non-adjacent blocks of y (each source's diagnostics sit in between), forcing channels from one forcing tensor,

@@ -59,6 +59,29 @@ def test_mirror_pad_matches_reference():
 _SLOW = os.environ.get("WX_SLOW", "0") == "1"
 
 
+@pytest.mark.parametrize("family", ["stress", "stress_hi"])
+@pytest.mark.parametrize("name", ["T0", "T1", "C1"])
+def test_stress_weight_families_match_reference_golden(name, family):
+    """The stress weight families of wxengine.synth (logits of +-40, pre-GELU 1e2, LayerNorm / GroupNorm inputs with |mean| / sigma of
+    100-240, a hidden unit beyond the f16 range) through the REAL reference (tools/make_goldens.py --only stress) vs the oracle."""
+    g = _load(f"model_{name}_{family}.npz")
+    cfg = named_config(name)
+    y = O.forward(cfg, synth_state_dict(cfg, family=family), synth_input(cfg))
+    s = int(g["stride"])
+    scale = float(np.abs(g["y"]).max())
+    assert np.abs(y[0, :, 0, ::s, ::s].numpy() - g["y"]).max() <= 2e-5 * scale
+
+
+def test_stress_families_differ_from_base_only_where_documented():
+    cfg = named_config("T0")
+    base, st, hi = (synth_state_dict(cfg, family=f) for f in ("base", "stress", "stress_hi"))
+    assert list(base) == list(st) == list(hi)
+    changed = {k for k in base if not np.array_equal(base[k], st[k])}
+    assert changed and all(k.endswith((".bias", ".g", ".weight_u", ".weight_v")) or ".0.convs." in k for k in changed)
+    k1 = "layers.0.1.layers.0.1.layers.1.bias"
+    assert hi[k1][3] == 7.0e4 and st[k1][3] == base[k1][3]
+
+
 @pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W", "T0U", "T0M", "T0F", "RT",
                                   pytest.param("C3", marks=pytest.mark.skipif(
                                       not _SLOW, reason="~1.5 min of CPU; set WX_SLOW=1"))])

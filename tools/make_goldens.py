@@ -31,7 +31,7 @@ from wxengine.synth import synth_denorm, synth_forcing, synth_input, synth_state
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def reference_model(cfg, post_conf=None):
+def reference_model(cfg, post_conf=None, family="base"):
     if getattr(cfg, "arch", "crossformer") == "wxformer":
         from credit.models.wxformer.crossformer import CrossFormer
     else:
@@ -47,7 +47,7 @@ def reference_model(cfg, post_conf=None):
         padding_conf={"activate": cfg.pad_activate, "mode": getattr(cfg, "pad_mode", "earth"), "pad_lat": list(cfg.pad_lat),
                       "pad_lon": list(cfg.pad_lon)},
         post_conf=post_conf or {"activate": False})
-    sd = synth_state_dict(cfg)
+    sd = synth_state_dict(cfg, family=family)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     m.eval()
     return m
@@ -59,10 +59,11 @@ def channel_stats(y):
     return (a.sum(dim=(1, 2)).numpy(), (a * a).sum(dim=(1, 2)).numpy(), a.abs().amax(dim=(1, 2)).numpy())
 
 
-def model_golden(name, stride, capture_layers):
+def model_golden(name, stride, capture_layers, family="base"):
+    """family != base: the stress weight families of wxengine.synth -> model_<name>_<family>.npz"""
     cfg = named_config(name)
     torch.manual_seed(0)
-    m = reference_model(cfg)
+    m = reference_model(cfg, family=family)
     x = torch.from_numpy(synth_input(cfg))
     caps = {}
     hooks = []
@@ -86,8 +87,8 @@ def model_golden(name, stride, capture_layers):
     out["y"] = y[0, :, 0, ::stride, ::stride].numpy().astype(np.float32)
     for n, v in caps.items():
         out["cap/" + n] = v[0].numpy().astype(np.float32)
-    np.savez_compressed(os.path.join(GOLD, f"model_{name}.npz"), **out)
-    print(f"[golden] {name}: forward {dt:.2f}s  mean|y|={y.abs().mean():.4f} max|y|={y.abs().max():.4f}  "
+    np.savez_compressed(os.path.join(GOLD, f"model_{name}.npz" if family == "base" else f"model_{name}_{family}.npz"), **out)
+    print(f"[golden] {name} ({family}): forward {dt:.2f}s  mean|y|={y.abs().mean():.4f} max|y|={y.abs().max():.4f}  "
           f"y sample {out['y'].shape}")
 
 
@@ -761,7 +762,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,fuxi,attend,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,T0F,RT")
+    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,fuxi,attend,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,T0F,RT,stress")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -810,6 +811,11 @@ def main():
             model_golden(item, 8, False)
         elif item in ("C3S", "C3"):
             model_golden(item, 16, False)
+        elif item == "stress":   # the stress weight families (wxengine.synth.FAMILIES) through the reference: T0 / T1 full maps, C1 strided
+            for fam in ("stress", "stress_hi"):
+                model_golden("T0", 1, False, family=fam)
+                model_golden("T1", 1, False, family=fam)
+                model_golden("C1", 8, False, family=fam)
         else:
             raise SystemExit(f"unknown item {item}")
 
