@@ -99,13 +99,24 @@ def _stress_engine(name, prec, family):
 @pytest.mark.parametrize("name", ["T0", "T1", "C1"])
 def test_stress_weights_vs_reference_golden(name, prec):
     """Weight family "stress" (wxengine.synth.FAMILIES): softmax logits of +-40 and more, FeedForward pre-GELU magnitudes of ~1e2,
-    one-sign conv biases in front of the first LayerNorm and of every second GroupNorm.  SAME gates as the base family:
-    fp32 1e-4 * max|y|, bf16 rel-L2 2e-2.  Golden = the reference's fp32 CPU forward (tools/make_goldens.py --only stress)."""
+    one-sign conv biases in front of the first LayerNorm and of every second GroupNorm.  Golden = the reference's fp32 CPU forward
+    (tools/make_goldens.py --only stress).  fp32 engine: the SAME gate as the base family, 1e-4 * max|y| (measured 4e-6 .. 1.1e-5).
+    bf16 engine: with LayerNorm gains of 8 / 60 every sub-block's update dwarfs the stream it is added to, so bf16 rounding is renewed,
+    not damped, layer by layer: the REFERENCE ITSELF under torch.autocast(bfloat16) sits 3.1e-2 .. 3.5e-2 (rel-L2) from its own fp32
+    output on this family (0.84e-2 .. 0.90e-2 on the base family; stored in the fixture as bf16_autocast_l2).  Gate: the engine must be
+    at least as close as that, and inside 3e-2 (measured 1.9e-2 .. 2.4e-2; base family: 0.75e-2 .. 0.81e-2 under the 2e-2 gate)."""
     cfg, eng = _stress_engine(name, prec, "stress")
     y = eng.forward(torch.from_numpy(synth_input(cfg)).cuda()).cpu()
     g = np.load(os.path.join(GOLD, f"model_{name}_stress.npz"))
     s = int(g["stride"])
-    check(y[0, :, 0, ::s, ::s].numpy(), g["y"], prec)
+    ys = y[0, :, 0, ::s, ::s].numpy()
+    if prec == "fp32":
+        check(ys, g["y"], prec)
+        return
+    assert np.isfinite(ys).all()
+    l2 = np.linalg.norm(ys.astype(np.float64) - g["y"]) / np.linalg.norm(g["y"])
+    print(f"stress {name} bf16 rel-L2 {l2:.3e} (reference under bf16 autocast: {float(g['bf16_autocast_l2']):.3e})")
+    assert l2 <= 3e-2 and l2 <= float(g["bf16_autocast_l2"])
 
 
 @pytest.mark.parametrize("name", ["T0", "T1", "C1"])
@@ -133,8 +144,10 @@ def test_stress_hi_bf16_stays_finite_and_bounded(name, monkeypatch):
     s = int(g["stride"])
     ys = y[0, :, 0, ::s, ::s].numpy().astype(np.float64)
     l2 = np.linalg.norm(ys - g["y"]) / np.linalg.norm(g["y"])
-    print(f"stress_hi {name} bf16 rel-L2 {l2:.3e}")
-    assert l2 <= 0.5
+    print(f"stress_hi {name} bf16 rel-L2 {l2:.3e} (reference under bf16 autocast: {float(g['bf16_autocast_l2']):.3e})")
+    # measured 4.4e-3 .. 5.6e-3 (the reference under torch.autocast(bf16): 4.9e-3 .. 5.7e-3): y is dominated by the decoder's one-sign
+    # biases here, so the END-TO-END metric does not see the stage-0 stream noise (tools/stress_report.py prints it layer by layer)
+    assert l2 <= 2e-2
 
 
 def test_step_with_two_interleaved_sources():

@@ -73,6 +73,75 @@ def test_wx_rollout_is_bit_identical_to_a_loop_of_wx_step(name, prec, graph, mon
     assert torch.equal(ring[0], want[-1]) and torch.equal(xf2, x_last)
 
 
+def test_captured_step_graphs_are_dropped_when_the_step_glue_changes(monkeypatch):
+    """ADVICE round 2 (graph invalidation): with WX_GRAPH=1 the second rollout call captures one hipGraph per step shape; the captured
+    kernels carry the de-normalisation vectors / tracer thresholds / channel map BY POINTER CONTENT at capture time.  Changing any of
+    them afterwards must drop the cache (roll_invalidate) -- a stale replay would silently keep the old constants."""
+    monkeypatch.setenv("WX_GRAPH", "1")
+    cfg, eng = make_engine("T0", "fp32", tracer=(list(range(9, 12)), [-0.05] * 3))
+    x0 = torch.from_numpy(synth_input(cfg)).cuda()
+    frcs = [torch.from_numpy(synth_forcing(cfg, 2, t + 1)).cuda() for t in range(3)]
+    outs = [torch.empty((1, cfg.base_output_channels) + tuple(cfg.out_hw), device="cuda") for _ in range(3)]
+    xf = torch.empty_like(x0)
+    for _ in range(3):                                   # eager, capture, replay
+        eng.rollout(x0, frcs, outs, x_final=xf)
+    before = [o.clone() for o in outs]
+
+    def loop_of_steps():
+        want, x = [], x0
+        for t in range(3):
+            _, yp, x = eng.step(x, frcs[t], want_y=False)
+            want.append(yp.clone())
+        return want, x
+
+    mean, std = synth_denorm(cfg.base_output_channels)
+    eng.set_denorm(mean + 1.0, std * 2.0)               # 1: new de-normalisation
+    eng.rollout(x0, frcs, outs, x_final=xf)
+    want, xl = loop_of_steps()
+    assert all(torch.equal(a, b) for a, b in zip(outs, want)) and torch.equal(xf, xl)
+    assert not torch.equal(outs[0], before[0])
+    for _ in range(2):
+        eng.rollout(x0, frcs, outs, x_final=xf)          # re-capture with the new constants
+    eng.set_tracer_fixer(list(range(9, 12)), [0.25] * 3, None, denorm=False)   # 2: new tracer thresholds
+    eng.rollout(x0, frcs, outs, x_final=xf)
+    want, xl = loop_of_steps()
+    assert all(torch.equal(a, b) for a, b in zip(outs, want)) and torch.equal(xf, xl)
+    for _ in range(2):
+        eng.rollout(x0, frcs, outs, x_final=xf)
+    eng.set_layout(cfg.channels * cfg.levels + cfg.surface_channels - 1, 3, 2)   # 3: another channel layout
+    eng.rollout(x0, frcs, outs, x_final=xf)
+    want, xl = loop_of_steps()
+    assert all(torch.equal(a, b) for a, b in zip(outs, want)) and torch.equal(xf, xl)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_step_outputs_at_addresses_that_are_not_16_byte_aligned(prec):
+    """ADVICE round 2 (tail alignment): a raw C-ABI caller may hand wx_step output pointers that are only 4-byte aligned (an offset view
+    of a larger allocation); the tail kernel's 16-byte store path must not be taken then.  Same bits as with aligned outputs."""
+    cfg, eng = make_engine("T0", prec, tracer=(list(range(9, 12)), [-0.05] * 3))
+    assert cfg.image_width % 4 == 0                      # the configuration that would take the 16-byte path
+    x0 = torch.from_numpy(synth_input(cfg)).cuda()
+    frc = torch.from_numpy(synth_forcing(cfg, 2, 1)).cuda()
+    y, yp, xn = eng.step(x0, frc)
+
+    def off_view(like, k):
+        buf = torch.full((like.numel() + 4,), float("nan"), device="cuda")
+        v = buf[k:k + like.numel()].view(like.shape)
+        assert v.data_ptr() % 16 == 4 * k and v.is_contiguous()
+        return buf, v
+
+    for k in (1, 2, 3):
+        (by, vy), (bp, vp), (bx, vx) = off_view(y, k), off_view(yp, k), off_view(xn, k)
+        eng.step(x0, frc, y_out=vy, phys_out=vp, next_out=vx)
+        assert torch.equal(vy, y) and torch.equal(vp, yp) and torch.equal(vx, xn)
+        for b, v in ((by, vy), (bp, vp), (bx, vx)):     # nothing written outside the views
+            assert torch.isnan(b[:k]).all() and torch.isnan(b[k + v.numel():]).all()
+    # only ONE of the three unaligned: the check must be per launch, not per pointer
+    bp, vp = off_view(yp, 1)
+    y2, _, xn2 = eng.step(x0, frc, phys_out=vp)
+    assert torch.equal(vp, yp) and torch.equal(y2, y) and torch.equal(xn2, xn)
+
+
 def test_wx_rollout_argument_errors():
     from wxengine.engine import WXEngineError
     cfg, eng = make_engine("T0", "fp32")

@@ -87,6 +87,13 @@ def model_golden(name, stride, capture_layers, family="base"):
     out["y"] = y[0, :, 0, ::stride, ::stride].numpy().astype(np.float32)
     for n, v in caps.items():
         out["cap/" + n] = v[0].numpy().astype(np.float32)
+    if family != "base":
+        # what bf16 ARITHMETIC costs on this family, measured on the reference itself: the same module under torch.autocast(bfloat16)
+        # against its own fp32 output.  The bf16 engine is gated against this number (it must not be worse than the framework's own bf16).
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            y16 = m(x).float()
+        out["bf16_autocast_l2"] = np.float64((y16 - y).norm() / y.norm())
+        print(f"[golden] {name} ({family}): reference under torch.autocast(bf16) vs its own fp32: rel-L2 {out['bf16_autocast_l2']:.3e}")
     np.savez_compressed(os.path.join(GOLD, f"model_{name}.npz" if family == "base" else f"model_{name}_{family}.npz"), **out)
     print(f"[golden] {name} ({family}): forward {dt:.2f}s  mean|y|={y.abs().mean():.4f} max|y|={y.abs().max():.4f}  "
           f"y sample {out['y'].shape}")
