@@ -309,8 +309,9 @@ def main():
     if rank == 0 and world == 1 and args.config == "C3" and args.precision == "bf16" and not args.no_config2:
         # BASELINE config 5 (second architecture): the FuXi-6h 0.25-degree forward (the model section of the reference's fuxi_6h_single_step.yml:
         # 640 x 1280, patch 4, 2 frames, 74 channels in / 71 out, dim 1024, 8 heads, 7 x 7 windows, depth 16; 266 M parameters) through wx_fuxi_*: CubeEmbedding, DownBlock, the Swin
-        # stage on 84 x 161 padded tokens, UpBlock, fc, patch -> pixel.  Keyed synthetic weights.  The stage is the engine's V2-Cr stage
-        # (pinned to credit/models/swin.py); the reference instantiates timm's class there, which is not vendored.
+        # stage on 84 x 161 padded tokens, UpBlock, fc, patch -> pixel.  Keyed synthetic weights.  The stage is made of timm's Swin V2 block
+        # (timm.models.swin_transformer_v2, what fuxi.py:250-260 instantiates: q / v bias, 16 sigmoid(cpb_mlp) bias table, mask over both
+        # axes, timm's state-dict keys); timm is not vendored, so that block follows timm's published code (parity unpinned).
         from wxengine.fuxi import FuxiHIP, named_fuxi_config, synth_fuxi_state_dict
         cfg5 = named_fuxi_config("F6H")
         m5 = FuxiHIP(precision="bf16", device=local_rank, cfg=cfg5)
@@ -332,8 +333,10 @@ def main():
                    "value": round(1.0 / best5, 2), "unit": "forwards/sec", "ms_per_forward": round(1e3 * best5, 3), "dtype": "bf16",
                    "params": int(sum(int(np.prod(v)) for v in cfg5.state_spec().values())),
                    "tflops": round(m5.flops / best5 / 1e12, 1), "finite_outputs": bool(torch.isfinite(y5).all().item()),
-                   "note": "best of 3 x 10 forwards after 3 warm-ups; whole forward (embedding, down / up blocks, 16-block Swin stage, fc); the stage "
-                           "is the engine's Swin V2 (Cr) stage, pinned to credit/models/swin.py -- FuXi's own stage is timm's class: unpinned (SURVEY 8(c))"}
+                   "stage_variant": cfg5.stage,
+                   "note": "best of 3 x 10 forwards after 3 warm-ups; whole forward (embedding, down / up blocks, 16-block Swin stage, fc); stage_variant "
+                           "'timm' = timm's SwinTransformerV2Block as the reference builds it (state-dict keys of a reference checkpoint; parity "
+                           "of the block itself unpinned: timm absent, SURVEY 8(c)); 'cr' = credit/models/swin.py's block (pinned)"}
         del m5
 
     if rank == 0:

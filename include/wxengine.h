@@ -159,6 +159,9 @@ typedef struct wx_winattn_desc {
   int32_t kind, shift_y, shift_x;
   float softmax_scale;         /* ignored when logit_scale is given */
   float mask_value;            /* kind 3 (the reference: -100) */
+  int32_t mask_axes;           /* kind 3: 1 (or 0) = latitude seam only (V2-Cr, swin.py:411-427); 3 = longitude seam too -- the mask of timm's
+                                  SwinTransformerV2Block (the class credit/models/fuxi.py:250-260 instantiates): nine img_mask slices over
+                                  both axes, i.e. at most 2 x 2 regions inside a window */
 } wx_winattn_desc;
 typedef struct wx_winattn* wx_winattn_handle;
 int wx_winattn_create(const wx_winattn_desc* desc, const float* bias_host, int n_bias_heads, const float* logit_scale_host, int device,
@@ -185,6 +188,7 @@ typedef struct wx_swin_desc {
   int32_t shift_y, shift_x;    /* of the odd blocks */
   float mask_value;            /* -100 (swin.py:425) */
   float ln_eps;                /* 1e-5 (nn.LayerNorm default) */
+  int32_t mask_axes;           /* 1 (or 0): V2-Cr mask, latitude only; 3: timm V2 mask, both axes (see wx_winattn_desc) */
 } wx_swin_desc;
 typedef struct wx_swin* wx_swin_handle;
 int wx_swin_create(const wx_swin_desc* desc, int device, wx_swin_handle* out);
@@ -199,8 +203,9 @@ int wx_swin_destroy(wx_swin_handle s);
  * (then the trailing F.interpolate(size = image) is the identity), frame_patch_size == frames (the time axis collapses, :470):
  *   x [C_in][frames][H][W] float32 -> CubeEmbedding (:82-143) -> UTransformer (:204-310: DownBlock, zero-pad to the window,
  *   Swin stage, crop, concat, UpBlock) -> fc + patch reshape (:484-488) -> y [C_out][H][W] float32.
- * The stage in the middle is the engine's V2-Cr stage (wx_swin above; the reference instantiates timm's class, not vendored:
- * parity of the stage is pinned to credit/models/swin.py instead), everything around it follows the reference's own modules.
+ * The stage in the middle is wx_swin above in one of two variants (wx_fuxi_desc.stage_variant): timm's Swin V2 block, which is
+ * what the reference instantiates (timm is not vendored: that variant follows timm's published block, parity unpinned), or the V2-Cr
+ * block of credit/models/swin.py (pinned to reference goldens).  Everything around the stage follows the reference's own modules.
  *   wx_fuxi_load(name, ...): name = the reference's state-dict key with EFFECTIVE weights (eval-mode spectral norm folded by the
  *     caller, fuxi.py:16-22): "cube_embedding.proj.weight" [dim][C_in][frames][ph][pw], "cube_embedding.proj.bias",
  *     "cube_embedding.norm.{weight,bias}", "u_transformer.down.conv.{weight [dim][dim][3][3],bias}",
@@ -217,7 +222,13 @@ typedef struct wx_fuxi_desc {
   int32_t patch_h, patch_w;
   int32_t dim, heads, window, depth;
   int32_t groups_down, groups_up;   /* to_2tuple(num_groups) */
+  int32_t stage_variant;        /* WX_STAGE_TIMM_V2 (what fuxi.py:250-260 builds: timm.models.swin_transformer_v2.SwinTransformerV2Stage --
+                                   shift mask over both axes; its q/v bias, 16 sigmoid(cpb_mlp) table and clamped logit scale reach the engine
+                                   as "attn.qkv.bias" / "attn.bias_table" / "attn.logit_scale", computed by the host) or WX_STAGE_V2_CR
+                                   (credit/models/swin.py's block: latitude-only mask; the variant pinned to reference goldens) */
 } wx_fuxi_desc;
+#define WX_STAGE_V2_CR 0
+#define WX_STAGE_TIMM_V2 1
 typedef struct wx_fuxi* wx_fuxi_handle;
 int wx_fuxi_create(const wx_fuxi_desc* desc, int device, wx_fuxi_handle* out);
 int wx_fuxi_load(wx_fuxi_handle f, const char* name, const float* host_data, int64_t count);

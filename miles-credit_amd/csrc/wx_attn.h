@@ -31,6 +31,8 @@ struct AttnParams {
   int wsz_x = 0;                  // window width (0 = wsz: the CrossFormer windows are square)
   int shift_y = 0, shift_x = 0;   // kind 3: cyclic shift; tokens whose rolled row is >= H - shift_y form a second region and pairs
   float mask_val = 0.f;           //         across the two regions get mask_val added (swin.py:411-427: -100, latitude only)
+  int mask_x = 0;                 // kind 3, != 0: the rolled COLUMNS >= W - shift_x are a region of their own as well -- timm's
+                                  //         SwinTransformerV2Block mask (3 x 3 slices over both axes; inside one window at most 2 x 2 regions)
   int64_t bias_head_stride = 0;   // floats between the [NP][NP] bias tables of consecutive heads (0 = one table for all heads)
   float q_scale = 0.f;            // bf16 path, != 0: multiply the query fragments by this (softmax scale x log2 e) in the kernel -- the
                                   // CrossFormer engine folds it into to_qkv's q rows instead and leaves 0 here
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
     for (int s = 0; s < QK_SUBS; ++s) kf[j][s] = attn_ld16(qkv_b + k_col + ko + s * 64 + g * 16);
   }
   // ---- per-workgroup tables, then the only workgroup barrier (LDS counter only: the loads above stay in flight) ------
-  if (SW && p.kind == 3 && threadIdx.x < NP) s_row[threadIdx.x] = (int)threadIdx.x / wsx;
+  if (SW && p.kind == 3 && threadIdx.x < NP) s_row[threadIdx.x] = ((int)threadIdx.x / wsx) | (((int)threadIdx.x % wsx) << 8);   // (ty, tx) of token t
   if constexpr (BT) {
     const int side = 2 * p.wsz - 1;
 #pragma unroll
@@ -493,9 +495,13 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
     float mx = -3.0e38f;
     const float* brow = p.bias + (int64_t)head * p.bias_head_stride + (int64_t)query * NP + g * 4;  // query < NP always
     // kind 3: region (0 / 1) of this lane's query under the shift mask; window row of the tile's window
-    const int reg_lim = p.H - p.shift_y - (win0 / wins_x) * p.wsz;   // token row ty is in region 1 iff ty >= reg_lim
-    const bool swin_mask = SW && p.kind == 3 && p.shift_y > 0;
-    const int reg_q = swin_mask ? (int)(s_row[query < NP ? query : 0] >= reg_lim) : 0;
+    // region code of a token inside THIS window: bit 0 = its row ty >= lim_y, bit 1 = its column tx >= lim_x (mask_x only); the limits
+    // sit inside the last window row / column of the rolled map only (everywhere else no token reaches them)
+    const int lim_y = p.H - p.shift_y - (win0 / wins_x) * p.wsz;
+    const int lim_x = p.mask_x ? p.W - p.shift_x - (win0 % wins_x) * wsx : (1 << 20);
+    const bool swin_mask = SW && p.kind == 3 && (p.shift_y > 0 || (p.mask_x && p.shift_x > 0));
+    auto region = [&](int v) -> int { return (int)((v & 255) >= lim_y) | ((int)((v >> 8) >= lim_x) << 1); };
+    const int reg_q = swin_mask ? region(s_row[query < NP ? query : 0]) : 0;
     float4 bt[BT ? NKF : 1];
     if constexpr (BT) {
       // bias[q][k] = tb[(qy - ky + w - 1) * (2w - 1) + (qx - kx + w - 1)]: one subtraction and one 4-byte LDS read per pair
@@ -515,10 +521,10 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
       else bb = *reinterpret_cast<const float4*>(brow + j * 16);
       if (swin_mask) {   // pairs across the wrap-around seam of the rolled map: + mask_val (the reference's -100)
         const int4 rk = *reinterpret_cast<const int4*>(s_row + j * 16 + g * 4);
-        bb.x += ((int)(rk.x >= reg_lim) != reg_q) ? p.mask_val : 0.f;
-        bb.y += ((int)(rk.y >= reg_lim) != reg_q) ? p.mask_val : 0.f;
-        bb.z += ((int)(rk.z >= reg_lim) != reg_q) ? p.mask_val : 0.f;
-        bb.w += ((int)(rk.w >= reg_lim) != reg_q) ? p.mask_val : 0.f;
+        bb.x += (region(rk.x) != reg_q) ? p.mask_val : 0.f;
+        bb.y += (region(rk.y) != reg_q) ? p.mask_val : 0.f;
+        bb.z += (region(rk.z) != reg_q) ? p.mask_val : 0.f;
+        bb.w += (region(rk.w) != reg_q) ? p.mask_val : 0.f;
       }
       if constexpr (sizeof(T) == 2) {
         // bf16 engine: q carries scale * log2(e) (folded into to_qkv at load) and the position bias is the accumulator's

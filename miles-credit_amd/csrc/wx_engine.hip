@@ -2960,6 +2960,7 @@ int wx_winattn_apply(wx_winattn_handle w, const void* qkv_dev, void* out_dev, vo
     p.shift_y = d.kind == 3 ? d.shift_y : 0; p.shift_x = d.kind == 3 ? d.shift_x : 0;
     const float l2e = d.precision == WX_PREC_BF16 ? 1.4426950408889634f : 1.0f;
     p.mask_val = d.mask_value * l2e;
+    p.mask_x = (d.kind == 3 && (d.mask_axes & 2)) ? 1 : 0;
     p.logit_scale = w->logit_dev;
     // scores: cosine mode has its scale in q (logit_scale); otherwise softmax_scale (x log2 e on the exp2 path)
     p.scale = w->logit_dev ? 1.0f : d.softmax_scale;                                             // fp32 path: scores * scale
@@ -2982,6 +2983,8 @@ int wx_swin_create(const wx_swin_desc* d, int device, wx_swin_handle* out) {
     if (d->precision != WX_PREC_FP32 && d->precision != WX_PREC_BF16) throw wx::ConfigError("swin: unknown precision");
     if (d->depth < 1 || d->H < 1 || d->W < 1 || d->heads < 1 || d->wsz_y < 1 || d->wsz_x < 1) throw wx::ConfigError("swin: bad geometry");
     wx::SwinDesc sd{d->H, d->W, d->C, d->heads, d->wsz_y, d->wsz_x, d->depth, d->hidden, d->shift_y, d->shift_x, d->mask_value, d->ln_eps};
+    if (d->mask_axes != 0 && d->mask_axes != 1 && d->mask_axes != 3) throw wx::ConfigError("swin: mask_axes must be 1 (latitude) or 3 (both axes)");
+    sd.mask_axes = d->mask_axes == 3 ? 3 : 1;
     auto w = std::make_unique<wx_swin>();
     try {
       if (d->precision == WX_PREC_BF16) w->impl = std::make_unique<wx::SwinStage<wx::bf16_t>>(sd, device);
@@ -3029,7 +3032,9 @@ int wx_fuxi_create(const wx_fuxi_desc* d, int device, wx_fuxi_handle* out) {
     if (d->H < 1 || d->W < 1 || d->C_in < 1 || d->C_out < 1 || d->frames < 1 || d->patch_h < 1 || d->patch_w < 1 || d->dim < 1 || d->heads < 1 ||
         d->window < 1 || d->depth < 1 || d->groups_down < 1 || d->groups_up < 1)
       throw wx::ConfigError("fuxi: bad geometry");
+    if (d->stage_variant != WX_STAGE_V2_CR && d->stage_variant != WX_STAGE_TIMM_V2) throw wx::ConfigError("fuxi: unknown stage_variant");
     wx::FuxiDesc fd{d->H, d->W, d->C_in, d->C_out, d->frames, d->patch_h, d->patch_w, d->dim, d->heads, d->window, d->depth, d->groups_down, d->groups_up};
+    fd.stage_variant = d->stage_variant;
     auto w = std::make_unique<wx_fuxi>();
     try {
       if (d->precision == WX_PREC_BF16) w->impl = std::make_unique<wx::FuxiModel<wx::bf16_t>>(fd, device);

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void fuxi_copy_pixels_kernel(const T* __restri
 
 struct FuxiDesc {
   int H, W, C_in, C_out, frames, ph, pw, dim, heads, wsz, depth, groups_down, groups_up;
+  int stage_variant = 0;   // WX_STAGE_V2_CR / WX_STAGE_TIMM_V2
 };
 
 struct FuxiBase {
@@ -179,6 +180,7 @@ struct FuxiModel : FuxiBase {
     SwinDesc sd{Hs, Ws, d.dim, d.heads, d.wsz, d.wsz, d.depth, 4 * d.dim, d.wsz / 2, d.wsz / 2, -100.0f, 1e-5f};
     if (Hs <= d.wsz) sd.shift_y = 0;
     if (Ws <= d.wsz) sd.shift_x = 0;
+    sd.mask_axes = d.stage_variant == 1 ? 3 : 1;   // timm's block masks the longitude seam too
     stage = std::make_unique<SwinStage<T>>(sd, device);
     const size_t dim = d.dim, Mp = (size_t)Hp * Wp, Md = (size_t)Hd * Wd, Ms = (size_t)Hs * Ws;
     auto wT = [&](size_t n) { return (T*)dalloc(n * sizeof(T)); };

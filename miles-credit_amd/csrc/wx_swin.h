@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const T* __restrict__ 
 struct SwinDesc {
   int H, W, C, heads, wsz_y, wsz_x, depth, hidden, shift_y, shift_x;
   float mask_value, ln_eps;
+  int mask_axes = 1;   // 1: latitude seam only (V2-Cr, swin.py:411-427); 3: both axes (timm's SwinTransformerV2Block)
 };
 
 struct SwinStageBase {
@@ -276,7 +277,7 @@ struct SwinStage : SwinStageBase {
       a.qkv = qkv; a.ld_qkv = 3 * (int64_t)d.C; a.out = attn_o; a.ld_out = d.C; a.bias = b.bias_tab;
       a.H = d.H; a.W = d.W; a.C = d.C; a.heads = d.heads; a.wsz = d.wsz_y; a.wsz_x = d.wsz_x; a.kind = shifted ? 3 : 0;
       a.shift_y = shifted ? d.shift_y : 0; a.shift_x = shifted ? d.shift_x : 0;
-      a.mask_val = d.mask_value * l2e; a.logit_scale = b.logit; a.scale = 1.0f; a.q_scale = 0.f;
+      a.mask_val = d.mask_value * l2e; a.mask_x = (d.mask_axes & 2) ? 1 : 0; a.logit_scale = b.logit; a.scale = 1.0f; a.q_scale = 0.f;
       a.bias_head_stride = (int64_t)NP * NP;
       launch_window_attn_any<T>(a, d.C / d.heads, s);
       linear(attn_o, d.C, b.wproj, b.bproj, d.C, branch, 0, s, b.wproj_kb);

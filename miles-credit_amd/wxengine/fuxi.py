@@ -23,7 +23,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 
 from .engine import PREC, WXEngineError, _check, load_library
-from .swin import effective_logit_scale, relative_position_bias
+from .swin import TIMM_DERIVED_SUFFIXES, effective_logit_scale, relative_position_bias, timm_block_tensors
 from .synth import keyed_normal, power_iterate
 
 META_HIDDEN = 384   # swin.py:233-239: the meta network's hidden width
@@ -32,7 +32,11 @@ META_HIDDEN = 384   # swin.py:233-239: the meta network's hidden width
 class wx_fuxi_desc(C.Structure):
     _fields_ = [("precision", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C_in", C.c_int32), ("C_out", C.c_int32),
                 ("frames", C.c_int32), ("patch_h", C.c_int32), ("patch_w", C.c_int32), ("dim", C.c_int32), ("heads", C.c_int32),
-                ("window", C.c_int32), ("depth", C.c_int32), ("groups_down", C.c_int32), ("groups_up", C.c_int32)]
+                ("window", C.c_int32), ("depth", C.c_int32), ("groups_down", C.c_int32), ("groups_up", C.c_int32), ("stage_variant", C.c_int32)]
+
+
+STAGE_VARIANT = {"cr": 0, "timm": 1}   # WX_STAGE_V2_CR / WX_STAGE_TIMM_V2 (include/wxengine.h)
+CPB_HIDDEN = 512                       # timm: cpb_mlp = Linear(2, 512) -> ReLU -> Linear(512, heads, bias=False)
 
 
 def window_padding(n: int, window: int) -> Tuple[int, int]:
@@ -65,6 +69,10 @@ class FuxiConfig:
     use_spectral_norm: bool = True
     interp: bool = True
     meta_hidden: int = META_HIDDEN
+    # which block the stage is made of: "timm" = timm.models.swin_transformer_v2.SwinTransformerV2Stage, what the reference builds
+    # (fuxi.py:4-5, 250-260) and what its checkpoints contain; "cr" = credit/models/swin.py's V2-Cr block (the variant whose goldens
+    # come from reference code -- timm is not installable here, so the timm variant follows timm's published block: parity unpinned)
+    stage: str = "timm"
 
     @classmethod
     def from_model_conf(cls, conf: Dict) -> "FuxiConfig":
@@ -90,6 +98,8 @@ class FuxiConfig:
         return cfg
 
     def check(self) -> None:
+        if self.stage not in STAGE_VARIANT:
+            raise ValueError("FuxiHIP: stage must be 'timm' or 'cr'")
         if self.frame_patch_size != self.frames:
             raise ValueError("FuxiHIP: frame_patch_size must equal frames (fuxi.py:470 squeezes the time axis)")
         if self.image_height % self.patch_height or self.image_width % self.patch_width:
@@ -148,8 +158,32 @@ class FuxiConfig:
         for i in (0, 3):
             wrapped(f"u_transformer.down.b.{i}", (d, d, 3, 3))
             plain(f"u_transformer.down.b.{i + 1}", d)
+        def wrapped_nobias(prefix, shape):   # nn.Linear(..., bias=False) under apply_spectral_norm
+            if sn:
+                spec[prefix + ".weight_orig"] = tuple(shape)
+                spec[prefix + ".weight_u"] = (shape[0],)
+                spec[prefix + ".weight_v"] = (int(np.prod(shape)) // shape[0],)
+            else:
+                spec[prefix + ".weight"] = tuple(shape)
+
         for i in range(self.depth):
             p = f"u_transformer.layer.blocks.{i}."
+            if self.stage == "timm":
+                # timm.models.swin_transformer_v2.SwinTransformerV2Block: attn = WindowAttention(logit_scale [heads, 1, 1], cpb_mlp,
+                # qkv = Linear(dim, 3 dim, bias=False), q_bias, v_bias (k_bias / coordinate tables / attn_mask: non-persistent buffers),
+                # proj), norm1, mlp = Mlp(fc1, fc2), norm2; apply_spectral_norm (fuxi.py:16-22) wraps every nn.Linear among them
+                spec[p + "attn.logit_scale"] = (self.num_heads, 1, 1)
+                spec[p + "attn.q_bias"] = (d,)
+                spec[p + "attn.v_bias"] = (d,)
+                wrapped(p + "attn.cpb_mlp.0", (CPB_HIDDEN, 2))
+                wrapped_nobias(p + "attn.cpb_mlp.2", (self.num_heads, CPB_HIDDEN))
+                wrapped_nobias(p + "attn.qkv", (3 * d, d))
+                wrapped(p + "attn.proj", (d, d))
+                plain(p + "norm1", d)
+                wrapped(p + "mlp.fc1", (4 * d, d))
+                wrapped(p + "mlp.fc2", (d, 4 * d))
+                plain(p + "norm2", d)
+                continue
             plain(p + "norm1", d)
             spec[p + "attn.logit_scale"] = (self.num_heads,)
             wrapped(p + "attn.qkv", (3 * d, d))
@@ -172,19 +206,25 @@ def named_fuxi_config(name: str) -> FuxiConfig:
     if name == "FT0":    # rectangular patch, K padding in the embed GEMM, lat axis as tall as one window (no lat shift), lon padded
         return FuxiConfig(image_height=16, patch_height=2, image_width=48, patch_width=4, levels=2, frames=2, frame_patch_size=2, dim=64,
                           num_groups=(8, 16), channels=3, surface_channels=1, input_only_channels=0, output_only_channels=0, num_heads=2,
-                          depth=2, window_size=4, meta_hidden=24)
+                          depth=2, window_size=4, meta_hidden=24, stage="cr")
     if name == "FT1":    # FuXi's window 7, both axes padded (9 -> 14, 11 -> 14), input-only channels, 4 channels per group as in FuXi
         return FuxiConfig(image_height=72, patch_height=4, image_width=88, patch_width=4, levels=2, frames=2, frame_patch_size=2, dim=128,
                           num_groups=32, channels=3, surface_channels=2, input_only_channels=1, output_only_channels=0, num_heads=2,
-                          depth=3, window_size=7, meta_hidden=24)
+                          depth=3, window_size=7, meta_hidden=24, stage="cr")
     if name == "FT2":    # no spectral norm, single frame, output-only channel
         return FuxiConfig(image_height=32, patch_height=4, image_width=64, patch_width=4, levels=1, frames=1, frame_patch_size=1, dim=64,
                           num_groups=4, channels=4, surface_channels=3, input_only_channels=0, output_only_channels=1, num_heads=1,
-                          depth=2, window_size=4, use_spectral_norm=False, meta_hidden=16)
+                          depth=2, window_size=4, use_spectral_norm=False, meta_hidden=16, stage="cr")
+    if name in ("FT0T", "FT1T", "FT2T"):   # the same three geometries with timm's block in the stage (the reference's own structure)
+        import dataclasses
+        return dataclasses.replace(named_fuxi_config(name[:-1]), stage="timm")
     if name == "F6H":    # config/gen_1/arXiv_2024/fuxi_6h_single_step.yml (model section): 74 channels in, 71 out, 266 M parameters
         return FuxiConfig(image_height=640, patch_height=4, image_width=1280, patch_width=4, levels=16, frames=2, frame_patch_size=2,
                           dim=1024, num_groups=32, channels=4, surface_channels=7, input_only_channels=3, output_only_channels=0,
-                          num_heads=8, depth=16, window_size=7)
+                          num_heads=8, depth=16, window_size=7, stage="timm")
+    if name == "F6HCR":  # the same with the V2-Cr stage (rounds 2-3 measured this one)
+        import dataclasses
+        return dataclasses.replace(named_fuxi_config("F6H"), stage="cr")
     raise KeyError(name)
 
 
@@ -198,6 +238,8 @@ def synth_fuxi_state_dict(cfg: FuxiConfig, seed: int = 0) -> "OrderedDict[str, n
         z = keyed_normal("fuxi/" + key, shape, seed)
         if key.endswith("logit_scale"):
             sd[key] = (np.log(10.0) + 0.3 * z).astype(np.float32)
+        elif key.endswith((".q_bias", ".v_bias")):
+            sd[key] = (0.1 * z).astype(np.float32)
         elif len(shape) >= 2:
             fan_in = int(np.prod(shape[1:]))
             sd[key] = (z / np.sqrt(fan_in)).astype(np.float32)
@@ -255,7 +297,7 @@ class FuxiHIP:
         self.device = torch.cuda.current_device() if device is None else int(device)
         g = cfg.groups
         d = wx_fuxi_desc(PREC[precision], cfg.image_height, cfg.image_width, cfg.in_chans, cfg.out_chans, cfg.frames, cfg.patch_height,
-                         cfg.patch_width, cfg.dim, cfg.num_heads, cfg.window_size, cfg.depth, g[0], g[1])
+                         cfg.patch_width, cfg.dim, cfg.num_heads, cfg.window_size, cfg.depth, g[0], g[1], STAGE_VARIANT[cfg.stage])
         self._h = C.c_void_p()
         self.lib.wx_fuxi_create.argtypes = [C.POINTER(wx_fuxi_desc), C.c_int, C.POINTER(C.c_void_p)]
         _check(self.lib.wx_fuxi_create(C.byref(d), self.device, C.byref(self._h)))
@@ -278,7 +320,7 @@ class FuxiHIP:
         cfg = self.cfg
         spec = cfg.state_spec()
         missing = [k for k in spec if k not in sd]
-        extra = [k for k in sd if k not in spec]
+        extra = [k for k in sd if k not in spec and not k.endswith(TIMM_DERIVED_SUFFIXES)]
         if missing or (strict and extra):
             raise KeyError(f"FuxiHIP.load_state_dict: missing {missing[:4]}{'...' if len(missing) > 4 else ''}, "
                            f"unexpected {extra[:4]}{'...' if len(extra) > 4 else ''}")
@@ -288,6 +330,17 @@ class FuxiHIP:
                 raise ValueError(f"FuxiHIP.load_state_dict: {k} has shape {got}, expected {tuple(shape)}")
         eff = fold_spectral_norm(OrderedDict((k, sd[k]) for k in spec))
         ws = (cfg.window_size, cfg.window_size)
+        if cfg.stage == "timm":
+            for k, v in eff.items():
+                if not k.startswith("u_transformer.layer.blocks."):
+                    self._put(k, v)
+            for i in range(cfg.depth):
+                p = f"u_transformer.layer.blocks.{i}."
+                for name, arr in timm_block_tensors(lambda k: eff[k], p, ws, cfg.dim).items():
+                    self._put(p + name, arr)
+            _check(self.lib.wx_fuxi_finalize(self._h))
+            self._loaded = True
+            return
         for k, v in eff.items():
             if ".attn.meta_mlp." in k or k.endswith("attn.logit_scale"):
                 continue

@@ -7,7 +7,9 @@ with the constructor kwargs of `credit.models.fuxi.Fuxi` (fuxi.py:327-356) and a
 
 builds it like any other model and `BaseModel.load_model` (base_model.py:57-87) fills it from a checkpoint.  `forward(x)` runs
 `wxengine.fuxi.FuxiHIP` (C ABI `wx_fuxi_*`) on the device of `x`; the weights are pushed to the engine on the first call after a
-`load_state_dict`.  The stage keys are those of the reference's V2-Cr block (see wxengine/fuxi.py for why not timm's).  No CPU fallback.
+`load_state_dict`.  The stage keys are timm's (`blocks.<i>.attn.{logit_scale,q_bias,v_bias,cpb_mlp.0.*,cpb_mlp.2.*,qkv.*,proj.*}`, ...), i.e.
+those of a reference FuXi checkpoint; `stage: "cr"` in the model section selects the V2-Cr block of credit/models/swin.py instead.
+No CPU fallback.
 """
 from __future__ import annotations
 
@@ -81,7 +83,8 @@ class FuxiHIPModel(_Base):
                 continue
             with torch.no_grad():
                 dst.copy_(src.to(dst.dtype))
-        unexpected = [k for k in state_dict if k not in self._spec]
+        from .swin import TIMM_DERIVED_SUFFIXES   # buffers older timm releases saved with the stage: derived data, not weights
+        unexpected = [k for k in state_dict if k not in self._spec and not k.endswith(TIMM_DERIVED_SUFFIXES)]
         if strict and (missing or unexpected):
             errors.insert(0, f"Missing key(s) in state_dict: {missing[:8]}{' ...' if len(missing) > 8 else ''}; "
                              f"Unexpected key(s) in state_dict: {unexpected[:8]}{' ...' if len(unexpected) > 8 else ''}.")
@@ -130,4 +133,4 @@ if _Base is nn.Module:
 def register(model_type: str = "fuxi_hip"):
     """Register the class with the reference's registry (credit.models.register_model)."""
     from credit.models import register_model  # type: ignore
-    return register_model(model_type, "Loading the MI355X-native FuXi engine (Swin V2-Cr stage) ...")(FuxiHIPModel)
+    return register_model(model_type, "Loading the MI355X-native FuXi engine ...")(FuxiHIPModel)

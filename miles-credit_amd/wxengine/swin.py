@@ -25,7 +25,24 @@ KIND = {"block": 0, "dilated": 1, "shifted": 3}
 class wx_winattn_desc(C.Structure):
     _fields_ = [("precision", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32),
                 ("head_dim", C.c_int32), ("wsz_y", C.c_int32), ("wsz_x", C.c_int32), ("kind", C.c_int32), ("shift_y", C.c_int32),
-                ("shift_x", C.c_int32), ("softmax_scale", C.c_float), ("mask_value", C.c_float)]
+                ("shift_x", C.c_int32), ("softmax_scale", C.c_float), ("mask_value", C.c_float), ("mask_axes", C.c_int32)]
+
+
+def cpb_position_bias(w0, b0, w2, window: Tuple[int, int]) -> np.ndarray:
+    """timm's Swin V2 continuous position bias, [heads, N, N]: `16 * sigmoid(cpb_mlp(relative_coords_table))[relative_position_index]`
+    (timm.models.swin_transformer_v2.WindowAttention: cpb_mlp = Linear(2, 512) -> ReLU -> Linear(512, heads, bias=False); the table
+    holds the offsets -(w-1)..(w-1) per axis, divided by (w-1), times 8, then sign(x) * log2(|x| + 1) / log2(8)).  Host, float64."""
+    wh, ww = window
+    dy = np.arange(-(wh - 1), wh, dtype=np.float64) / max(wh - 1, 1)
+    dx = np.arange(-(ww - 1), ww, dtype=np.float64) / max(ww - 1, 1)
+    tab = np.stack(np.meshgrid(dy, dx, indexing="ij"), axis=-1) * 8.0                       # [2wh-1, 2ww-1, 2]
+    tab = np.sign(tab) * np.log2(np.abs(tab) + 1.0) / np.log2(8.0)
+    h = np.maximum(tab.reshape(-1, 2) @ np.asarray(w0, np.float64).T + np.asarray(b0, np.float64), 0.0)
+    t = 16.0 / (1.0 + np.exp(-(h @ np.asarray(w2, np.float64).T)))                           # [(2wh-1)(2ww-1), heads]
+    ys, xs = np.meshgrid(np.arange(wh), np.arange(ww), indexing="ij")
+    cy, cx = ys.ravel(), xs.ravel()
+    idx = (cy[:, None] - cy[None, :] + wh - 1) * (2 * ww - 1) + (cx[:, None] - cx[None, :] + ww - 1)   # [N, N], query-major
+    return np.ascontiguousarray(t[idx.ravel()].reshape(wh * ww, wh * ww, -1).transpose(2, 0, 1), dtype=np.float32)
 
 
 def relative_position_bias(fc1_w, fc1_b, fc2_w, fc2_b, window: Tuple[int, int]) -> np.ndarray:
@@ -48,8 +65,9 @@ def effective_logit_scale(raw) -> np.ndarray:
 class WindowAttention:
     def __init__(self, feat: Tuple[int, int], heads: int, head_dim: int, window, shift: Sequence[int] = (0, 0), kind: Optional[str] = None,
                  bias=None, logit_scale=None, softmax_scale: Optional[float] = None, mask_value: float = -100.0,
-                 precision: str = "bf16", device: Optional[int] = None):
-        """bias: [heads, N, N] or [1, N, N] or None; logit_scale: [heads] (already exponentiated) selects cosine attention."""
+                 precision: str = "bf16", device: Optional[int] = None, mask_axes: int = 1):
+        """bias: [heads, N, N] or [1, N, N] or None; logit_scale: [heads] (already exponentiated) selects cosine attention;
+        mask_axes: 1 = the latitude-only seam mask of swin.py:411-427, 3 = both axes (timm's SwinTransformerV2Block)."""
         import torch
         if not torch.cuda.is_available():
             raise WXEngineError("no GPU visible: window attention has no CPU fallback")
@@ -62,7 +80,7 @@ class WindowAttention:
             kind = "shifted" if any(self.shift) else "block"
         d = wx_winattn_desc(PREC[precision], feat[0], feat[1], heads * head_dim, heads, head_dim, ws[0], ws[1], KIND[kind],
                             self.shift[0], self.shift[1], float(softmax_scale if softmax_scale is not None else head_dim ** -0.5),
-                            float(mask_value))
+                            float(mask_value), int(mask_axes))
         fp = C.POINTER(C.c_float)
         n = ws[0] * ws[1]
         b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32).reshape(-1, n, n)
@@ -107,7 +125,22 @@ class WindowAttention:
 class wx_swin_desc(C.Structure):
     _fields_ = [("precision", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32),
                 ("wsz_y", C.c_int32), ("wsz_x", C.c_int32), ("depth", C.c_int32), ("hidden", C.c_int32), ("shift_y", C.c_int32),
-                ("shift_x", C.c_int32), ("mask_value", C.c_float), ("ln_eps", C.c_float)]
+                ("shift_x", C.c_int32), ("mask_value", C.c_float), ("ln_eps", C.c_float), ("mask_axes", C.c_int32)]
+
+
+# keys of timm's stage that carry no information the engine needs: non-persistent buffers in timm >= 0.9 (older releases saved them)
+TIMM_DERIVED_SUFFIXES = ("attn.relative_coords_table", "attn.relative_position_index", "attn.k_bias", "attn_mask")
+
+
+def timm_block_tensors(get, p: str, window: Tuple[int, int], dim: int):
+    """One block of timm's SwinTransformerV2Stage (EFFECTIVE weights under prefix `p`) -> the engine's wx_swin_load tensors:
+    qkv bias = (q_bias | 0 | v_bias) (the k bias is a zero buffer), bias table = cpb_position_bias, logit scale = exp(clamp(., log 100))."""
+    out = {name: get(p + name) for name in ("attn.qkv.weight", "attn.proj.weight", "attn.proj.bias", "norm1.weight", "norm1.bias",
+                                            "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias", "norm2.weight", "norm2.bias")}
+    out["attn.qkv.bias"] = np.concatenate([get(p + "attn.q_bias").ravel(), np.zeros(dim, np.float32), get(p + "attn.v_bias").ravel()])
+    out["attn.bias_table"] = cpb_position_bias(get(p + "attn.cpb_mlp.0.weight"), get(p + "attn.cpb_mlp.0.bias"), get(p + "attn.cpb_mlp.2.weight"), window)
+    out["attn.logit_scale"] = effective_logit_scale(get(p + "attn.logit_scale").ravel())
+    return out
 
 
 class SwinStage:
@@ -123,8 +156,14 @@ class SwinStage:
                "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias", "norm2.weight", "norm2.bias")
 
     def __init__(self, dim: int, depth: int, num_heads: int, feat_size: Tuple[int, int], window_size, mlp_ratio: float = 4.0,
-                 precision: str = "bf16", device: Optional[int] = None):
+                 precision: str = "bf16", device: Optional[int] = None, variant: str = "cr"):
+        """variant "cr": credit/models/swin.py's SwinTransformerV2CrBlock (keys attn.meta_mlp.*, attn.qkv.bias; latitude-only mask).
+        variant "timm": timm.models.swin_transformer_v2.SwinTransformerV2Block, the block FuXi's stage is made of (fuxi.py:250-260):
+        keys attn.q_bias / attn.v_bias / attn.cpb_mlp.{0,2}.* / attn.logit_scale [heads, 1, 1], mask over both axes."""
         import torch
+        if variant not in ("cr", "timm"):
+            raise ValueError("SwinStage: variant must be 'cr' or 'timm'")
+        self.variant = variant
         if not torch.cuda.is_available():
             raise WXEngineError("no GPU visible: the Swin stage has no CPU fallback")
         self.lib = load_library()
@@ -137,7 +176,7 @@ class SwinStage:
         self.precision = precision
         self.device = torch.cuda.current_device() if device is None else int(device)
         d = wx_swin_desc(PREC[precision], self.feat[0], self.feat[1], self.dim, self.heads, self.window[0], self.window[1], self.depth,
-                         self.hidden, self.shift[0], self.shift[1], -100.0, 1e-5)
+                         self.hidden, self.shift[0], self.shift[1], -100.0, 1e-5, 3 if variant == "timm" else 1)
         self._h = C.c_void_p()
         self.lib.wx_swin_create.argtypes = [C.POINTER(wx_swin_desc), C.c_int, C.POINTER(C.c_void_p)]
         _check(self.lib.wx_swin_create(C.byref(d), self.device, C.byref(self._h)))
@@ -160,6 +199,10 @@ class SwinStage:
         get = lambda k: np.asarray(sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k], dtype=np.float32)  # noqa: E731
         for i in range(self.depth):
             p = f"{prefix}{i}."
+            if self.variant == "timm":
+                for name, arr in timm_block_tensors(get, p, self.window, self.dim).items():
+                    self._put(i, name, arr)
+                continue
             for name in self._DIRECT:
                 self._put(i, name, get(p + name))
             self._put(i, "attn.bias_table", relative_position_bias(get(p + "attn.meta_mlp.fc1.weight"), get(p + "attn.meta_mlp.fc1.bias"),

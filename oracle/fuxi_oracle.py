@@ -73,8 +73,12 @@ def up_block(x: Tensor, w: Dict[str, Tensor], groups: int) -> Tensor:
     return _residual_path(F.conv_transpose2d(x[None], w[p + "conv.weight"], w[p + "conv.bias"], stride=2)[0], w, p, groups)
 
 
-def stage(x: Tensor, w: Dict[str, Tensor], heads: int, window: int, depth: int, prefix: str = "u_transformer.layer.blocks.") -> Tensor:
-    """x [H, W, C]; blocks alternate shift 0 / window // 2, an axis as large as its window is not shifted (swin.py:405-409)."""
+def stage(x: Tensor, w: Dict[str, Tensor], heads: int, window: int, depth: int, prefix: str = "u_transformer.layer.blocks.",
+          variant: str = "cr") -> Tensor:
+    """x [H, W, C]; blocks alternate shift 0 / window // 2, an axis as large as its window is not shifted (swin.py:405-409).
+    variant "timm": timm's Swin V2 block (what fuxi.py:250-260 instantiates; swin_oracle.stage_timm, parity unpinned)."""
+    if variant == "timm":
+        return S.stage_timm(x, w, heads, window, depth, prefix=prefix)
     H, W, _ = x.shape
     ws = (min(window, H), min(window, W))
     for i in range(depth):
@@ -84,7 +88,7 @@ def stage(x: Tensor, w: Dict[str, Tensor], heads: int, window: int, depth: int, 
 
 
 def forward(x: Tensor, sd: Dict[str, Tensor], heads: int, window: int, depth: int, groups: Tuple[int, int], out_chans: int,
-            taps: dict = None) -> Tensor:
+            taps: dict = None, variant: str = "cr") -> Tensor:
     """x [C_in, T, H, W] -> y [C_out, H, W]; `taps` (optional dict) receives the intermediate maps, channels-last."""
     w = effective_weights(sd, x.dtype)
     ph, pw = w["cube_embedding.proj.weight"].shape[3:]
@@ -92,7 +96,7 @@ def forward(x: Tensor, sd: Dict[str, Tensor], heads: int, window: int, depth: in
     d = down_block(e, w, groups[0])
     _, hd, wd = d.shape
     (pt, pb), (pl, pr) = window_padding(hd, window), window_padding(wd, window)
-    t = stage(F.pad(d, (pl, pr, pt, pb)).permute(1, 2, 0), w, heads, window, depth).permute(2, 0, 1)
+    t = stage(F.pad(d, (pl, pr, pt, pb)).permute(1, 2, 0), w, heads, window, depth, variant=variant).permute(2, 0, 1)
     t = t[:, pt: pt + hd, pl: pl + wd]
     u = up_block(torch.cat([d, t], 0), w, groups[1])
     f = F.linear(u.permute(1, 2, 0), w["fc.weight"], w["fc.bias"])                               # [Hp, Wp, ph pw C_out]

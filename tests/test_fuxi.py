@@ -10,6 +10,7 @@ GPU: the HIP model (`wx_fuxi_*`) against the goldens and the oracle:
     fp32 (exact-f32 MFMA)  max|y - ref| <= 2e-4 * max|ref| on y and every intermediate map
     bf16                   rel-L2 <= 2e-2 and max err <= 6e-2 * max|ref| on y; rel-L2 <= 2e-2 on the maps
 and, at BASELINE config 5's own size (F6H: 640 x 1280, patch 4, dim 1024, 16 blocks), size-independent properties."""
+import dataclasses
 import os
 
 import numpy as np
@@ -35,7 +36,7 @@ def case(name):
 def run_oracle(cfg, sd, x, dtype=torch.float32):
     taps = {}
     y = FO.forward(torch.from_numpy(x[0]).to(dtype), {k: torch.from_numpy(v) for k, v in sd.items()}, cfg.num_heads, cfg.window_size, cfg.depth,
-                   cfg.groups, cfg.out_chans, taps)
+                   cfg.groups, cfg.out_chans, taps, variant=cfg.stage)
     return y, taps
 
 
@@ -155,6 +156,48 @@ def test_load_model_builds_the_fuxi_class_through_the_real_registry(tmp_path):
     cm._MODEL_REGISTRY.pop("fuxi_hip", None)
 
 
+def test_timm_stage_keys_are_the_reference_checkpoint_keys():
+    """The DEFAULT stage is timm's (what credit/models/fuxi.py:250-260 builds): the state spec carries timm's parameter names and
+    shapes -- q_bias / v_bias and no qkv bias, cpb_mlp.{0,2}, logit_scale [heads, 1, 1] -- each nn.Linear wrapped by
+    apply_spectral_norm (fuxi.py:16-22), and none of the V2-Cr names; buffers that only old timm releases saved are tolerated."""
+    from wxengine.fuxi_model import FuxiHIPModel
+    cfg = FuxiConfig.from_model_conf(dict(image_height=16, patch_height=2, image_width=48, patch_width=4, levels=2, frames=2, frame_patch_size=2,
+                                          dim=64, num_groups=8, channels=3, surface_channels=1, num_heads=2, depth=2, window_size=4))
+    assert cfg.stage == "timm" and named_fuxi_config("F6H").stage == "timm" and named_fuxi_config("FT0").stage == "cr"
+    spec = cfg.state_spec()
+    p = "u_transformer.layer.blocks.1.attn."
+    assert spec[p + "logit_scale"] == (2, 1, 1) and spec[p + "q_bias"] == (64,) and spec[p + "v_bias"] == (64,)
+    assert spec[p + "cpb_mlp.0.weight_orig"] == (512, 2) and spec[p + "cpb_mlp.0.bias"] == (512,) and spec[p + "cpb_mlp.2.weight_orig"] == (2, 512)
+    assert spec[p + "qkv.weight_orig"] == (192, 64) and spec[p + "qkv.weight_u"] == (192,) and spec[p + "qkv.weight_v"] == (64,)
+    for absent in ("qkv.bias", "cpb_mlp.2.bias", "k_bias", "meta_mlp.fc1.weight_orig", "relative_coords_table"):
+        assert p + absent not in spec
+    assert "u_transformer.layer.blocks.1.mlp.fc2.weight_orig" in spec and "u_transformer.layer.blocks.1.norm2.bias" in spec
+    m = FuxiHIPModel(**{f: getattr(cfg, f) for f in cfg.__dataclass_fields__})
+    sd = {k: torch.from_numpy(v) for k, v in synth_fuxi_state_dict(cfg).items()}
+    old_timm = {p + "relative_coords_table": torch.zeros(1, 7, 7, 2), p + "relative_position_index": torch.zeros(16, 16),
+                p + "k_bias": torch.zeros(64), "u_transformer.layer.blocks.1.attn_mask": torch.zeros(12, 16, 16)}
+    r = m.load_state_dict({**sd, **old_timm})
+    assert not r.missing_keys and not r.unexpected_keys
+    with pytest.raises(RuntimeError, match="Unexpected key"):           # a V2-Cr key is NOT part of a timm-stage model
+        m.load_state_dict({**sd, p + "meta_mlp.fc1.bias": torch.zeros(3)})
+    # the two variants of one geometry differ exactly in the attention's parameter names
+    cr = dataclasses.replace(cfg, stage="cr").state_spec()
+    assert {k for k in spec if ".attn." not in k} == {k for k in cr if ".attn." not in k}
+
+
+@pytest.mark.parametrize("name", ["FT0T", "FT1T", "FT2T"])
+def test_timm_variant_oracle_runs_and_differs_from_cr_only_in_the_stage(name):
+    cfg, sd, x = named_fuxi_config(name), None, None
+    sd = synth_fuxi_state_dict(cfg)
+    x = keyed_normal("fuxi/x0", (1, cfg.in_chans, cfg.frames, cfg.image_height, cfg.image_width), 1000)
+    y, taps = run_oracle(cfg, sd, x)
+    assert torch.isfinite(y).all() and y.shape == (cfg.out_chans, cfg.image_height, cfg.image_width)
+    g = np.load(os.path.join(GOLD, f"fuxi_{name[:-1]}.npz"))          # same weights for everything outside the stage (keyed by name)
+    for k in ("embed", "down"):
+        assert (taps[k] - torch.from_numpy(g[k])).abs().max() <= 2e-5 * np.abs(g[k]).max(), k
+    assert (taps["stage"] - torch.from_numpy(g["stage"])).abs().max() > 1e-3
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------------------------------
 def build(cfg, sd, prec):
     from wxengine.fuxi import FuxiHIP
@@ -193,6 +236,31 @@ def test_hip_fuxi_vs_reference_golden(name, prec):
     y2 = m(torch.cat([xd, 2 * xd]))
     assert torch.equal(y2[0, :, 0].cpu(), y)
     assert not torch.equal(y2[1], y2[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["FT0T", "FT1T", "FT2T"])
+def test_hip_fuxi_with_the_timm_stage_vs_oracle(name, prec):
+    """The reference's own structure -- timm's Swin V2 block in the stage -- against oracle/fuxi_oracle.py (stage: swin_oracle.stage_timm,
+    parity unpinned: timm absent; everything around it pinned by the goldens above).  Same gates as the pinned variant."""
+    cfg = named_fuxi_config(name)
+    sd = synth_fuxi_state_dict(cfg)
+    x = keyed_normal("fuxi/x0", (1, cfg.in_chans, cfg.frames, cfg.image_height, cfg.image_width), 1000)
+    m = build(cfg, sd, prec)
+    y = m(torch.from_numpy(x).cuda())[0, :, 0].cpu()
+    yo, taps = run_oracle(cfg, sd, x, torch.float64)
+    for k in MAPS:
+        got, want = torch.from_numpy(m.debug_map(k)).double(), taps[k]
+        if prec == "fp32":
+            assert (got - want).abs().max() <= 2e-4 * want.abs().max(), f"{k}: {(got - want).abs().max():.3e} of {want.abs().max():.3e}"
+        else:
+            assert ((got - want).norm() / want.norm()).item() <= 2e-2, k
+    if prec == "fp32":
+        assert (y.double() - yo).abs().max() <= 2e-4 * yo.abs().max()
+    else:
+        l2 = ((y.double() - yo).norm() / yo.norm()).item()
+        assert l2 <= 2e-2 and (y.double() - yo).abs().max() <= 6e-2 * yo.abs().max(), f"bf16 rel-L2 {l2:.3e}"
 
 
 @pytest.mark.gpu

@@ -5,6 +5,7 @@ CPU: oracle/swin_oracle.py against tests/golden/swin_attention.npz, the output o
 the position-bias table is an input of the fixture because the reference computes it with timm, which is not vendored).
 GPU: the HIP operator (`wx_winattn_*` through wxengine.swin.WindowAttention) against the same goldens:
     fp32 (exact-f32 MFMA): max|out - ref| <= 1e-4 * max|ref|;   bf16: rel-L2 <= 2e-2, max err <= 5e-2 * max|ref|."""
+import math
 import os
 
 import numpy as np
@@ -336,3 +337,97 @@ def test_hip_attend_vs_reference_golden(name, prec):
         Attend(dropout=0.1)
     with pytest.raises(WXEngineError):
         att(torch.zeros(1, 2, 200, 32).cuda(), torch.zeros(1, 2, 200, 32).cuda(), torch.zeros(1, 2, 200, 32).cuda())
+
+
+# ---- timm's Swin V2 block: the block FuXi's stage is REALLY made of (fuxi.py:4-5, 250-260).  timm cannot be installed here, so these
+# ---- tests pin the engine to oracle/swin_oracle.py::block_timm (a restatement of timm's published block; header: "parity unpinned"),
+# ---- and the restatement to everything that can be checked without timm.
+def timm_stage_dict(dim, heads, depth, seed=0):
+    """Random stage weights under timm's key names (effective weights: no spectral-norm triples at this level)."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, scale=1.0: torch.randn(*s, generator=g) * scale  # noqa: E731
+    sd = {}
+    for i in range(depth):
+        p = f"blocks.{i}."
+        sd[p + "attn.logit_scale"] = math.log(10.0) + 0.3 * r(heads, 1, 1)
+        sd[p + "attn.q_bias"], sd[p + "attn.v_bias"] = r(dim, scale=0.2), r(dim, scale=0.2)
+        sd[p + "attn.cpb_mlp.0.weight"], sd[p + "attn.cpb_mlp.0.bias"] = r(512, 2, scale=0.7), r(512, scale=0.3)
+        sd[p + "attn.cpb_mlp.2.weight"] = r(heads, 512, scale=0.08)
+        sd[p + "attn.qkv.weight"] = r(3 * dim, dim, scale=dim ** -0.5)
+        sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"] = r(dim, dim, scale=dim ** -0.5), r(dim, scale=0.1)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = r(4 * dim, dim, scale=dim ** -0.5), r(4 * dim, scale=0.1)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = r(dim, 4 * dim, scale=(4 * dim) ** -0.5), r(dim, scale=0.1)
+        for n in ("norm1", "norm2"):
+            sd[p + n + ".weight"], sd[p + n + ".bias"] = 1.0 + 0.1 * r(dim), 0.1 * r(dim)
+    return sd
+
+
+TIMM_CASES = {   # feat, window, heads, head_dim, depth
+    "rect_both_axes": ((12, 24), 4, 2, 32, 2),       # shift (2, 2): latitude AND longitude seams in the last window row / column
+    "fuxi_like": ((14, 21), 7, 2, 128, 3),           # FuXi's 7 x 7 windows and 128-wide heads
+    "lat_clipped": ((4, 16), 4, 2, 64, 2),           # the map is one window tall: that axis is neither clipped further nor shifted
+}
+
+
+def test_timm_mask_and_bias_restatement():
+    """What can be said about timm's mask / bias without timm: (1) with a latitude-only shift the 3 x 3-slice mask IS the reference's
+    own V2-Cr mask (swin.py:411-427, pinned by swin_attention.npz); (2) inside any window it has at most 2 x 2 regions, only in the
+    last window row / column -- the property the kernel's two limits rely on; (3) the host table (numpy float64) equals the oracle's."""
+    for feat, ws, sh in (((12, 24), (4, 4), (2, 0)), ((14, 21), (7, 7), (3, 0))):
+        assert torch.equal(S.shift_mask_timm(feat, ws, sh), S.shift_mask(feat, ws, sh))
+    feat, ws, sh = (12, 24), (4, 8), (2, 4)
+    m = S.shift_mask_timm(feat, ws, sh).reshape(feat[0] // ws[0], feat[1] // ws[1], ws[0] * ws[1], ws[0] * ws[1])
+    for wy in range(m.shape[0]):
+        for wx in range(m.shape[1]):
+            t = torch.arange(ws[0] * ws[1])
+            reg = (t // ws[1] >= feat[0] - sh[0] - wy * ws[0]).long() + 2 * (t % ws[1] >= feat[1] - sh[1] - wx * ws[1]).long()
+            want = torch.where(reg[:, None] != reg[None, :], -100.0, 0.0)
+            assert torch.equal(m[wy, wx], want), (wy, wx)
+            if wy < m.shape[0] - 1 and wx < m.shape[1] - 1:
+                assert not m[wy, wx].any()
+    from wxengine.swin import cpb_position_bias
+    sd = timm_stage_dict(64, 2, 1)
+    for ws in ((4, 4), (7, 7), (4, 8)):
+        host = cpb_position_bias(sd["blocks.0.attn.cpb_mlp.0.weight"].numpy(), sd["blocks.0.attn.cpb_mlp.0.bias"].numpy(),
+                                 sd["blocks.0.attn.cpb_mlp.2.weight"].numpy(), ws)
+        orc = S.cpb_position_bias({k: v.double() for k, v in sd.items()}, "blocks.0.attn.", ws, 2, torch.float64)
+        assert host.shape == (2, ws[0] * ws[1], ws[0] * ws[1]) and 0.0 <= host.min() and host.max() <= 16.0
+        np.testing.assert_allclose(host, orc.numpy(), rtol=0, atol=2e-6)
+        assert np.allclose(host[:, 0, 0], host[:, 5, 5])        # a function of the offset only: the diagonal is constant
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", sorted(TIMM_CASES))
+def test_hip_swin_stage_timm_variant_vs_oracle(name, prec):
+    """wxengine.swin.SwinStage(variant="timm") -- q / v bias, 16 sigmoid(cpb) table, both-axes mask -- against block_timm / stage_timm
+    after one block and after the whole stage; fp32 1e-4 * max, bf16 rel-L2 2e-2 (the gates of the pinned V2-Cr variant)."""
+    from wxengine.swin import SwinStage
+    feat, window, heads, hd, depth = TIMM_CASES[name]
+    dim = heads * hd
+    sd = timm_stage_dict(dim, heads, depth, seed=len(name))
+    x = torch.randn(feat[0], feat[1], dim, generator=torch.Generator().manual_seed(3))
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    for d in (1, depth):
+        st = SwinStage(dim=dim, depth=d, num_heads=heads, feat_size=feat, window_size=window, precision=prec, variant="timm")
+        st.load_state_dict(sd)
+        got = st(x.to(dt).cuda().contiguous()).float().cpu().double()
+        ref = S.stage_timm(x.double(), {k: v.double() for k, v in sd.items()}, heads, window, d)
+        scale, err = float(ref.abs().max()), float((got - ref).abs().max())
+        if prec == "fp32":
+            assert err <= 1e-4 * scale, f"{name} depth {d}: fp32 max err {err:.3e} of {scale:.3e}"
+        else:
+            l2 = float((got - ref).norm() / ref.norm())
+            assert l2 <= 2e-2 and err <= 6e-2 * scale, f"{name} depth {d}: bf16 rel-L2 {l2:.3e}, max err {err:.3e} of {scale:.3e}"
+    # the longitude seam matters: the V2-Cr mask on the same weights gives a different answer wherever a window straddles it
+    if name == "rect_both_axes":
+        from wxengine.swin import WindowAttention, cpb_position_bias, effective_logit_scale
+        qkv = torch.randn(feat[0], feat[1], 3 * dim, generator=torch.Generator().manual_seed(5)).cuda()
+        kw = dict(feat=feat, heads=heads, head_dim=hd, window=window, shift=(2, 2), precision="fp32",
+                  bias=cpb_position_bias(sd["blocks.1.attn.cpb_mlp.0.weight"].numpy(), sd["blocks.1.attn.cpb_mlp.0.bias"].numpy(),
+                                         sd["blocks.1.attn.cpb_mlp.2.weight"].numpy(), (window, window)),
+                  logit_scale=effective_logit_scale(sd["blocks.1.attn.logit_scale"].numpy().ravel()))
+        both, lat = WindowAttention(mask_axes=3, **kw)(qkv).cpu(), WindowAttention(mask_axes=1, **kw)(qkv).cpu()
+        seam = torch.tensor([(c - 2) % feat[1] >= feat[1] - window for c in range(feat[1])])   # original columns inside the last rolled window column
+        assert torch.equal(both[:, ~seam], lat[:, ~seam])
+        assert (both[:, seam] - lat[:, seam]).abs().max() > 1e-3
