@@ -26,6 +26,7 @@
 #include <rccl/rccl.h>   // types and prototypes only: the library is bound with dlopen when a communicator is requested
 #include "wx_gemm.h"
 #include "wx_gemm_stream.h"
+#include "wx_gemm_wreg.h"
 #include "wx_attn_block.h"
 #include "wx_swin.h"
 #include "wx_fuxi.h"
@@ -934,14 +935,30 @@ class Engine : public EngineBase {
   int skinny_steps = getenv("WX_SKINNY_STEPS") ? std::max(1, atoi(getenv("WX_SKINNY_STEPS"))) : 2;   // 128-byte K steps per range, at least
   int skinny_min_nk = getenv("WX_SKINNY_MIN_NK") ? atoi(getenv("WX_SKINNY_MIN_NK")) : 16;
   int skinny_tiles = getenv("WX_SKINNY_TILES") ? atoi(getenv("WX_SKINNY_TILES")) : 32;
-  float* splitk_buf = nullptr;
-  size_t splitk_bytes = 0;
+  int skinny_tiles_band = getenv("WX_SKINNY_TILES_BAND") ? atoi(getenv("WX_SKINNY_TILES_BAND")) : 128;
+  float* splitk_buf = nullptr;   // fp32 partial sums of every split-K form (plain, skinny, hidden-split FeedForward): ONE buffer, sized in
+  size_t splitk_bytes = 0;       // alloc_activations from the split rules' own bounds -- the forward never allocates (hipMalloc inside a
+                                 // forward would also be illegal under the opt-in graph capture)
+  size_t splitk_bound() const {
+    const size_t tile = (size_t)128 * 128 * sizeof(float);
+    size_t b = (size_t)512 * tile;                                                               // plain rule: S * tiles <= 512
+    b = std::max(b, (size_t)std::max(std::max(skinny_tiles, skinny_tiles_band), 1) * (size_t)std::max(skinny_max, 1) * tile); // skinny rule: tiles <= skinny_tiles, S <= skinny_max
+    b = std::max(b, (size_t)std::max(ff_split_tiles, 1) * 128 * 256 * (size_t)std::max(ff_split_max, 1) * sizeof(float));   // <= ff_split_tiles pixel tiles of <= 128 px, C <= 256
+    return b;
+  }
+  float* splitk_scratch(size_t need) {
+    if (need > splitk_bytes) throw StateError("split-K scratch: a launch asks for " + std::to_string(need) + " bytes, " + std::to_string(splitk_bytes) + " were reserved (the split rules and splitk_bound() disagree)");
+    return splitk_buf;
+  }
   bool embed_split = !getenv("WX_NO_EMBED_SPLIT");
   int embed_split_ways = getenv("WX_EMBED_SPLIT") ? std::max(2, atoi(getenv("WX_EMBED_SPLIT"))) : 4;
   float* embed_partial = nullptr;
   size_t embed_partial_bytes = 0;
   bool use_stream = !(getenv("WX_NO_STREAM") && getenv("WX_NO_STREAM")[0] == '1');   // persistent large-tile GEMM (wx_gemm_stream.h) for the LN-folded 1x1 layers of the deep stages
   int stream_min_rows = 4096;
+  bool use_wreg = !(getenv("WX_NO_WREG") && getenv("WX_NO_WREG")[0] == '1');   // weight-stationary GEMM (wx_gemm_wreg.h) for K = 512 layers on mid-sized maps
+  int wreg_min_rows = getenv("WX_WREG_MIN_ROWS") ? atoi(getenv("WX_WREG_MIN_ROWS")) : 1024;
+  int wreg_max_rows = getenv("WX_WREG_MAX_ROWS") ? atoi(getenv("WX_WREG_MAX_ROWS")) : 4096;
   char* stream_sink = nullptr;
   int dbg_flags = 0;
   int gemm_cfg = 0;
@@ -1005,6 +1022,8 @@ class Engine : public EngineBase {
     WX_HIP(hipMemset(zero_page, 0, 256));
     if (const char* e = getenv("WX_NO_DMA")) use_dma = !(e[0] == '1');
     stream_sink = (char*)dalloc(4096);
+    splitk_bytes = splitk_bound();
+    splitk_buf = (float*)dalloc(splitk_bytes);
     if (const char* e = getenv("WX_DBG")) dbg_flags = atoi(e);
     if (const char* e = getenv("WX_STREAM_MIN_ROWS")) stream_min_rows = atoi(e);
     if (const char* e = getenv("WX_GEMM_CFG")) gemm_cfg = atoi(e);
@@ -1301,6 +1320,30 @@ class Engine : public EngineBase {
       // LayerNorm-folded 1x1 layers with many rows and K >= 512 (to_qkv, FeedForward layer 1 of stages 2-3): the persistent
       // 128 x 256-tile kernel; measured per shape against the 128 x 128 kernel in tools/gemm_stream_probe
       const bool one = w.kh == 1 && w.kw == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && in_h == out_h && in_w == out_w;
+      // K = 512 layers on maps of a few thousand rows (a lat-band rank's share of the 0.25-degree stage 2: 2 000 - 4 000 tokens): the
+      // weight-stationary kernel (wx_gemm_wreg.h: the wave's weight slice in registers, activations streamed tile by tile, one barrier
+      // per tile).  tools/gemm_wreg_probe, M = 2500: to_qkv 11.5 us against 16.1 (persistent kernel) -- at M = 20 000 the two tie, so the
+      // unsharded model keeps the persistent kernel.  Bitwise the same outputs; row partials in N / 32 slots instead of N / 128.
+      {
+        const int64_t rows = (int64_t)out_h * out_w;
+        const bool ln_v = rs && !res && !want_stats && w.colsum >= 0, res_v = !rs && res && want_stats && fuse_ln && act == 0;
+        if (use_wreg && use_dma && w.wt_kb >= 0 && one && w.cin == 512 && w.n % WREG_BN == 0 && w.bias >= 0 && out_mode == 0 && !want_gn && !dbg_flags &&
+            !blk_hidden && rows >= wreg_min_rows && rows < wreg_max_rows && (ln_v || (res_v && w.n / 32 <= WREG_MAXT)) &&
+            wreg_gemm_ok(rows, w.n, w.cin, p.stat_tiles, ln_v)) {
+          StreamGemmParams q;
+          std::memset(&q, 0, sizeof(q));
+          q.a = reinterpret_cast<const bf16_t*>(in); q.lda = in_ld; q.w = reinterpret_cast<const bf16_t*>(wt_dev + w.wt_kb);
+          q.M = (int)rows; q.N = w.n; q.K = w.cin; q.bias = p.bias; q.colsum = p.colsum;
+          q.rowstat = rs; q.stat_tiles = p.stat_tiles; q.stat_inv_c = p.stat_inv_c;
+          q.res = reinterpret_cast<const bf16_t*>(res); q.res_ld = res_ld;
+          q.stat_out = res_v ? statpart : nullptr; q.stat_slots = w.n / 32;
+          q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
+          cur_family = "wreg";
+          timed(cls, flops, bytes, [&] { launch_gemm_wreg(q, res_v ? 3 : (act == 1 ? 2 : 1), cur_stream); });
+          if (res_v) last_stat_slots = q.stat_slots;
+          return res_v;
+        }
+      }
       // residual layers with N = 512 / 1024 (to_out, FeedForward layer 2 of stages 2 and 3): 160 x 128 tiles, two workgroups per CU
       // (47.9 vs 58.3 us on layer 2, 21.0 vs 23.2 us on to_out; bitwise equal to the 128 x 128 kernel's output)
       if (use_stream && use_dma && w.wt_kb >= 0 && one && !rs && res && act == 0 && out_mode == 0 && want_stats && fuse_ln && !want_gn &&
@@ -1346,8 +1389,7 @@ class Engine : public EngineBase {
       const int S = plain_split_ways(w, (int64_t)out_h * out_w);
       if (S >= 2) {
         const size_t need = (size_t)S * out_h * out_w * w.n * sizeof(float);
-        if (need > splitk_bytes) { splitk_buf = (float*)dalloc(need); splitk_bytes = need; }
-        p.partial = splitk_buf;
+        p.partial = splitk_scratch(need);
         p.k_splits = S;
       }
     }
@@ -1359,10 +1401,11 @@ class Engine : public EngineBase {
       const int64_t tiles = (int64_t)cdiv((int64_t)out_h * out_w, 128) * conv_gemm_n_tiles(w.n);
       const int nk = w.cin * (int)sizeof(T) / 128;
       const int S = std::min(skinny_max, nk / skinny_steps);
-      if (tiles <= skinny_tiles && nk >= skinny_min_nk && S >= 2) {
+      // lat-band ranks: a rank's share of the 0.25-degree stage 2 is ~80 tiles walking K = 2048 alone (FeedForward layer 2: 40 us) -- the
+      // rule tuned on the 1-degree model (<= 32 tiles) is widened there (slowest of 8 ranks 4.62 -> 4.53 ms)
+      if (tiles <= (band_on ? std::max(skinny_tiles, skinny_tiles_band) : skinny_tiles) && nk >= skinny_min_nk && S >= 2) {
         const size_t need = (size_t)S * out_h * out_w * w.n * sizeof(float);
-        if (need > splitk_bytes) { splitk_buf = (float*)dalloc(need); splitk_bytes = need; }
-        p.partial = splitk_buf;
+        p.partial = splitk_scratch(need);
         p.k_splits = S;
       }
     }
@@ -1505,7 +1548,7 @@ class Engine : public EngineBase {
         const int S = std::min(ff_split_max, nch / 4);
         const int ch_per = cdiv(nch, S), S_eff = cdiv(nch, ch_per);
         const size_t need = (size_t)S_eff * m * c * sizeof(float);
-        if (need > splitk_bytes) { splitk_buf = (float*)dalloc(need); splitk_bytes = need; }
+        splitk_scratch(need);
         FFParams fp{};
         fp.x = reinterpret_cast<const bf16_t*>(x); fp.ld = ld; fp.out = reinterpret_cast<bf16_t*>(x); fp.out_ld = ld;
         fp.M = m; fp.hidden = 4 * c; fp.wpack = reinterpret_cast<const char*>(wt_dev + f.pack);
@@ -1842,7 +1885,11 @@ class Engine : public EngineBase {
   void* band_comm_stream(void* adopt) override {
     band_need();
     WX_HIP(hipSetDevice(device));
+    // never while an exchange is in flight: band_resume records its "done" event on b_cstream, and the unpack waits on that event --
+    // swapping the stream (or destroying the one the engine owns) mid-exchange would leave the bytes in flight unordered
+    if (b_pending >= 0) throw StateError("wx_band_comm_stream: a step is in flight");
     if (adopt) {
+      if (b_cstream && b_cstream != (hipStream_t)adopt) WX_HIP(hipStreamSynchronize(b_cstream));
       if (b_cstream_own && b_cstream) (void)hipStreamDestroy(b_cstream);
       b_cstream = (hipStream_t)adopt; b_cstream_own = false;
     } else if (!b_cstream) {
@@ -1855,7 +1902,6 @@ class Engine : public EngineBase {
     }
     b_async = true;
     if (!b_split) {   // an overlapped transport: give it something to overlap with
-      if (b_pending >= 0) throw StateError("wx_band_comm_stream: a step is in flight");
       b_split = true;
       band_build_program();
     }

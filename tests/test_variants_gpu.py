@@ -153,6 +153,52 @@ def test_persistent_gemm_forced_on_small_maps(name):
     print(f"[stream parity] {name}: {len(deep)} deep-stage captures, {n_diff} differ bitwise from the 128x128 path; y vs plain {l2:.2e}, vs oracle {l2o:.2e}")
 
 
+@pytest.mark.parametrize("name", ["T5", "C1"])
+def test_weight_stationary_gemm_forced_on_small_maps(name):
+    """`gemm_wreg_kernel` (wx_gemm_wreg.h: weights in registers, activations streamed in 32-row tiles) takes the K = 512 layers on maps
+    of 1024 .. 4095 rows by itself -- a lat-band rank's share of the 0.25-degree stage 2.  WX_WREG_MIN_ROWS=0 forces it onto T5's
+    stage 2 (C = 512 on 200 rows: ragged last tile, fewer tiles than workgroups) and C1's stage 3 (C = 512 on 360 rows), where its
+    three epilogues run: LN fold from partials AND from final row statistics, LN fold + GELU, residual + row partials (16 slots).
+    Checked like the persistent kernel: against the engine without it, per block against the oracle, run-to-run, and by family tag."""
+    from oracle import wxformer_oracle as O
+    cfg = named_config(name)
+    sd = synth_state_dict(cfg)
+    xin = synth_input(cfg)
+    x = torch.from_numpy(xin).cuda()
+    wreg = _engine(name, "bf16", {"WX_WREG_MIN_ROWS": "0", "WX_SKINNY_MAX": "0"})   # (the skinny split-K rule would take C1's 360-row layers first)
+    plain = _engine(name, "bf16", {"WX_NO_WREG": "1", "WX_SKINNY_MAX": "0"})
+    cap = {}
+    y_ref = O.forward(cfg, sd, xin, capture=cap)
+    outs = {}
+    for tag, eng in (("wreg", wreg), ("plain", plain)):
+        eng.set_debug(True)
+        y = eng.forward(x).clone()
+        outs[tag] = (y, {k: eng.debug_read(k) for k in cap})
+        eng.set_debug(False)
+    assert torch.equal(outs["wreg"][0], wreg.forward(x)), "weight-stationary GEMM: two runs differ (race)"
+    for eng, want in ((wreg, True), (plain, False)):
+        eng.profile(3)
+        eng.profile_reset()
+        eng.forward(x)
+        torch.cuda.synchronize()
+        tagged = [r["name"] for r in eng.profile_read() if r["name"].endswith("@wreg")]
+        eng.profile(0)
+        assert bool(tagged) == want, tagged
+        if want:
+            assert {t.split(".")[0] for t in tagged} >= {"gemm_qkv", "gemm_out", "gemm_ff1"}, tagged
+    stage = "layers.2.1." if name == "T5" else "layers.3.1."
+    deep = [k for k in cap if k.startswith(stage)]
+    assert len(deep) >= 4, deep
+    for k in deep:
+        ref = cap[k][0].numpy().astype(np.float64)
+        a, b = outs["wreg"][1][k].astype(np.float64), outs["plain"][1][k].astype(np.float64)
+        assert np.linalg.norm(a - ref) / np.linalg.norm(ref) <= 2e-2, k
+        assert np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30) <= 8e-3, k
+    yr = y_ref.numpy().astype(np.float64)
+    l2o = np.linalg.norm(outs["wreg"][0].cpu().numpy().astype(np.float64) - yr) / np.linalg.norm(yr)
+    assert l2o <= 2e-2, f"{name}: forward vs oracle rel-L2 {l2o:.3e}"
+
+
 @pytest.mark.parametrize("name", ["T1", "T5", "C1", "RT"])
 def test_attention_block_kernel_opt_in(name):
     """`attn_block_kernel` (wx_attn_block.h: LayerNorm + to_qkv + window attention + to_out + residual in one launch, q|k|v never in

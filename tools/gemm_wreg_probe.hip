@@ -10,7 +10,7 @@
 #include <random>
 #include <vector>
 
-#include "wx_gemm_wreg.h"
+#include "wx_gemm_wreg32.h"
 
 using namespace wx;
 
@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
     shapes.push_back({19987, 512, 512, 3, 0, "tail M out"});
     shapes.push_back({101, 2048, 512, 2, 8, "tiny ff1 (T = 8)"});
     shapes.push_back({2500, 1536, 512, 1, 1, "band-sized qkv (T = 1)"});
+    shapes.push_back({2501, 2048, 512, 2, -1, "band-sized ff1, final row statistics (T = 0)"});
   }
   hipStream_t st;
   WX_HIP(hipStreamCreate(&st));
@@ -103,7 +104,8 @@ int main(int argc, char** argv) {
     StreamGemmParams q;
     std::memset(&q, 0, sizeof(q));
     q.a = x; q.lda = K; q.w = wblk; q.M = M; q.N = N; q.K = K; q.bias = bias; q.colsum = colsum; q.o_blk = o_blk; q.o_rows = M;
-    q.rowstat = ln ? rowstat : nullptr; q.stat_tiles = T; q.stat_inv_c = 1.f / K;
+    q.rowstat = ln ? rowstat : nullptr; q.stat_tiles = s.T < 0 ? 0 : T; q.stat_inv_c = 1.f / K;
+    if (s.T < 0) WX_HIP(hipMemcpy(rowstat, hs.data(), (size_t)M * 8, hipMemcpyHostToDevice));   // final (mean, rstd) per row
     q.res = res ? rs : nullptr; q.res_ld = N; q.out_ld = N; q.sink = sink;
     StreamGemmParams q_old = q, q_new = q;
     q_old.out = y0; q_old.stat_out = res ? so0 : nullptr; q_old.stat_slots = 2 * (N / 128);
@@ -114,7 +116,7 @@ int main(int argc, char** argv) {
       else launch_gemm_stream_n128<5, 3, 2>(q_old, st);
     };
     const bool m32 = getenv("WX_M32") != nullptr;
-    auto run_new = [&] { launch_gemm_wreg(q_new, s.variant, st, m32); };
+    auto run_new = [&] { if (m32) launch_gemm_wreg32(q_new, s.variant, st); else launch_gemm_wreg(q_new, s.variant, st); };
     WX_HIP(hipMemset(y0, 0, (size_t)M * N * 2));
     WX_HIP(hipMemset(y1, 0xff, (size_t)M * N * 2));
     run_old();
