@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--no-config2", action="store_true", help="skip the secondary BASELINE-config-2 (1-degree, 24-step rollout) measurement")
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary exact-f32 measurement (the mode whose outputs meet "
                                                             "the stated fp32 tolerance against the reference)")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the secondary measurement of two forecasts in flight on the one GPU")
     ap.add_argument("--no-host-delivery", action="store_true", help="skip the PCIe-inclusive measurement (every step's output delivered to pinned host memory)")
     ap.add_argument("--per-step-calls", action="store_true", help="drive the loop with one wx_step call per step from Python "
                                                                   "instead of one wx_rollout call for the K steps")
@@ -165,6 +166,39 @@ def main():
                                  "overlapped with the next step's compute; one wx_step call per step); PCIe Gen5 x16 = 63 GB/s spec"}
         del hd
 
+    concurrent = None
+    if rank == 0 and world == 1 and args.config == "C3" and not args.no_concurrent:
+        # Serving option, never `value`: TWO forecasts (init times) in flight on the one GPU, each on its own engine + stream
+        # (wxengine.replicas.ForecastPool) -- the reference walks a rank's init times one at a time (rollout_to_netcdf.py:259-262).
+        from wxengine.replicas import ForecastPool
+
+        def make():
+            e = WXEngine(cfg, args.precision, local_rank)
+            e.load_state_dict(sd)
+            e.finalize()
+            e.set_denorm(mean, std)
+            e.set_layout(n_prog, n_static, n_dyn)
+            e.set_tracer_fixer(q_inds, [1e-8] * len(q_inds), None, denorm=True)
+            return e
+        pool = ForecastPool(make, 2, local_rank)
+        nc = max(2, min(args.steps, 20))
+        jobs = []
+        for i in range(2):
+            xi = torch.from_numpy(synth_input(cfg, seed=2000 + i)).to(dev)
+            jobs.append(dict(x0=xi, forcings=[frcs[t % n_frc] for t in range(nc)], phys_out=[torch.empty_like(y_phys)] * nc, x_final=torch.empty_like(xi)))
+        pool.rollout_all([dict(j, forcings=j["forcings"][:3], phys_out=j["phys_out"][:3]) for j in jobs])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pool.rollout_all(jobs)
+        torch.cuda.synchronize()
+        ec = time.perf_counter() - t1
+        concurrent = {"forecasts_in_flight": 2, "value": round(2 * nc / ec, 3), "unit": "forecast-steps/sec (aggregate of the two forecasts)",
+                      "steps_per_forecast": nc, "ms_per_step_per_forecast": round(1e3 * ec / nc, 3),
+                      "finite_outputs": bool(all(torch.isfinite(j["phys_out"][0]).all().item() for j in jobs)),
+                      "note": "two engines + two HIP streams on one GPU (wxengine.replicas.ForecastPool); each forecast is B = 1 and bit-identical "
+                              "to running it alone; the headline `value` above is ONE forecast in flight"}
+        del pool, jobs
+
     roofline = None
     if rank == 0 and not args.no_roofline:
         eng.profile(True)
@@ -183,7 +217,7 @@ def main():
         # HBM traffic of the same kernel from the PMC passes of tools/collect_profiles.sh (rocprofv3 cannot run inside
         # this process; the summary is committed next to the kernel-stats it was collected with)
         traffic = None
-        tname = next((n for n in ("pmc_traffic_r03.json", "pmc_traffic_r01.json") if os.path.isfile(os.path.join(ROOT, "profiles", n))), None)
+        tname = next((n for n in ("pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r01.json") if os.path.isfile(os.path.join(ROOT, "profiles", n))), None)
         if args.config == "C3" and args.precision == "bf16" and tname:
             kern = json.load(open(os.path.join(ROOT, "profiles", tname)))["kernels"]
             fam = [kern[k] for k in ("wx::conv_gemm_dma_kernel", "wx::gemm_stream_kernel") if k in kern]
@@ -351,7 +385,7 @@ def main():
                        "parallelism": f"replicas over init times x{world} (no data-path collective)",
                        "loop": "one wx_step call per step" if args.per_step_calls else "wx_rollout (the K steps in one C-ABI call)",
                        "total_steps": total_steps, "params": cfg.num_params(), "finite_outputs": finite},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "fp32": fp32, "host_delivery": host_delivery, "config2": config2, "config5": config5,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "fp32": fp32, "host_delivery": host_delivery, "concurrent_forecasts": concurrent, "config2": config2, "config5": config5,
         }
         print(json.dumps(out), flush=True)
     grp.close()

@@ -121,8 +121,17 @@ constexpr int attn_min_waves(int nkf, int dh, int elem, bool sw) {
 // SW: the Swin-mode features (kind 3 token map, seam mask, cosine attention, per-block q scaling).  A template switch, not a
 // run-time one: the mask test used to split the score loop into one basic block per key fragment, and hipcc schedules inside
 // basic blocks -- the WXFormer launches paid for a mode they never use (58 -> 70 us per 100-token launch, round-2 profile).
-template <typename T, int NKF, bool SPLIT, bool BT, int DH = 32, bool SW = false>
+// B2W (round 4; BT kernels, even square windows of B2W x B2W tokens): tokens are numbered in 2 x 2 BLOCKS -- token 4 b + r is pixel
+// (2 by + (r >> 1), 2 bx + (r & 1)) of block b = (by, bx) -- for queries, keys and the V image alike (a softmax does not care about
+// the order of its keys, and every use of a token index goes through token_pixel / s_bk).  The four keys a lane holds per fragment
+// (4 g .. 4 g + 3) are then one block, and their four position-bias entries depend on ONE offset (query pixel - block origin): the
+// LDS table holds, per offset, the four entries as a float4 ((2w - 1)^2 x 16 bytes = 5.8 KB at w = 10 instead of the 4 KB scalar
+// table), so a fragment's bias is one subtraction + one ds_read_b128 straight into the MFMA accumulator instead of a ds_read_b128
+// of four offsets + four subtractions + four ds_read_b32; the block's table offset is loop-invariant (7 registers per lane).  The
+// bias gather was 63 of the ~260 instructions of a 16-query block; it is 14 (+ 4 selects for the padded key blocks).
+template <typename T, int NKF, bool SPLIT, bool BT, int DH = 32, bool SW = false, int B2W = 0>
 __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) void window_attn_kernel(const AttnParams p) {
+  static_assert(B2W == 0 || (BT && !SW && !SPLIT && B2W % 2 == 0 && B2W * B2W <= NKF * 16 && (B2W * B2W) % 4 == 0), "2 x 2-block token order: BT kernels, even windows");
   constexpr int TBN = 1024;  // LDS bias table: [0, (2w-1)^2) the offsets, the rest -1e30 (padded keys index there)
   constexpr int D = DH;      // head dimension: 32 (CrossFormer), up to 128 (FuXi's Swin stage)
   constexpr int NDF = D / 16;
@@ -188,6 +197,12 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
       wy = q;
       wx_ = w - q * wins_x;
     }
+    if constexpr (B2W > 0) {   // block order: tl = 4 b + r -> (ty, tx) -> the row-major token index the linear form below expects
+      const int b = tl >> 2, r = tl & 3;
+      const int by = (int)(((unsigned)b * ((65536u + B2W / 2 - 1) / (B2W / 2))) >> 16), bx = b - by * (B2W / 2);
+      const int ty2 = 2 * by + (r >> 1);
+      tl = ty2 * B2W + 2 * bx + (r & 1);
+    }
     const int ty = (int)(((unsigned)tl * mg_x) >> 16);
     if (SW && p.kind == 3) {  // window of the rolled map: rolled (r, c) holds pixel ((r + shift_y) % H, (c + shift_x) % W)
       int py = wy * p.wsz + ty + p.shift_y;
@@ -220,11 +235,22 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
   const size_t k_col = (size_t)p.C * sizeof(T), v_col = 2 * k_col;
   T* vt = reinterpret_cast<T*>(smem + (SPLIT ? 0 : wave) * VT_BYTES);
   float* s_tb = reinterpret_cast<float*>(smem + (SPLIT ? 1 : 4) * VT_BYTES);
-  int* s_bk = reinterpret_cast<int*>(s_tb + TBN);   // [NP] byte offset 4*(ty*(2w-1)+tx) of token t, or -2048 when padded
+  constexpr int TB2 = B2W > 0 ? ((2 * B2W - 1) * (2 * B2W - 1) + 7) / 8 * 8 : 0;   // B2W: float4 entries of the block table
+  int* s_bk = reinterpret_cast<int*>(s_tb + (B2W > 0 ? TB2 * 4 : TBN));   // [NP] byte offset 4*(ty*(2w-1)+tx) of token t, or -2048 when padded
   int* s_row = BT ? s_bk + NP : reinterpret_cast<int*>(s_tb);   // [NP] window row ty of token t (kind 3: the shift mask's regions)
   // position-bias generating table: requested FIRST, so that waiting for it (vmcnt is in-order) leaves the K / V loads in flight
   float tbv[BT ? TBN / 256 : 1];
-  if constexpr (BT) {
+  float tb4[B2W > 0 ? (TB2 + 255) / 256 : 1][4];
+  if constexpr (B2W > 0) {
+    // entry e = (dy + w - 1) * (2w - 1) + (dx + w - 1), (dy, dx) = query pixel - block origin: the bias of the block's keys
+    // (0, 0), (0, 1), (1, 0), (1, 1) = tb[e], tb[e - 1], tb[e - (2w - 1)], tb[e - 2w] (entries no valid pair reaches are clamped)
+    constexpr int SD = 2 * B2W - 1;
+#pragma unroll
+    for (int i = 0; i < (TB2 + 255) / 256; ++i) {
+      const int e = min((int)threadIdx.x + i * 256, SD * SD - 1);
+      tb4[i][0] = p.tb[e]; tb4[i][1] = p.tb[max(e - 1, 0)]; tb4[i][2] = p.tb[max(e - SD, 0)]; tb4[i][3] = p.tb[max(e - SD - 1, 0)];
+    }
+  } else if constexpr (BT) {
     const int side2 = (2 * p.wsz - 1) * (2 * p.wsz - 1);
 #pragma unroll
     for (int i = 0; i < TBN / 256; ++i) tbv[i] = p.tb[min((int)threadIdx.x + i * 256, side2 - 1)];
@@ -259,18 +285,35 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
   if (SW && p.kind == 3 && threadIdx.x < NP) s_row[threadIdx.x] = ((int)threadIdx.x / wsx) | (((int)threadIdx.x % wsx) << 8);   // (ty, tx) of token t
   if constexpr (BT) {
     const int side = 2 * p.wsz - 1;
+    if constexpr (B2W > 0) {
 #pragma unroll
-    for (int i = 0; i < TBN / 256; ++i) {
-      const int e = (int)threadIdx.x + i * 256;
-      s_tb[e] = e < side * side ? tbv[i] : -1.0e30f;
+      for (int i = 0; i < (TB2 + 255) / 256; ++i) {
+        const int e = (int)threadIdx.x + i * 256;
+        if (e < TB2) *reinterpret_cast<float4*>(s_tb + 4 * e) = make_float4(tb4[i][0], tb4[i][1], tb4[i][2], tb4[i][3]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TBN / 256; ++i) {
+        const int e = (int)threadIdx.x + i * 256;
+        s_tb[e] = e < side * side ? tbv[i] : -1.0e30f;
+      }
     }
     if (threadIdx.x < NP) {
       const int t = threadIdx.x;
-      const int ty = (int)(((unsigned)t * ((65536u + (unsigned)p.wsz - 1u) / (unsigned)p.wsz)) >> 16), tx = t - ty * p.wsz;
+      int ty = (int)(((unsigned)t * ((65536u + (unsigned)p.wsz - 1u) / (unsigned)p.wsz)) >> 16), tx = t - ty * p.wsz;
+      if constexpr (B2W > 0) {
+        const int b = t >> 2, r = t & 3, by = b / (B2W / 2), bx = b - by * (B2W / 2);
+        ty = 2 * by + (r >> 1); tx = 2 * bx + (r & 1);
+      }
       s_bk[t] = t < N ? 4 * (ty * side + tx) : -2048;
     }
   }
   if constexpr (!SPLIT) attn_lds_barrier();
+  int bk0[B2W > 0 ? NKF : 1];   // B2W: 16-byte table offset of the 2 x 2 key block this lane holds in fragment j (loop-invariant);
+  if constexpr (B2W > 0) {      // a padded block (keys >= N) reads entry 0 and is overwritten with -1e30 below
+#pragma unroll
+    for (int j = 0; j < NKF; ++j) bk0[j] = 4 * max(s_bk[j * 16 + g * 4], 0);
+  }
   if (SW && p.logit_scale) {
 #pragma unroll
     for (int j = 0; j < NKF; ++j) cosine_normalise<T, QK_SUBS>(kf[j], 1.0f);
@@ -509,9 +552,17 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
       const char* tbb = reinterpret_cast<const char*>(s_tb) + aq;
 #pragma unroll
       for (int j = 0; j < NKF; ++j) {
-        const int4 bk = *reinterpret_cast<const int4*>(s_bk + j * 16 + g * 4);
-        bt[j] = make_float4(*reinterpret_cast<const float*>(tbb - bk.x), *reinterpret_cast<const float*>(tbb - bk.y),
-                            *reinterpret_cast<const float*>(tbb - bk.z), *reinterpret_cast<const float*>(tbb - bk.w));
+        if constexpr (B2W > 0) {
+          bt[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_tb) + 4 * aq - bk0[j]);
+          if ((j * 16 + 15) >= B2W * B2W) {   // fragments that contain padded key blocks (compile-time: the last one)
+            const bool pad = j * 16 + g * 4 >= N;
+            bt[j] = pad ? make_float4(-1.0e30f, -1.0e30f, -1.0e30f, -1.0e30f) : bt[j];
+          }
+        } else {
+          const int4 bk = *reinterpret_cast<const int4*>(s_bk + j * 16 + g * 4);
+          bt[j] = make_float4(*reinterpret_cast<const float*>(tbb - bk.x), *reinterpret_cast<const float*>(tbb - bk.y),
+                              *reinterpret_cast<const float*>(tbb - bk.z), *reinterpret_cast<const float*>(tbb - bk.w));
+        }
       }
     }
 #pragma unroll
@@ -552,11 +603,33 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
       // (found as a run-to-run difference at 721 x 1440).  Hence: nothing moves across the barrier, and the first asm
       // statement waits out the longest MFMA write-back (19 wait states) itself.
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+      if constexpr (NKF == 7 && B2W > 0) {
+        // the whole chain as ONE statement: between separate asm statements hipcc puts an s_nop 0 (14 issue slots per block); two
+        // interleaved chains halve the dependent latency (VALU -> VALU dependencies are interlocked by the hardware)
+        float m2 = mx;
+        asm volatile(
+            "s_nop 7\n\ts_nop 7\n\ts_nop 2\n\t"
+            "v_max3_f32 %0, %0, %2, %3\n\tv_max3_f32 %1, %1, %4, %5\n\t"
+            "v_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %1, %1, %8, %9\n\t"
+            "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %1, %1, %12, %13\n\t"
+            "v_max3_f32 %0, %0, %14, %15\n\tv_max3_f32 %1, %1, %16, %17\n\t"
+            "v_max3_f32 %0, %0, %18, %19\n\tv_max3_f32 %1, %1, %20, %21\n\t"
+            "v_max3_f32 %0, %0, %22, %23\n\tv_max3_f32 %1, %1, %24, %25\n\t"
+            "v_max3_f32 %0, %0, %26, %27\n\tv_max3_f32 %1, %1, %28, %29\n\t"
+            "v_max_f32 %0, %0, %1"
+            : "+v"(mx), "+v"(m2)
+            : "v"(sv[0][0]), "v"(sv[0][1]), "v"(sv[0][2]), "v"(sv[0][3]), "v"(sv[1][0]), "v"(sv[1][1]), "v"(sv[1][2]), "v"(sv[1][3]),
+              "v"(sv[2][0]), "v"(sv[2][1]), "v"(sv[2][2]), "v"(sv[2][3]), "v"(sv[3][0]), "v"(sv[3][1]), "v"(sv[3][2]), "v"(sv[3][3]),
+              "v"(sv[4][0]), "v"(sv[4][1]), "v"(sv[4][2]), "v"(sv[4][3]), "v"(sv[5][0]), "v"(sv[5][1]), "v"(sv[5][2]), "v"(sv[5][3]),
+              "v"(sv[6][0]), "v"(sv[6][1]), "v"(sv[6][2]), "v"(sv[6][3])
+            : "memory");
+      } else {
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
 #pragma unroll
-      for (int j = 0; j < NKF; ++j) {
-        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][0]), "v"(sv[j][1]));
-        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][2]), "v"(sv[j][3]));
+        for (int j = 0; j < NKF; ++j) {
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][0]), "v"(sv[j][1]));
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sv[j][2]), "v"(sv[j][3]));
+        }
       }
     }
     if constexpr (WX_ATTN_PERMLANE_MAX) mx = max_over_rows(mx);
@@ -669,7 +742,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
 #endif
 }
 
-template <typename T, int NKF, bool SPLIT, bool BT = false, int DH = 32, bool SW = false>
+template <typename T, int NKF, bool SPLIT, bool BT = false, int DH = 32, bool SW = false, int B2W = 0>
 inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
   if ((int64_t)p.H * p.W >= (1 << 24) || (int64_t)p.ld_qkv * (int64_t)sizeof(T) >= (1 << 24) || p.ld_out >= (1 << 24) ||
       (int64_t)p.H * p.W * p.ld_qkv * (int64_t)sizeof(T) >= (int64_t(1) << 32))
@@ -681,8 +754,9 @@ inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
 #else
   constexpr int VT_COLS = (sizeof(T) == 2) ? NKB * 32 : (NKF * 16 + 4);
 #endif
-  constexpr int LDS = (SPLIT ? 1 : 4) * DH * VT_COLS * (int)sizeof(T) + (BT ? 1024 * 4 + NKF * 16 * 4 : 0) + NKF * 16 * 4;
-  auto kern = window_attn_kernel<T, NKF, SPLIT, BT, DH, SW>;
+  constexpr int TB2 = B2W > 0 ? ((2 * B2W - 1) * (2 * B2W - 1) + 7) / 8 * 8 : 0;
+  constexpr int LDS = (SPLIT ? 1 : 4) * DH * VT_COLS * (int)sizeof(T) + (B2W > 0 ? TB2 * 16 + NKF * 16 * 4 : BT ? 1024 * 4 + NKF * 16 * 4 : 0) + NKF * 16 * 4;
+  auto kern = window_attn_kernel<T, NKF, SPLIT, BT, DH, SW, B2W>;
   static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -712,6 +786,7 @@ inline int attn_nkf_tokens(int n) {
 inline int attn_pack(int wsz) { const int n = wsz * wsz; return n <= 8 ? 16 / n : 1; }
 inline int attn_nkf(int wsz) { return attn_nkf_tokens(wsz * wsz * attn_pack(wsz)); }
 
+inline bool attn_no_block_order() { static const bool v = getenv("WX_ATTN_NO_B2") && getenv("WX_ATTN_NO_B2")[0] == '1'; return v; }   // A/B switch
 template <typename T>
 inline void launch_window_attn(const AttnParams& p, hipStream_t stream, int split_mode = 0) {
   // split_mode: 0 = automatic (split when the launch has fewer than ~8 tasks per SIMD), 1 = never, 2 = always (>= 4 key fragments)
@@ -731,6 +806,7 @@ inline void launch_window_attn(const AttnParams& p, hipStream_t stream, int spli
       break;
     case 7:
       if (split) launch_window_attn_n<T, 7, true>(p, stream);
+      else if (bt && p.wsz == 10 && (p.wsz_x == 0 || p.wsz_x == 10) && sizeof(T) == 2 && !attn_no_block_order()) launch_window_attn_n<T, 7, false, true, 32, false, 10>(p, stream);
       else if (bt) launch_window_attn_n<T, 7, false, true>(p, stream);
       else launch_window_attn_n<T, 7, false>(p, stream);
       break;
