@@ -4,12 +4,12 @@ tag=${1:-r01}
 mkdir -p gpurun_out
 python bench.py --steps 40 --warmup 5 2>&1 | tail -1 > gpurun_out/${tag}_bench.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_kt -o kt -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-fp32 --no-config2 --no-host-delivery > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_kt -o kt -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-fp32 --no-config2 --no-host-delivery --no-concurrent > /dev/null 2>&1
 python tools/prof_summary.py gpurun_out/${tag}_kt > gpurun_out/${tag}_kernel_stats.txt
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pf -o pf -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-fp32 --no-config2 --no-host-delivery > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pw -o pw -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-fp32 --no-config2 --no-host-delivery > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pf -o pf -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-fp32 --no-config2 --no-host-delivery --no-concurrent > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pw -o pw -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-fp32 --no-config2 --no-host-delivery --no-concurrent > /dev/null 2>&1
 python tools/pmc_traffic.py gpurun_out/${tag}_pf gpurun_out/${tag}_pw gpurun_out/${tag}_pmc_traffic.json
 python tools/pmc_traffic.py gpurun_out/${tag}_pf gpurun_out/${tag}_pw gpurun_out/${tag}_pmc_traffic.json > gpurun_out/${tag}_pmc_traffic.txt; rm -rf gpurun_out/${tag}_kt gpurun_out/${tag}_pf gpurun_out/${tag}_pw
 # same-box pair for profiles/README.md: un-profiled wall (events off) vs the rocprofv3 kernel sum above
-python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline --no-fp32 --no-config2 --no-host-delivery 2>&1 | tail -1 > gpurun_out/${tag}_bench_events_off.json
+python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline --no-fp32 --no-config2 --no-host-delivery --no-concurrent 2>&1 | tail -1 > gpurun_out/${tag}_bench_events_off.json
 cut -c1-300 gpurun_out/${tag}_bench.json; head -12 gpurun_out/${tag}_kernel_stats.txt

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 bash tools/collect_profiles.sh r04 > gpurun_out/r04_collect.log 2>&1
 bash tools/util_report.sh r04 >> gpurun_out/r04_collect.log 2>&1
-python bench.py --config C1 --steps 48 --warmup 6 --no-cpu-baseline --no-fp32 --no-config2 --no-host-delivery 2>&1 | tail -1 > gpurun_out/r04_bench_config2_1deg.json
+python bench.py --config C1 --steps 48 --warmup 6 --no-cpu-baseline --no-fp32 --no-config2 --no-host-delivery --no-concurrent 2>&1 | tail -1 > gpurun_out/r04_bench_config2_1deg.json
 python tools/stage_classes.py C3 bf16 > gpurun_out/r04_stage_classes_C3_bf16.txt 2>&1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04_fx -o kt -- python tools/fuxi_time.py bf16 5 > gpurun_out/r04_fuxi_time.log 2>&1
