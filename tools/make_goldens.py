@@ -202,7 +202,7 @@ def glue_golden():
     np.savez_compressed(os.path.join(GOLD, "rollout_T0.npz"), **out)
 
 
-def long_rollout_golden(name, n_steps, stride, with_fp64=True):
+def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base"):
     """Row R of SURVEY.md 8(a): the predict() loop (rollout_to_netcdf.py:262-316) for n_steps steps on a full-size grid, through the
     reference's own pieces -- CrossFormer forward (fp32, CPU), TracerFixer, y*std+mean, update_x -- and, beside it, the same
     trajectory from the fp64 oracle (oracle/wxformer_oracle.py::rollout).  Stored per step: strided samples of the
@@ -212,14 +212,16 @@ def long_rollout_golden(name, n_steps, stride, with_fp64=True):
     from credit.postblock.gen1 import TracerFixer
     from oracle import wxformer_oracle as O
     cfg = named_config(name)
-    m = reference_model(cfg)
-    sd = synth_state_dict(cfg)
+    m = reference_model(cfg, family=family)
+    sd = synth_state_dict(cfg, family=family)
     groups, n_pred = build_channel_layout(glue_conf(cfg))
     q_inds = list(range(3 * cfg.levels, 4 * cfg.levels))
     thres = [-0.05] * len(q_inds)
     fixer = TracerFixer({"tracer_fixer": {"tracer_inds": q_inds, "tracer_thres": thres, "denorm": False}})
     x = torch.from_numpy(synth_input(cfg))
     x64 = x.double()
+    x16 = x.clone()   # stress families: the reference's own loop under torch.autocast(bfloat16) -- what bf16 arithmetic costs per step
+    ac = []
     out = {"tracer_inds": np.array(q_inds), "tracer_thres": np.array(thres, dtype=np.float32), "n_static": np.int64(2),
            "n_dyn": np.int64(2), "stride": np.int64(stride), "n_steps": np.int64(n_steps)}
     ys, y64s, sums, rel = [], [], [], []
@@ -234,19 +236,27 @@ def long_rollout_golden(name, n_steps, stride, with_fp64=True):
                 x64 = O.update_x(x64, frc.double(), y64, n_pred, 2)
             else:   # 0.25-degree grid: torch's fp64 CPU convolution of the k = 32 CrossEmbed branch wants 157 GB of scratch
                 y64 = y.double()
+            if family != "base":
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    y16 = m(x16).float()
+                y16 = fixer({"y_pred": y16, "x": x16})["y_pred"]
+                x16 = update_x(x16, frc, y16.detach(), groups)
+                ac.append(float((y16 - y).norm() / y.norm()))
             ys.append(y[0, :, 0, ::stride, ::stride].numpy().astype(np.float32))
             y64s.append(y64[0, :, 0, ::stride, ::stride].numpy().astype(np.float32))
             s1, s2, _ = channel_stats(y)
             sums.append(np.stack([s1, s2]))
             d = (y.double() - y64)[0, :, 0]
             rel.append(float(d.norm() / y64[0, :, 0].norm()))
-            print(f"[golden] {name} rollout step {step}/{n_steps}: mean|y|={y.abs().mean():.4f}  reference-fp32 vs fp64 oracle "
-                  f"rel-L2 {rel[-1]:.3e}  ({time.time() - t0:.0f}s)", flush=True)
+            print(f"[golden] {name} ({family}) rollout step {step}/{n_steps}: mean|y|={y.abs().mean():.4f}  reference-fp32 vs fp64 oracle "
+                  f"rel-L2 {rel[-1]:.3e}" + (f"  reference under bf16 autocast {ac[-1]:.3e}" if ac else "") + f"  ({time.time() - t0:.0f}s)", flush=True)
     out["y"] = np.stack(ys)            # [n_steps, C_out, H/stride, W/stride]  reference, fp32
     out["y64"] = np.stack(y64s)        # the fp64 oracle's trajectory at the same points
     out["ch_sums"] = np.stack(sums)    # [n_steps, 2, C_out] float64
     out["ref_vs_fp64_rel_l2"] = np.array(rel) if with_fp64 else np.full(n_steps, np.nan)
-    np.savez_compressed(os.path.join(GOLD, f"rollout_{name}.npz"), **out)
+    if ac:
+        out["bf16_autocast_l2"] = np.array(ac)
+    np.savez_compressed(os.path.join(GOLD, f"rollout_{name}.npz" if family == "base" else f"rollout_{name}_{family}.npz"), **out)
 
 
 def swin_golden():
@@ -790,6 +800,8 @@ def main():
             long_rollout_golden("C1", 24, 20)
         elif item == "rollC3S":     # 8 steps on the 0.25-degree grid (small-width model)
             long_rollout_golden("C3S", 8, 40, with_fp64=False)
+        elif item == "rollC1stress":   # 8 steps of the 1-degree model on the "stress" weight family (logits +-40, pre-GELU 1e2)
+            long_rollout_golden("C1", 8, 20, family="stress")
         elif item == "rollC3":      # BASELINE config 3 itself: 6 steps of the FULL-width 124 M-parameter model on the 0.25-degree grid
             long_rollout_golden("C3", 6, 40, with_fp64=False)
         elif item == "layout":
