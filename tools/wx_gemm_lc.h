@@ -322,7 +322,9 @@ __global__ __launch_bounds__(512, 1) void gemm_lc_kernel(const StreamGemmParams 
       if (issued < total) { issue(); ++issued; }
       if (issued - step - LAG >= NST - LAG) { if (a_cnt == A_I) dma_wait_allow<(NST - LAG) * (A_I + B_I)>(); else dma_wait_allow<(NST - LAG) * (A_I - 1 + B_I)>(); }
       else dma_wait_all();
+#if !(defined(WX_LC_ABL) && (WX_LC_ABL & 8))
       ring_barrier();
+#endif
     }
     return;
   }
@@ -340,9 +342,16 @@ __global__ __launch_bounds__(512, 1) void gemm_lc_kernel(const StreamGemmParams 
     _Pragma("unroll") for (int b = 0; b < FM; ++b) x[b] = *reinterpret_cast<const uint4*>(cur + x_base + b * 16 * KB);               \
     _Pragma("unroll") for (int a = 0; a < FN; ++a) w[a] = *reinterpret_cast<const uint4*>(cur + w_base_l + (a >> 1) * 32 * KB + (a & 1) * 4 * KB); \
   }
+#ifdef WX_LC_AGPR   // accumulators in the AccVGPR half of the register file (does the LDS return path then stop colliding with C/D traffic?)
+#define WX_LC_MM(x, w)                                                                                    \
+  _Pragma("unroll") for (int a = 0; a < FN; ++a)                                                          \
+  _Pragma("unroll") for (int b = 0; b < FM; ++b)                                                          \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[a][b]) : "v"(__builtin_bit_cast(bf16x8_t, w[a])), "v"(__builtin_bit_cast(bf16x8_t, x[b])));
+#else
 #define WX_LC_MM(x, w)                                                                                    \
   _Pragma("unroll") for (int a = 0; a < FN; ++a)                                                          \
   _Pragma("unroll") for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<bf16_t>(w[a], x[b], acc[a][b]);
+#endif
 #if defined(WX_LC_ABL) && (WX_LC_ABL & 1)
 #define WX_LC_EPI                                 \
   _Pragma("unroll") for (int a = 0; a < FN; ++a)  \
@@ -350,9 +359,14 @@ __global__ __launch_bounds__(512, 1) void gemm_lc_kernel(const StreamGemmParams 
 #else
 #define WX_LC_EPI epilogue(r, std::false_type{});
 #endif
+#if defined(WX_LC_ABL) && (WX_LC_ABL & 8)
+#define WX_LC_BAR
+#else
+#define WX_LC_BAR ring_barrier();
+#endif
 #define WX_LC_TAIL                                              \
   __builtin_amdgcn_sched_barrier(0);                            \
-  ring_barrier();                                               \
+  WX_LC_BAR                                                     \
   c_stage = (c_stage + 1 == NST) ? 0 : c_stage + 1;             \
   if (++ks == nk) {                                             \
     ks = 0;                                                     \
@@ -360,6 +374,29 @@ __global__ __launch_bounds__(512, 1) void gemm_lc_kernel(const StreamGemmParams 
     ++r;                                                        \
   }
     WX_LC_RD(xa, wa, 0)
+#ifdef WX_LC_INTERLEAVE
+    // the NEXT step's 12 fragment reads trickle out between this step's MFMAs (one read, then FM MFMAs ... ) instead of leaving as one
+    // burst that every consumer wave of the CU pushes into the LDS queue at the same moment
+    static_assert(FN == 8 && FM == 4, "interleave pattern written for 128 x 256 tiles");
+#define WX_LC_STEP(xc, wc, xn, wn)                                                                                                     \
+  {                                                                                                                                    \
+    const char* nxt = smem + ((c_stage + 1 == NST) ? 0 : c_stage + 1) * STAGE;                                                         \
+    _Pragma("unroll") for (int a = 0; a < FN; ++a) {                                                                                   \
+      wn[a] = *reinterpret_cast<const uint4*>(nxt + w_base_l + (a >> 1) * 32 * KB + (a & 1) * 4 * KB);                                 \
+      if (a < FM) xn[a] = *reinterpret_cast<const uint4*>(nxt + x_base + a * 16 * KB);                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                                               \
+      _Pragma("unroll") for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<bf16_t>(wc[a], xc[b], acc[a][b]);                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                                               \
+    }                                                                                                                                  \
+  }
+    for (int step = 0; step < total; step += 2) {
+      WX_LC_STEP(xa, wa, xb, wb)
+      WX_LC_TAIL
+      WX_LC_STEP(xb, wb, xa, wa)
+      WX_LC_TAIL
+    }
+#undef WX_LC_STEP
+#else
     for (int step = 0; step < total; step += 2) {
       { const unsigned nx = (c_stage + 1 == NST) ? 0 : c_stage + 1; WX_LC_RD(xb, wb, nx) }
       __builtin_amdgcn_sched_barrier(0);
@@ -370,10 +407,12 @@ __global__ __launch_bounds__(512, 1) void gemm_lc_kernel(const StreamGemmParams 
       WX_LC_MM(xb, wb)
       WX_LC_TAIL
     }
+#endif
 #undef WX_LC_RD
 #undef WX_LC_MM
 #undef WX_LC_TAIL
 #undef WX_LC_EPI
+#undef WX_LC_BAR
     return;
   }
   unsigned c_stage = 0;
