@@ -956,6 +956,7 @@ class Engine : public EngineBase {
   size_t embed_partial_bytes = 0;
   bool use_stream = !(getenv("WX_NO_STREAM") && getenv("WX_NO_STREAM")[0] == '1');   // persistent large-tile GEMM (wx_gemm_stream.h) for the LN-folded 1x1 layers of the deep stages
   int stream_min_rows = 4096;
+  bool use_stream_lc = !(getenv("WX_NO_STREAM_LC") && getenv("WX_NO_STREAM_LC")[0] == '1');   // loader / consumer form of the persistent GEMM (one-tile-per-CU residual layers)
   bool use_wreg = !(getenv("WX_NO_WREG") && getenv("WX_NO_WREG")[0] == '1');   // weight-stationary GEMM (wx_gemm_wreg.h) for K = 512 layers on mid-sized maps
   int wreg_min_rows = getenv("WX_WREG_MIN_ROWS") ? atoi(getenv("WX_WREG_MIN_ROWS")) : 1024;
   int wreg_max_rows = getenv("WX_WREG_MAX_ROWS") ? atoi(getenv("WX_WREG_MAX_ROWS")) : 4096;
@@ -1357,8 +1358,13 @@ class Engine : public EngineBase {
         q.stat_out = statpart; q.stat_slots = w.n / 64;
         q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
         q.a_blk = blk_hidden ? 1 : 0; q.a_rows = q.M;
-        cur_family = "stream";
-        timed(cls, flops, bytes, [&] { launch_gemm_stream_n128<5, 3, 2>(q, cur_stream); });
+        // at most one 160 x 128 tile per CU and a deep K (stage 3 of the 0.25-degree model): the loader / consumer form of the kernel
+        const bool lc = use_stream_lc && stream_gemm_lc_pays(q.M, q.N, q.K, 5);
+        cur_family = lc ? "stream_lc" : "stream";
+        timed(cls, flops, bytes, [&] {
+          if (lc) launch_gemm_stream_n128_lc<5, 8>(q, cur_stream);
+          else launch_gemm_stream_n128<5, 3, 2>(q, cur_stream);
+        });
         last_stat_slots = q.stat_slots;
         return true;
       }

@@ -78,10 +78,20 @@ __device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt
 // s_waitcnt immediate (gfx9 encoding): vmcnt = n, expcnt / lgkmcnt untouched
 constexpr int wx_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
 
+#ifndef WX_STAT_BATCH
+#define WX_STAT_BATCH 8   // row-statistics partials fetched per L2 round trip (the N = 512 producers leave 8 per row: one trip, 41.9 -> 41.4 us on to_qkv)
+#endif
 // FN = weight fragments per wave: 8 -> 256-column tiles (two workgroups per CU), 4 -> 128-column tiles for the N = 512 layers
 // (to_out, FeedForward layer 2: twice the tiles, so that every CU still holds two workgroups; OCC of them with a 2-stage ring)
-template <int FM, int NST, bool LN, bool ACT, bool RES, bool STAT, int FN = 8, int OCC = 2>
-__global__ __launch_bounds__(256, OCC) void gemm_stream_kernel(const StreamGemmParams p) {
+// LC (round 4, "loaders / consumers"): ONE 8-wave workgroup per CU -- waves 0-3 read fragments, run the MFMAs and the epilogue exactly
+// as below, waves 4-7 do nothing but stage the ring (one of each kind per SIMD; the ring may then be NST = 8 deep: the workgroup owns
+// the CU's LDS) and the two kinds meet at the per-K-step barrier.  For launches that are down to one tile per CU anyway (stage 3 of
+// the 0.25-degree model: 256 tiles of 160 x 128 for 256 CUs), where the 4-wave form leaves one wave per SIMD alternating between DMA
+// issue, waiting for a 3-stage ring and MFMAs: FeedForward layer 2 (K = 4096) 66.5 -> 47.5 us, to_out (K = 1024) 22.5 -> 18.4
+// (tools/gemm_lc_probe, profiles/r04_gemm_lc_probe.txt; bitwise the same output).  With two or more tiles per CU the two free-running
+// 4-wave workgroups win (their epilogues hide under each other's K loops; the LC form has nothing to cover its epilogue with).
+template <int FM, int NST, bool LN, bool ACT, bool RES, bool STAT, int FN = 8, int OCC = 2, bool LC = false>
+__global__ __launch_bounds__(LC ? 512 : 256, LC ? 1 : OCC) void gemm_stream_kernel(const StreamGemmParams p) {
   constexpr int BM = 32 * FM, BN = 32 * FN, KB = 64;   // KB: bytes of K per stage row (32 bf16 = one MFMA k step)
   constexpr int A_TOT = BM / 16;                   // DMA instructions per stage for the activation rows (16 rows each)
   constexpr int A_I = (A_TOT + 3) / 4;             // ... per wave (waves with index >= A_TOT % 4 issue one fewer when A_TOT % 4 != 0)
@@ -91,7 +101,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_stream_kernel(const StreamGemmP
   float* s_par = reinterpret_cast<float*>(smem + NST * STAGE);   // bias[256] | colsum[256]
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = LC && wave_all >= 4;
+  const int wave = wave_all & 3;   // index among the consumers (or among the loaders): DMA coordinates and wave tile
   const int wm = wave & 1, wn = wave >> 1;
   const int li = lane & 15, g = lane >> 4;
 
@@ -179,12 +191,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_stream_kernel(const StreamGemmP
     if (p.stat_tiles == 0) return p.rowstat[m];
     float s = 0.f, q = 0.f;
     const float2* src = p.rowstat + (int64_t)m * p.stat_tiles;
-    for (int t = 0; t < p.stat_tiles; t += 4) {
-      float2 v[4];
+    for (int t = 0; t < p.stat_tiles; t += WX_STAT_BATCH) {
+      float2 v[WX_STAT_BATCH];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = src[t + j < p.stat_tiles ? t + j : p.stat_tiles - 1];
+      for (int j = 0; j < WX_STAT_BATCH; ++j) v[j] = src[t + j < p.stat_tiles ? t + j : p.stat_tiles - 1];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < WX_STAT_BATCH; ++j)
         if (t + j < p.stat_tiles) { s += v[j].x; q += v[j].y; }
     }
     const float mean = s * p.stat_inv_c;
@@ -319,6 +331,51 @@ __global__ __launch_bounds__(256, OCC) void gemm_stream_kernel(const StreamGemmP
   };
 
   // ---- main loop over the flattened (tile, k step) stream ----------------------------------------------
+  if constexpr (LC) {
+    static_assert(NST >= 3 && (NST - 2) * (A_I + B_I) <= 63, "ring depth against the vmcnt range");
+    if (loader) {
+      // groups 0 .. step + 1 have landed at the barrier that ends step `step`; NST - 2 younger groups stay in flight
+      int issued = 0;
+#pragma unroll
+      for (int j = 0; j < NST - 1; ++j)
+        if (issued < total) { issue(); ++issued; }
+      if (issued == NST - 1) { if (a_cnt == A_I) dma_wait_allow<(NST - 2) * (A_I + B_I)>(); else dma_wait_allow<(NST - 2) * (A_I - 1 + B_I)>(); }
+      else dma_wait_all();
+      ring_barrier();
+      for (int step = 0; step < total; ++step) {
+        if (issued < total) { issue(); ++issued; }
+        if (issued - step - 2 >= NST - 2) { if (a_cnt == A_I) dma_wait_allow<(NST - 2) * (A_I + B_I)>(); else dma_wait_allow<(NST - 2) * (A_I - 1 + B_I)>(); }
+        else dma_wait_all();
+        ring_barrier();
+      }
+      return;
+    }
+    ring_barrier();
+    unsigned c_stage = 0;
+    int ks = 0, r = 0;
+    for (int step = 0; step < total; ++step) {
+      const char* cur = smem + c_stage * STAGE;
+      {
+        uint4 xf[FM], wf[FN];
+#pragma unroll
+        for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const uint4*>(cur + x_base + b * 16 * KB);
+#pragma unroll
+        for (int a = 0; a < FN; ++a) wf[a] = *reinterpret_cast<const uint4*>(cur + w_base_l + (a >> 1) * 32 * KB + (a & 1) * 4 * KB);
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<bf16_t>(wf[a], xf[b], acc[a][b]);
+      }
+      ring_barrier();
+      c_stage = (c_stage + 1 == NST) ? 0 : c_stage + 1;
+      if (++ks == nk) {
+        ks = 0;
+        epilogue(r, std::false_type{});
+        ++r;
+      }
+    }
+    return;
+  }
 #ifdef WX_STREAM_TRACE
   const unsigned long long tr_t0 = stream_tick();
 #endif
@@ -416,18 +473,19 @@ inline void stream_gemm_geometry(StreamGemmParams& p, int fm, int max_per_xcd = 
 
 inline int& stream_gemm_max_per_xcd() { static int v = 64; return v; }   // probe knob: 32 = one workgroup per CU
 
-template <int FM, int NST, bool LN, bool ACT, bool RES, bool STAT, int FN = 8, int OCC = 2>
+template <int FM, int NST, bool LN, bool ACT, bool RES, bool STAT, int FN = 8, int OCC = 2, bool LC = false>
 inline void launch_gemm_stream_v(StreamGemmParams p, hipStream_t stream) {
   constexpr int LDS = NST * (32 * FM + 32 * FN) * 64 + 2 * 32 * FN * 4 + 2 * 32 * FM * 8;   // ring | bias, colsum | two slots of row statistics
-  auto kern = gemm_stream_kernel<FM, NST, LN, ACT, RES, STAT, FN, OCC>;
+  static_assert(LDS <= 160 * 1024, "ring deeper than the CU's LDS");
+  auto kern = gemm_stream_kernel<FM, NST, LN, ACT, RES, STAT, FN, OCC, LC>;
   static uint64_t attr_done_mask = 0;
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_mark_device(attr_done_mask);
   }
-  stream_gemm_geometry(p, FM, stream_gemm_max_per_xcd() * OCC / 2, 32 * FN);
+  stream_gemm_geometry(p, FM, LC ? 32 : stream_gemm_max_per_xcd() * OCC / 2, 32 * FN);   // LC: one workgroup per CU
   const unsigned grid = 8u * p.nt * p.s_per_xcd;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(LC ? 512 : 256), LDS, stream, p);
   WX_HIP(hipGetLastError());
 }
 
@@ -449,6 +507,14 @@ inline void launch_gemm_stream(const StreamGemmParams& p, int variant, hipStream
 template <int FM, int NST, int OCC>
 inline void launch_gemm_stream_n128(const StreamGemmParams& p, hipStream_t stream) {
   launch_gemm_stream_v<FM, NST, false, false, true, true, 4, OCC>(p, stream);
+}
+// ... in the loader / consumer form (see the kernel): for launches of at most one such tile per CU
+template <int FM, int NST>
+inline void launch_gemm_stream_n128_lc(const StreamGemmParams& p, hipStream_t stream) {
+  launch_gemm_stream_v<FM, NST, false, false, true, true, 4, 1, true>(p, stream);
+}
+inline bool stream_gemm_lc_pays(int64_t M, int N, int K, int fm, int n_cu = 256) {
+  return cdiv(M, (int64_t)32 * fm) * (N / 128) <= n_cu && K >= 1024;
 }
 
 }  // namespace wx

@@ -199,6 +199,39 @@ def test_weight_stationary_gemm_forced_on_small_maps(name):
     assert l2o <= 2e-2, f"{name}: forward vs oracle rel-L2 {l2o:.3e}"
 
 
+@pytest.mark.parametrize("name", ["T5", "C1"])
+def test_loader_consumer_gemm_forced_on_small_maps(name):
+    """The loader / consumer form of `gemm_stream_kernel` (wx_gemm_stream.h, LC: four MFMA waves + four staging waves, 8-stage ring)
+    takes the residual layers that are down to one 160 x 128 tile per CU with K >= 1024 -- stage 3 of the 0.25-degree model by itself.
+    WX_STREAM_MIN_ROWS=0 brings the persistent kernel onto T5's stage 2 (C = 512 on 200 rows: a ragged last tile) and C1's stage 3
+    (360 rows), where FeedForward layer 2 (K = 2048) then runs in that form.  Same arithmetic in the same order as the 4-wave form:
+    the forward must be BITWISE equal to the engine with WX_NO_STREAM_LC=1, run-to-run stable, inside the bf16 gate against the
+    oracle, and the profile must say which form ran."""
+    from oracle import wxformer_oracle as O
+    cfg = named_config(name)
+    xin = synth_input(cfg)
+    x = torch.from_numpy(xin).cuda()
+    common = {"WX_STREAM_MIN_ROWS": "0", "WX_SKINNY_MAX": "0", "WX_NO_WREG": "1"}
+    lc = _engine(name, "bf16", dict(common))
+    plain = _engine(name, "bf16", dict(common, WX_NO_STREAM_LC="1"))
+    y_lc, y_plain = lc.forward(x).clone(), plain.forward(x).clone()
+    assert torch.equal(y_lc, y_plain), "loader / consumer GEMM: output differs from the 4-wave form"
+    assert torch.equal(y_lc, lc.forward(x)), "loader / consumer GEMM: two runs differ (race)"
+    for eng, want in ((lc, True), (plain, False)):
+        eng.profile(3)
+        eng.profile_reset()
+        eng.forward(x)
+        torch.cuda.synchronize()
+        tagged = [r["name"] for r in eng.profile_read() if r["name"].endswith("@stream_lc")]
+        eng.profile(0)
+        assert bool(tagged) == want, tagged
+        if want:
+            assert {t.split(".")[0] for t in tagged} >= {"gemm_ff2"}, tagged   # (+ to_out where a stage is 1024 wide: K = 1024)
+    yr = O.forward(cfg, synth_state_dict(cfg), xin).numpy().astype(np.float64)
+    l2o = np.linalg.norm(y_lc.cpu().numpy().astype(np.float64) - yr) / np.linalg.norm(yr)
+    assert l2o <= 2e-2, f"{name}: forward vs oracle rel-L2 {l2o:.3e}"
+
+
 @pytest.mark.parametrize("name", ["T1", "T5", "C1", "RT"])
 def test_attention_block_kernel_opt_in(name):
     """`attn_block_kernel` (wx_attn_block.h: LayerNorm + to_qkv + window attention + to_out + residual in one launch, q|k|v never in

@@ -45,9 +45,14 @@ int main(int argc, char** argv) {
       {20000, 2048, 512, 2, 16, "s2 ff1  (LN+GELU)"},
       {20000, 512, 512, 3, 0, "s2 out  (res+stat)"},
   };
+  shapes.push_back({20000, 1536, 512, 1, 8, "s2 qkv  T=8"});
+  shapes.push_back({20000, 2048, 512, 2, 8, "s2 ff1  T=8"});
+  shapes.push_back({20000, 1536, 512, 1, 4, "s2 qkv  T=4"});
+  shapes.push_back({20000, 1536, 512, 1, 1, "s2 qkv  T=1"});
   shapes.push_back({20000, 512, 2048, 3, 0, "s2 ff2  (res+stat)"});
   shapes.push_back({5000, 1024, 4096, 3, 0, "s3 ff2  (res+stat)"});
   shapes.push_back({5000, 3072, 1024, 1, 16, "s3 qkv  (LN)"});
+  shapes.push_back({5000, 1024, 1024, 3, 0, "s3 out  (res+stat)"});
   if (set >= 1) {
     shapes.push_back({19999, 1536, 512, 1, 4, "tail M qkv (T = 4)"});
     shapes.push_back({19987, 512, 512, 3, 0, "tail M out"});
