@@ -154,7 +154,9 @@ __global__ __launch_bounds__(512, 1) void gemm_lc_kernel(const StreamGemmParams 
     const int m0 = m_blk + wm * 16 * FM + li;
     // next tile's row statistics first: their loads are OLDER than this epilogue's stores (vmcnt retires in order), and the slot
     // they go to was last read one whole tile ago
+#ifndef WX_LC_LSTAT
     if (r + 1 < n_my) stage_stats(r + 1);
+#endif
     float mean[FM], rstd[FM];
     if constexpr (LN) {
 #pragma unroll
@@ -318,8 +320,24 @@ __global__ __launch_bounds__(512, 1) void gemm_lc_kernel(const StreamGemmParams 
     if (issued == NST - 1) { if (a_cnt == A_I) dma_wait_allow<(NST - LAG) * (A_I + B_I)>(); else dma_wait_allow<(NST - LAG) * (A_I - 1 + B_I)>(); }
     else dma_wait_all();
     ring_barrier();
+    int l_ks = 0, l_r = 0;
     for (int step = 0; step < total; ++step) {
       if (issued < total) { issue(); ++issued; }
+#ifdef WX_LC_LSTAT
+      // the NEXT tile's row statistics are the loaders' job (their issue slots are mostly idle): taken off the consumers' epilogue,
+      // where the partial loads were dependent L2 round trips in front of the first store
+      if constexpr (LN) {
+        if (l_ks == 1 && l_r + 1 < n_my) {
+          const int lt = tid - 256;
+          if (lt < BM) {
+            int m = (first + (l_r + 1) * stride) * BM + lt;
+            m = m < p.M ? m : p.M - 1;
+            s_stat[((l_r + 1) & 1) * BM + lt] = row_stat(m);
+          }
+        }
+        if (++l_ks == nk) { l_ks = 0; ++l_r; }
+      }
+#endif
       if (issued - step - LAG >= NST - LAG) { if (a_cnt == A_I) dma_wait_allow<(NST - LAG) * (A_I + B_I)>(); else dma_wait_allow<(NST - LAG) * (A_I - 1 + B_I)>(); }
       else dma_wait_all();
 #if !(defined(WX_LC_ABL) && (WX_LC_ABL & 8))
