@@ -97,6 +97,7 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 1 : OCC) void gemm_stream_kern
   constexpr int A_I = (A_TOT + 3) / 4;             // ... per wave (waves with index >= A_TOT % 4 issue one fewer when A_TOT % 4 != 0)
   constexpr int B_I = BN / 64;
   constexpr int STAGE = (BM + BN) * KB;
+  constexpr bool ZERO_C = LN && !ACT && !RES && !LC;   // see the K loop
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_par = reinterpret_cast<float*>(smem + NST * STAGE);   // bias[256] | colsum[256]
 
@@ -320,10 +321,12 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 1 : OCC) void gemm_stream_kern
         *sd = make_float2(s1[b], s2[b]);
       }
     }
+    if constexpr (!ZERO_C) {
 #pragma unroll
-    for (int a = 0; a < FN; ++a)
+      for (int a = 0; a < FN; ++a)
 #pragma unroll
-      for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     // tell hipcc's vmcnt scoreboard that every LOAD of this epilogue has returned (they have: their values were consumed
     // above) while leaving the stores just issued in flight: vmcnt(N_STORES) is a no-op at run time, but without it the
     // scoreboard carries "load pending" over the back-edge and plants a vmcnt(0) inside the K loop
@@ -413,10 +416,20 @@ __global__ __launch_bounds__(LC ? 512 : 256, LC ? 1 : OCC) void gemm_stream_kern
 #pragma unroll
       for (int a = 0; a < FN; ++a) acc[a][0][0] += __builtin_bit_cast(float, wf[a].x ^ xf[a % FM].y);
 #else
+      // first K step of a tile: C = 0 as the MFMA's inline constant instead of FM * FN * 4 v_mov per tile in the epilogue.  Only in the
+      // plain LayerNorm-fold variant (to_qkv: 41.3 -> 40.3 us at stage 2, 38.5 -> 37.5 at stage 3); with the GELU epilogue the second
+      // copy of the MFMA block costs registers (56 -> 67 us), the residual variants do not move (tools/gemm_lc_probe, round 4)
+      if (ZERO_C && ks == 0) {
 #pragma unroll
-      for (int a = 0; a < FN; ++a)
+        for (int a = 0; a < FN; ++a)
 #pragma unroll
-        for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<bf16_t>(wf[a], xf[b], acc[a][b]);
+          for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<bf16_t>(wf[a], xf[b], f32x4_t{0.f, 0.f, 0.f, 0.f});
+      } else {
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<bf16_t>(wf[a], xf[b], acc[a][b]);
+      }
 #endif
     }
     // stage step+1 must have landed (this wave's pieces; the barrier extends it to everyone's); with a 3-stage ring the

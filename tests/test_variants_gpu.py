@@ -127,7 +127,7 @@ def test_persistent_gemm_forced_on_small_maps(name):
         eng.profile_reset()
         eng.forward(x)
         torch.cuda.synchronize()
-        tagged = [r["name"] for r in eng.profile_read() if r["name"].endswith("@stream")]
+        tagged = [r["name"] for r in eng.profile_read() if r["name"].endswith(("@stream", "@stream_lc"))]   # _lc: its loader / consumer form
         eng.profile(0)
         assert bool(tagged) == want, tagged
         if want:
