@@ -12,5 +12,6 @@ rm -rf gpurun_out/r04_fx
 python tools/fuxi_time.py bf16 10 2>&1 | tail -1 > gpurun_out/r04_fuxi_forward.txt
 BAND_CLASSES=1 python tools/band_time.py C3 bf16 8 > gpurun_out/r04_latband_virtual_ranks_C3_bf16.txt 2>&1
 tools/_build/gemm_wreg_probe 1 > gpurun_out/r04_gemm_wreg_probe_raw.txt 2>&1
+WX_LC_CFG=2 tools/_build/gemm_lc_probe 0 > gpurun_out/r04_gemm_lc_probe_raw.txt 2>&1
 python tools/stress_report.py > gpurun_out/r04_stress_report.txt 2>&1
 cut -c1-400 gpurun_out/r04_bench.json; head -14 gpurun_out/r04_kernel_stats.txt; cat gpurun_out/r04_fuxi_forward.txt; cut -c1-200 gpurun_out/r04_bench_config2_1deg.json

@@ -30,4 +30,7 @@ tot = sum(r["ms"] for r in rows) / K
 print(f"{name} {prec}: {tot:.3f} ms kernel time / step")
 for r in rows:
     if flt in r["name"]:
-        print(f"  {r['name']:<26s} {r['ms'] / K:8.3f} ms  {r['launches'] // K:4d} launches  {1e3 * r['ms'] / r['launches']:8.1f} us each")
+        tf = r["flops"] / (r["ms"] * 1e-3) * 1e-12 if r["ms"] > 0 else 0.0     # algorithmic FLOP / measured time
+        tb = r["bytes"] / (r["ms"] * 1e-3) * 1e-12 if r["ms"] > 0 else 0.0     # algorithmic bytes / measured time
+        print(f"  {r['name']:<26s} {r['ms'] / K:8.3f} ms  {r['launches'] // K:4d} launches  {1e3 * r['ms'] / r['launches']:8.1f} us each"
+              f"  {tf:7.0f} TFLOP/s  {tb:5.2f} TB/s")
