@@ -57,7 +57,7 @@ typedef struct wx_config {
   int32_t image_height, image_width;
   int32_t frames, output_frames;
   int32_t channels, surface_channels, input_only_channels, output_only_channels, levels;
-  int32_t dim[4], depth[4], dim_head;
+  int32_t dim[4], depth[4], dim_head;   /* dim_head: 32 (reference default, tuned kernels) or 64 / 96 / 128 (general attention kernel); must divide every dim[s] */
   int32_t global_window_size[4], local_window_size[4];
   int32_t n_embed_kernels[4];       /* branches per stage (<= 4) */
   int32_t embed_kernels[4][4];      /* cross_embed_kernel_sizes */

@@ -179,7 +179,13 @@ class Engine : public EngineBase {
   void derive() {
     if (cfg.abi_version != WX_ABI_VERSION) throw ConfigError("wx_config.abi_version mismatch");
     if (cfg.frames < 1 || cfg.output_frames < 1) throw ConfigError("frames/output_frames must be >= 1");
-    if (cfg.dim_head != 32) throw ConfigError("engine supports dim_head == 32 only (reference default)");
+    // dim_head (crossformer.py:372-401, a constructor kwarg; every YAML of the reference leaves the default 32): 32 runs the tuned kernels;
+    // 64 / 96 / 128 run the general-head-dimension attention kernel of the Swin mode (launch_window_attn_any) between the plain GEMMs --
+    // the attention block kernel and the fused FeedForward's to_out / to_qkv variants are built around 32-wide heads and stay off
+    if (cfg.dim_head != 32 && cfg.dim_head != 64 && cfg.dim_head != 96 && cfg.dim_head != 128)
+      throw ConfigError("dim_head must be 32, 64, 96 or 128");
+    for (int s = 0; s < 4; ++s)
+      if (cfg.dim[s] % cfg.dim_head) throw ConfigError("every stage width must be a multiple of dim_head");
     if (cfg.arch != WX_ARCH_CROSSFORMER && cfg.arch != WX_ARCH_WXFORMER && cfg.arch != WX_ARCH_CROSSFORMER_UPCONV)
       throw ConfigError("unknown wx_config.arch");
     C_in = (cfg.channels * cfg.levels + cfg.surface_channels + cfg.input_only_channels) * cfg.frames;
@@ -677,7 +683,7 @@ class Engine : public EngineBase {
     } else {
       // bf16 engine: softmax scale (and the log2 e of its exp2) lives in the q rows; the fp32 engine multiplies the scores instead
       a.qkv = make_conv(p + ".to_qkv", 0, 3 * c, c, c, 1, 1, false, g.data.data(), b.data.data(), nullptr,
-                        sizeof(T) == 2 ? c : 0, 1.4426950408889634 / std::sqrt(32.0));
+                        sizeof(T) == 2 ? c : 0, 1.4426950408889634 / std::sqrt((double)cfg.dim_head));
       pack_kblocked(a.qkv);
       a.bias_tab = make_bias_table(p + ".dpb", wsz, c / 4, &a.bias_tb);
     }
@@ -1451,7 +1457,7 @@ class Engine : public EngineBase {
   // exist in memory on this path: a debug run captures the sub-block's output only)
   bool small_map_tokens(int s) const { return (int64_t)sh[s] * sw[s] <= 32768; }
   bool attn_block_ok(const AttnL& a, int s) const {
-    if (sizeof(T) != 2 || !attn_block || band_on || attn_kind_override >= 0 || a.bias_tb < 0) return false;
+    if (sizeof(T) != 2 || !attn_block || band_on || attn_kind_override >= 0 || a.bias_tb < 0 || cfg.dim_head != 32) return false;
     if (attn_block == 2) {
       const bool big_s0 = cfg.dim[s] == 128 && attn_nkf(a.wsz) == 7 && (int64_t)(sh[s] / a.wsz) * (sw[s] / a.wsz) >= 2048;
       const bool small_map = small_map_tokens(s);   // launch-bound maps (1-degree model): one launch instead of three
@@ -1492,11 +1498,14 @@ class Engine : public EngineBase {
       AttnParams p;
       p.trace = nullptr;
       p.qkv = scratch; p.ld_qkv = 3 * c; p.out = attn_o; p.ld_out = c; p.bias = f_dev + a.bias_tab; p.tb = a.bias_tb >= 0 ? f_dev + a.bias_tb : nullptr;
-      p.H = h; p.W = w; p.C = c; p.heads = c / 32; p.wsz = a.wsz; p.kind = attn_kind_override >= 0 ? attn_kind_override : a.kind;
-      p.scale = (float)(1.0 / std::sqrt(32.0));   // fp32 engine only: the bf16 engine's q already carries scale * log2(e)
+      p.H = h; p.W = w; p.C = c; p.heads = c / cfg.dim_head; p.wsz = a.wsz; p.kind = attn_kind_override >= 0 ? attn_kind_override : a.kind;
+      p.scale = (float)(1.0 / std::sqrt((double)cfg.dim_head));   // fp32 engine only: the bf16 engine's q already carries scale * log2(e)
       p.pack = attn_pack(a.wsz);
       const double n = (double)a.wsz * a.wsz;
-      timed("window_attn", 4.0 * m * n * c, 4.0 * m * c * sizeof(T), [&] { launch_window_attn<T>(p, cur_stream, attn_split); });
+      timed("window_attn", 4.0 * m * n * c, 4.0 * m * c * sizeof(T), [&] {
+        if (cfg.dim_head == 32) launch_window_attn<T>(p, cur_stream, attn_split);
+        else launch_window_attn_any<T>(p, cfg.dim_head, cur_stream);   // [NP][NP] bias table shared by the heads (bias_head_stride 0)
+      });
       capture(dbg_name + ".qkv", scratch, h, w, 3 * c, 3 * c, w);
     }
     capture(dbg_name + ".attn", attn_o, h, w, c, c, w);
@@ -1515,7 +1524,7 @@ class Engine : public EngineBase {
     if (cfg.dim[cur_stage] == 128 || cfg.dim[cur_stage] == 64) return cdiv(m, 128) >= std::min(ff_min_wgs, 40);
     return cdiv(m, 64) >= ff_min_wgs;
   }
-  bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on && ff_big_enough(); }
+  bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on && ff_big_enough() && cfg.dim_head == 32; }
   bool ff_takes_out(const FFL& f, const AttnL& a) const { return ff_takes_out(f) && !attn_block_ok(a, cur_stage); }
   bool ff_makes_qkv(const FFL& f) const { return ff_takes_out(f) && fuse_qkv && f.pack_pp >= 0 && !band_on && !(f.next && attn_block_ok(*f.next, cur_stage)); }
   bool ff_split_ok(const FFL& f, int s, const AttnL* pre) const {
@@ -1952,6 +1961,7 @@ class Engine : public EngineBase {
     if (e.cfg.arch != WX_ARCH_CROSSFORMER && e.cfg.arch != WX_ARCH_WXFORMER)
       throw ConfigError("lat-band mode: the upsample_v_conv decoder variant is not wired (crossformer and wxformer are)");
     if (e.cfg.frames != 1 || e.cfg.output_frames != 1) throw ConfigError("lat-band mode needs frames == output_frames == 1");
+    if (e.cfg.dim_head != 32) throw ConfigError("lat-band mode needs dim_head == 32");
   }
 
   void band_enable(int rank, int n) override {

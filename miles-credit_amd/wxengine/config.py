@@ -105,6 +105,8 @@ class WXConfig:
             for kind, wsz in (("local", self.local_window_size[s]), ("global", self.global_window_size[s])):
                 if h % wsz or w % wsz:
                     raise ValueError(f"stage {s} map {h}x{w} not divisible by {kind} window {wsz}")
+        if self.dim_head not in (32, 64, 96, 128):
+            raise ValueError("dim_head must be 32 (the reference default: the tuned kernels), 64, 96 or 128 (general attention kernel)")
         for d in self.dim:
             if d % self.dim_head:
                 raise ValueError("dim must be a multiple of dim_head")
@@ -300,6 +302,15 @@ def named_config(name: str) -> WXConfig:
         mc = dict(base, image_height=37, image_width=72, levels=3, output_only_channels=3,
                   dim=[32, 64, 128, 256], depth=[1, 1, 2, 1], global_window_size=[4, 2, 2, 1], local_window_size=3,
                   padding_conf=dict(activate=True, mode="mirror", pad_lat=[5, 7], pad_lon=[12, 12]))
+    elif name == "T0H":  # T0's geometry with dim_head = 64 (crossformer.py:372-401: a constructor kwarg; heads 1 / 2 / 4 / 8): 9- and
+        # 16-token windows and the packed 2 x 2 ones on the general-head-dimension attention kernel
+        mc = dict(base, image_height=37, image_width=72, levels=3, output_only_channels=3, dim_head=64,
+                  dim=[64, 128, 256, 512], depth=[1, 1, 2, 1], global_window_size=[4, 2, 2, 1], local_window_size=3,
+                  padding_conf=dict(activate=True, mode="earth", pad_lat=[6, 6], pad_lon=[12, 12]))
+    elif name == "T1H":  # T1's geometry (25-token windows) with dim_head = 128 (heads 1 / 2 / 4 / 8; the widths of the 0.25-degree model)
+        mc = dict(base, image_height=61, image_width=120, levels=5, output_only_channels=2, dim_head=128,
+                  dim=[128, 256, 512, 1024], depth=[1, 1, 1, 1], global_window_size=[5, 5, 2, 1], local_window_size=5,
+                  padding_conf=dict(activate=True, mode="earth", pad_lat=[11, 9], pad_lon=[24, 16]))
     elif name == "T0":  # tiny: odd padded height (49 -> 24), asymmetric-free pads, all branches exercised
         mc = dict(base, image_height=37, image_width=72, levels=3, output_only_channels=3,
                   dim=[32, 64, 128, 256], depth=[1, 1, 2, 1], global_window_size=[4, 2, 2, 1], local_window_size=3,

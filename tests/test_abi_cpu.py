@@ -115,6 +115,13 @@ def test_config_validation_errors():
         WXConfig.from_model_conf(dict(base, padding_conf=dict(activate=True, mode="mirror", pad_lat=[37, 6], pad_lon=[12, 12])))
     with pytest.raises(ValueError):
         WXConfig.from_model_conf(dict(base, patch_height=2, patch_width=2))
+    # dim_head (crossformer.py:372-401): 32 / 64 / 96 / 128, dividing every stage width
+    wide = WXConfig.from_model_conf(dict(base, dim=[64, 128, 256, 512], dim_head=64))
+    assert wide.heads == (1, 2, 4, 8) and E.make_c_config(wide, "bf16").dim_head == 64
+    with pytest.raises(ValueError):
+        WXConfig.from_model_conf(dict(base, dim_head=64))               # 32 is not a multiple of 64
+    with pytest.raises(ValueError):
+        WXConfig.from_model_conf(dict(base, dim=[48, 96, 192, 384], dim_head=48))
 
 
 def test_named_configs_match_survey_parameter_counts():

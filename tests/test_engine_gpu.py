@@ -47,7 +47,7 @@ def check(y, ref, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", ["T0", "T1", "T0W", "T0U", "T0M", "T0F"])
+@pytest.mark.parametrize("name", ["T0", "T1", "T0W", "T0U", "T0M", "T0F", "T0H", "T1H"])
 def test_forward_and_every_block_vs_oracle(name, prec):
     cfg = named_config(name)
     sd = synth_state_dict(cfg)
@@ -82,6 +82,19 @@ def test_c1_vs_oracle_and_reference_golden(name, prec):
     y = get_engine(name, prec).forward(torch.from_numpy(x).cuda()).cpu()
     y_ref = O.forward(cfg, synth_state_dict(cfg), x)
     check(y.numpy(), y_ref.numpy(), prec)
+    g = np.load(os.path.join(GOLD, f"model_{name}.npz"))
+    s = int(g["stride"])
+    check(y[0, :, 0, ::s, ::s].numpy(), g["y"], prec)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["T0H", "T1H"])
+def test_wide_heads_vs_reference_golden(name, prec):
+    """dim_head = 64 / 128 (crossformer.py:372-401; the reference's YAMLs leave the default 32): the general-head-dimension attention
+    kernel between the plain GEMMs, against the reference's own fp32 forward (tools/make_goldens.py --only T0H / T1H), same gates
+    as the 32-wide heads.  The per-block oracle captures of these configs are in test_forward_and_every_block_vs_oracle."""
+    cfg = named_config(name)
+    y = get_engine(name, prec).forward(torch.from_numpy(synth_input(cfg)).cuda()).cpu()
     g = np.load(os.path.join(GOLD, f"model_{name}.npz"))
     s = int(g["stride"])
     check(y[0, :, 0, ::s, ::s].numpy(), g["y"], prec)
