@@ -798,7 +798,10 @@ inline void launch_window_attn(const AttnParams& p, hipStream_t stream, int spli
   (void)tasks;
   switch (nkf) {
     case 1: launch_window_attn_n<T, 1, false>(p, stream); break;
-    case 2: launch_window_attn_n<T, 2, false>(p, stream); break;
+    case 2:
+      if (bt) launch_window_attn_n<T, 2, false, true>(p, stream);   // 17 .. 32 tokens (5 x 5 long windows of the 0.25-degree stage 1): bias from the LDS generating table
+      else launch_window_attn_n<T, 2, false>(p, stream);
+      break;
     case 4:
       if (split) launch_window_attn_n<T, 4, true>(p, stream);
       else if (bt) launch_window_attn_n<T, 4, false, true>(p, stream);

@@ -1,3 +1,4 @@
+"""Dev tool: every launch of ONE step of a rocprofv3 kernel trace, in order (duration, grid, workgroup, kernel).   python tools/trace_list.py <trace dir>"""
 import csv,sys,glob
 f=glob.glob(sys.argv[1]+'/**/*kernel_trace.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
