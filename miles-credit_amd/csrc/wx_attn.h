@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
   // string of dependent latencies (bias gather: two LDS round trips; score MFMA; 14 dependent v_max3; two cross-lane shuffles; MFMA;
   // v_exp; four dependent PV MFMAs) that only other waves could fill; a second, independent block in the SAME wave fills it without
   // costing LDS.  The price is registers: 28 more live scores -> three waves per SIMD instead of four (attn_min_waves).
-  constexpr bool PAIR = WX_ATTN_PAIR && sizeof(T) == 2 && BT && !SW && !SPLIT && DH == 32 && NKF >= 7 && NKF <= 8 && VTR && WX_ATTN_MFMA_SOFTMAX;
+  constexpr bool PAIR = WX_ATTN_PAIR && B2W == 0 && sizeof(T) == 2 && BT && !SW && !SPLIT && DH == 32 && NKF >= 7 && NKF <= 8 && VTR && WX_ATTN_MFMA_SOFTMAX;
   if constexpr (PAIR) {
     struct QS {
       float sv[NKF][4];

@@ -186,6 +186,10 @@ class Engine : public EngineBase {
       throw ConfigError("dim_head must be 32, 64, 96 or 128");
     for (int s = 0; s < 4; ++s)
       if (cfg.dim[s] % cfg.dim_head) throw ConfigError("every stage width must be a multiple of dim_head");
+    if (cfg.dim_head != 32)   // launch_window_attn_dh: windows of at most 128 tokens
+      for (int s = 0; s < 4; ++s)
+        if (cfg.local_window_size[s] * cfg.local_window_size[s] > 128 || cfg.global_window_size[s] * cfg.global_window_size[s] > 128)
+          throw ConfigError("dim_head != 32 needs windows of at most 128 tokens (the general attention kernel's limit)");
     if (cfg.arch != WX_ARCH_CROSSFORMER && cfg.arch != WX_ARCH_WXFORMER && cfg.arch != WX_ARCH_CROSSFORMER_UPCONV)
       throw ConfigError("unknown wx_config.arch");
     C_in = (cfg.channels * cfg.levels + cfg.surface_channels + cfg.input_only_channels) * cfg.frames;
@@ -945,10 +949,10 @@ class Engine : public EngineBase {
   float* splitk_buf = nullptr;   // fp32 partial sums of every split-K form (plain, skinny, hidden-split FeedForward): ONE buffer, sized in
   size_t splitk_bytes = 0;       // alloc_activations from the split rules' own bounds -- the forward never allocates (hipMalloc inside a
                                  // forward would also be illegal under the opt-in graph capture)
-  size_t splitk_bound() const {
+  size_t splitk_bound(bool band = false) const {   // band: the wider skinny rule of lat-band ranks (reserved by band_enable only)
     const size_t tile = (size_t)128 * 128 * sizeof(float);
     size_t b = (size_t)512 * tile;                                                               // plain rule: S * tiles <= 512
-    b = std::max(b, (size_t)std::max(std::max(skinny_tiles, skinny_tiles_band), 1) * (size_t)std::max(skinny_max, 1) * tile); // skinny rule: tiles <= skinny_tiles, S <= skinny_max
+    b = std::max(b, (size_t)std::max(band ? std::max(skinny_tiles, skinny_tiles_band) : skinny_tiles, 1) * (size_t)std::max(skinny_max, 1) * tile); // skinny rule: tiles <= skinny_tiles, S <= skinny_max
     b = std::max(b, (size_t)std::max(ff_split_tiles, 1) * 128 * 256 * (size_t)std::max(ff_split_max, 1) * sizeof(float));   // <= ff_split_tiles pixel tiles of <= 128 px, C <= 256
     return b;
   }
@@ -978,7 +982,14 @@ class Engine : public EngineBase {
                                 // against 91 + 218 us per sub-block, and 0.5 GB less HBM traffic each) and on maps of <= 32768 tokens, where three
                                 // launch-bound kernels become one (1-degree model +5 %); slower in between
   int ff_min_wgs = 256;         // fused feed-forward only when it yields at least this many workgroups (WX_FF_MIN_WGS)
-  float2* statpart = nullptr;   // [max_hw][8] LayerNorm partials written by the producing GEMM epilogue
+  float2* statpart = nullptr;   // [rows][slots] LayerNorm partials written by the producing GEMM epilogue (slots <= 8, or C / 32)
+  int64_t statpart_elems = 0;
+  float2* stat_dst(int64_t rows, int slots) const {
+    if (rows * slots > statpart_elems)
+      throw StateError("LayerNorm partials: " + std::to_string(rows) + " rows x " + std::to_string(slots) + " slots exceed the " +
+                       std::to_string(statpart_elems) + " reserved");
+    return statpart;
+  }
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
   bool blk_hidden = false;      // set around a FeedForward's two gemm() calls: the hidden tensor is k-blocked [4C/32][M][32] (layer 1 writes
                                 // it, layer 2 reads it: full cache lines per LDS-DMA piece; ff2 47.9 -> 45.0 us, ff1 56.6 -> 53.8 us)
@@ -1023,7 +1034,11 @@ class Engine : public EngineBase {
     dec = (T*)dalloc((int64_t)Hd * Wd * ld_dec * sizeof(T));
     WX_HIP(hipMemset(dec, 0, (int64_t)Hd * Wd * ld_dec * sizeof(T)));
     rowstat = (float2*)dalloc(max_hw * sizeof(float2));
-    statpart = (float2*)dalloc(max_hw * 8 * sizeof(float2));
+    // LayerNorm partials: most producers leave <= 8 per row; the weight-stationary GEMM and the attention block kernel leave C / 32
+    // (16 at C = 512) -- sized from the largest rows x slots product any stage can ask for, and checked at every producer (stat_dst)
+    statpart_elems = max_hw * 8;
+    for (int s = 0; s < 4; ++s) statpart_elems = std::max(statpart_elems, (int64_t)sh[s] * sw[s] * std::max(8, cfg.dim[s] / 32));
+    statpart = (float2*)dalloc(statpart_elems * sizeof(float2));
     gnpart = (float2*)dalloc((int64_t)cdiv(max_hw, 128) * cfg.dim[3] * sizeof(float2));
     zero_page = (char*)dalloc(256);
     WX_HIP(hipMemset(zero_page, 0, 256));
@@ -1343,7 +1358,7 @@ class Engine : public EngineBase {
           q.M = (int)rows; q.N = w.n; q.K = w.cin; q.bias = p.bias; q.colsum = p.colsum;
           q.rowstat = rs; q.stat_tiles = p.stat_tiles; q.stat_inv_c = p.stat_inv_c;
           q.res = reinterpret_cast<const bf16_t*>(res); q.res_ld = res_ld;
-          q.stat_out = res_v ? statpart : nullptr; q.stat_slots = w.n / 32;
+          q.stat_out = res_v ? stat_dst(rows, w.n / 32) : nullptr; q.stat_slots = w.n / 32;
           q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
           cur_family = "wreg";
           timed(cls, flops, bytes, [&] { launch_gemm_wreg(q, res_v ? 3 : (act == 1 ? 2 : 1), cur_stream); });
@@ -1361,7 +1376,7 @@ class Engine : public EngineBase {
         q.a = reinterpret_cast<const bf16_t*>(in); q.lda = in_ld; q.w = reinterpret_cast<const bf16_t*>(wt_dev + w.wt_kb);
         q.M = out_h * out_w; q.N = w.n; q.K = w.cin; q.bias = p.bias;
         q.res = reinterpret_cast<const bf16_t*>(res); q.res_ld = res_ld;
-        q.stat_out = statpart; q.stat_slots = w.n / 64;
+        q.stat_out = stat_dst(q.M, w.n / 64); q.stat_slots = w.n / 64;
         q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
         q.a_blk = blk_hidden ? 1 : 0; q.a_rows = q.M;
         // at most one 160 x 128 tile per CU and a deep K (stage 3 of the 0.25-degree model): the loader / consumer form of the kernel
@@ -1483,7 +1498,7 @@ class Engine : public EngineBase {
         bp.tb = f_dev + a.bias_tb; bp.H = h; bp.W = w; bp.wsz = a.wsz; bp.kind = a.kind;
         bp.pack = a.wsz == 2 ? 4 : 1;
         const double n = (double)a.wsz * a.wsz;
-        bp.stat_out = fuse_ln && !dbg_flags ? statpart : nullptr;
+        bp.stat_out = fuse_ln && !dbg_flags ? stat_dst(m, c / 32) : nullptr;
         timed("attn_block", 8.0 * m * c * c + 4.0 * m * n * c, 2.0 * m * c * sizeof(T), [&] { launch_attn_block(c, bp, cur_stream); });
         stat_tiles_ready = bp.stat_out ? c / 32 : 0;
         capture(dbg_name, x, h, w, c, ld, w);
@@ -1971,6 +1986,10 @@ class Engine : public EngineBase {
     if (n < 1 || rank < 0 || rank >= n) throw ConfigError("wx_band_enable: bad rank / nranks");
     band_check_supported(*this);
     WX_HIP(hipSetDevice(device));
+    if (splitk_bound(true) > splitk_bytes) {   // the band ranks' split-K rule reaches more tiles than the whole-map engine's
+      splitk_bytes = splitk_bound(true);
+      splitk_buf = (float*)dalloc(splitk_bytes);
+    }
     for (int s = 0; s < 4; ++s) gsh[s] = sh[s];
     bplan.build(band_model(*this, n));
     b_rank = rank; b_n = n;

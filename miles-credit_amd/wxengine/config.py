@@ -110,6 +110,8 @@ class WXConfig:
         for d in self.dim:
             if d % self.dim_head:
                 raise ValueError("dim must be a multiple of dim_head")
+        if self.dim_head != 32 and max(max(self.local_window_size), max(self.global_window_size)) ** 2 > 128:
+            raise ValueError("dim_head != 32 needs windows of at most 128 tokens (the general attention kernel's limit)")
         if self.dim[-1] % 8:
             raise ValueError("dim[-1] must be divisible by 8 (decoder widths)")
         hw = self.stage_hw

@@ -265,15 +265,27 @@ def _sn_matrix(prefix: str, w: np.ndarray) -> np.ndarray:
     return w.reshape(w.shape[0], -1)
 
 
-def fold_spectral_norm(sd) -> "OrderedDict[str, np.ndarray]":
+# Modules whose weight the reference reads WITHOUT the spectral normalisation, timm stage only: timm's V2 WindowAttention never calls
+# its `qkv` module -- it runs F.linear(x, self.qkv.weight, cat(q_bias, k_bias, v_bias)) -- so the forward pre-hook that
+# torch.nn.utils.spectral_norm installs (fuxi.py:16-22) never fires for it, and the plain `weight` attribute it reads is the alias of
+# `weight_orig` the hook-based implementation leaves behind (checked here with torch alone: after load_state_dict,
+# `m.weight.data_ptr() == m.weight_orig.data_ptr()` until the module itself is called).  The effective qkv weight is weight_orig.
+TIMM_UNNORMALISED = (".attn.qkv",)
+
+
+def fold_spectral_norm(sd, raw=()) -> "OrderedDict[str, np.ndarray]":
     """Eval-mode weights: every `<m>.weight_orig / weight_u / weight_v` triple becomes `<m>.weight = weight_orig / sigma`,
-    sigma = u . (W_mat v) in fp32 as torch computes it (torch/nn/utils/spectral_norm.py compute_weight, do_power_iteration False)."""
+    sigma = u . (W_mat v) in fp32 as torch computes it (torch/nn/utils/spectral_norm.py compute_weight, do_power_iteration False).
+    `raw`: module-name suffixes whose weight stays weight_orig (TIMM_UNNORMALISED)."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     get = lambda k: np.asarray(sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k], dtype=np.float32)  # noqa: E731
     for k in sd:
         if k.endswith(".weight_orig"):
             base = k[: -len(".weight_orig")]
             w = get(k)
+            if raw and base.endswith(tuple(raw)):
+                out[base + ".weight"] = w
+                continue
             sigma = np.float32(np.dot(get(base + ".weight_u"), _sn_matrix(base, w) @ get(base + ".weight_v")))
             out[base + ".weight"] = (w / sigma).astype(np.float32)
         elif k.endswith((".weight_u", ".weight_v")):
@@ -328,7 +340,7 @@ class FuxiHIP:
             got = tuple(sd[k].shape)
             if got != tuple(shape):
                 raise ValueError(f"FuxiHIP.load_state_dict: {k} has shape {got}, expected {tuple(shape)}")
-        eff = fold_spectral_norm(OrderedDict((k, sd[k]) for k in spec))
+        eff = fold_spectral_norm(OrderedDict((k, sd[k]) for k in spec), raw=TIMM_UNNORMALISED if cfg.stage == "timm" else ())
         ws = (cfg.window_size, cfg.window_size)
         if cfg.stage == "timm":
             for k, v in eff.items():

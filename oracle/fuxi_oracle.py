@@ -25,13 +25,18 @@ from torch import Tensor
 from oracle import swin_oracle as S
 
 
-def effective_weights(sd: Dict[str, Tensor], dtype=torch.float32) -> Dict[str, Tensor]:
+def effective_weights(sd: Dict[str, Tensor], dtype=torch.float32, raw: Tuple[str, ...] = ()) -> Dict[str, Tensor]:
+    """raw: module suffixes read without the normalisation -- timm's WindowAttention calls F.linear(x, self.qkv.weight, ...) and never
+    the qkv module, so spectral_norm's forward pre-hook does not fire and `weight` stays the alias of weight_orig (variant "timm")."""
     out = {}
     for k, v in sd.items():
         v = torch.as_tensor(v)
         if k.endswith(".weight_orig"):
             base = k[: -len(".weight_orig")]
             w = v.to(torch.float32)
+            if raw and base.endswith(tuple(raw)):
+                out[base + ".weight"] = w.to(dtype)
+                continue
             mat = w.transpose(0, 1).reshape(w.shape[1], -1) if base.endswith("u_transformer.up.conv") else w.reshape(w.shape[0], -1)
             sigma = torch.dot(torch.as_tensor(sd[base + ".weight_u"]).float(), mat @ torch.as_tensor(sd[base + ".weight_v"]).float())
             out[base + ".weight"] = (w / sigma).to(dtype)
@@ -90,7 +95,7 @@ def stage(x: Tensor, w: Dict[str, Tensor], heads: int, window: int, depth: int, 
 def forward(x: Tensor, sd: Dict[str, Tensor], heads: int, window: int, depth: int, groups: Tuple[int, int], out_chans: int,
             taps: dict = None, variant: str = "cr") -> Tensor:
     """x [C_in, T, H, W] -> y [C_out, H, W]; `taps` (optional dict) receives the intermediate maps, channels-last."""
-    w = effective_weights(sd, x.dtype)
+    w = effective_weights(sd, x.dtype, raw=(".attn.qkv",) if variant == "timm" else ())
     ph, pw = w["cube_embedding.proj.weight"].shape[3:]
     e = cube_embedding(x, w)
     d = down_block(e, w, groups[0])

@@ -341,3 +341,33 @@ def test_fuxi_6h_full_size_properties_and_throughput():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     print(f"\nFuXi-6h 0.25 deg forward (bf16): {ms:.2f} ms, {1e3 / ms:.1f} forwards/s, {m.flops / ms / 1e9:.0f} TFLOP/s algorithmic")
+
+
+def test_timm_qkv_is_read_without_spectral_normalisation():
+    """timm's V2 WindowAttention runs F.linear(x, self.qkv.weight, ...) and never calls the qkv MODULE, so the forward pre-hook of
+    torch.nn.utils.spectral_norm (fuxi.py:16-22) does not fire for it: the `weight` attribute it reads stays the alias of weight_orig.
+    The aliasing is a property of torch's hook-based implementation and is checked here with torch alone; the timm stage's host fold and
+    the oracle therefore keep attn.qkv at weight_orig (every other Linear / Conv is divided by sigma)."""
+    lin = torch.nn.utils.spectral_norm(torch.nn.Linear(8, 24, bias=False))
+    lin.load_state_dict({k: torch.randn_like(v) for k, v in lin.state_dict().items()})
+    lin.eval()
+    assert lin.weight.data_ptr() == lin.weight_orig.data_ptr()          # what F.linear(x, m.weight) sees when m is never called
+    lin(torch.randn(2, 8))
+    assert not torch.equal(lin.weight, lin.weight_orig)                 # ... and what a module call would have made of it
+    from wxengine.fuxi import TIMM_UNNORMALISED
+    cfg = named_fuxi_config("FT0")
+    sd = synth_fuxi_state_dict(cfg)
+    qk = [k for k in sd if k.endswith(".attn.qkv.weight_orig")]
+    if not qk:                                                          # FT0 may be the V2-Cr stage: use the timm-stage twin
+        cfg = FuxiConfig(**{**cfg.__dict__, "stage": "timm"}) if hasattr(cfg, "__dict__") else cfg
+        sd = synth_fuxi_state_dict(cfg)
+        qk = [k for k in sd if k.endswith(".attn.qkv.weight_orig")]
+    assert qk
+    host = fold_spectral_norm(sd, raw=TIMM_UNNORMALISED)
+    orc = FO.effective_weights({k: torch.from_numpy(v) for k, v in sd.items()}, raw=TIMM_UNNORMALISED)
+    for k in qk:
+        base = k[: -len(".weight_orig")]
+        np.testing.assert_array_equal(host[base + ".weight"], sd[k])
+        np.testing.assert_array_equal(orc[base + ".weight"].numpy(), sd[k])
+    other = next(k for k in sd if k.endswith(".weight_orig") and k not in qk)
+    assert not np.array_equal(host[other[: -len("_orig")]], sd[other])

@@ -251,7 +251,8 @@ def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base"):
             print(f"[golden] {name} ({family}) rollout step {step}/{n_steps}: mean|y|={y.abs().mean():.4f}  reference-fp32 vs fp64 oracle "
                   f"rel-L2 {rel[-1]:.3e}" + (f"  reference under bf16 autocast {ac[-1]:.3e}" if ac else "") + f"  ({time.time() - t0:.0f}s)", flush=True)
     out["y"] = np.stack(ys)            # [n_steps, C_out, H/stride, W/stride]  reference, fp32
-    out["y64"] = np.stack(y64s)        # the fp64 oracle's trajectory at the same points
+    # the fp64 oracle's trajectory at the same points (without it: an empty array -- tests then gate against the reference alone)
+    out["y64"] = np.stack(y64s) if with_fp64 else np.zeros((0,), np.float32)
     out["ch_sums"] = np.stack(sums)    # [n_steps, 2, C_out] float64
     out["ref_vs_fp64_rel_l2"] = np.array(rel) if with_fp64 else np.full(n_steps, np.nan)
     if ac:
@@ -802,8 +803,8 @@ def main():
             long_rollout_golden("C3S", 8, 40, with_fp64=False)
         elif item == "rollC1stress":   # 8 steps of the 1-degree model on the "stress" weight family (logits +-40, pre-GELU 1e2)
             long_rollout_golden("C1", 8, 20, family="stress")
-        elif item == "rollC3":      # BASELINE config 3 itself: 6 steps of the FULL-width 124 M-parameter model on the 0.25-degree grid
-            long_rollout_golden("C3", 6, 40, with_fp64=False)
+        elif item == "rollC3":      # BASELINE config 3 itself: its 40 steps of the FULL-width 124 M-parameter model on the 0.25-degree grid
+            long_rollout_golden("C3", 40, 40, with_fp64=False)   # (rounds 2-4 stored 6 steps; ~30 min of CPU for 40)
         elif item == "layout":
             layout_golden()
         elif item == "fixers":
@@ -830,6 +831,12 @@ def main():
             model_golden(item, 8, False)
         elif item in ("C3S", "C3"):
             model_golden(item, 16, False)
+        elif item == "stressC3S":   # the stress families at HEADLINE map size (721 x 1440): the kernel instantiations only that size selects
+            for fam in ("stress", "stress_hi"):
+                model_golden("C3S", 16, False, family=fam)
+        elif item == "stressC3":    # ... and through the full-width 124 M-parameter model
+            for fam in ("stress", "stress_hi"):
+                model_golden("C3", 16, False, family=fam)
         elif item == "stress":   # the stress weight families (wxengine.synth.FAMILIES) through the reference: T0 / T1 full maps, C1 strided
             for fam in ("stress", "stress_hi"):
                 model_golden("T0", 1, False, family=fam)
