@@ -47,7 +47,11 @@ enum wx_arch {
 
 enum wx_precision {
   WX_PREC_FP32 = 0,        /* f32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32) */
-  WX_PREC_BF16 = 1         /* bf16 storage + bf16 MFMA, fp32 accumulate / LN / softmax / GN */
+  WX_PREC_BF16 = 1,        /* bf16 storage + bf16 MFMA, fp32 accumulate / LN / softmax / GN */
+  WX_PREC_FP32_SPLIT = 2   /* f32 storage, LN / softmax / GN / attention as WX_PREC_FP32; every implicit GEMM as split-bf16 arithmetic:
+                            * x = x_hi + x_lo, W = W_hi + W_lo, three v_mfma_f32_16x16x32_bf16 per product (hi.hi + hi.lo + lo.hi),
+                            * fp32 accumulate -- the fast mode that still meets the fp32 tolerance against the reference (whose
+                            * inference is fp32 with TF32 off, credit/seed.py:24-25).  wx_create only (not the Swin / FuXi handles). */
 };
 
 /* The YAML `model:` mapping of the reference constructor
@@ -378,6 +382,14 @@ typedef struct wx_kernel_stat {
   double flops;       /* algorithmic FLOPs issued by these launches (2*MAC) */
   double bytes;       /* algorithmic HBM bytes (each operand read/written once) */
 } wx_kernel_stat;
+ /* wx_query: one integer fact about the engine / its LAST forward, by name -- which schedule and precision variant actually ran (what a
+ * parity test needs to prove it exercised the path it names; the reference has no counterpart: its "schedule" is ATen's).  Keys:
+ *   "two_stream_stages"  stages of the last forward whose sub-block chains ran as two half-maps on two streams (round 5)
+ *   "launches"           kernel launches of the last forward (counted when wx_profile is on, else -1)
+ *   "precision"          the wx_config precision the engine was created with
+ *   "split_gemms"        GEMM launches of the last forward that ran split-bf16 arithmetic (WX_PREC_FP32_SPLIT)
+ * Unknown key -> WX_ERR_INVALID. */
+int wx_query(wx_handle h, const char* key, int64_t* value);
 int wx_profile(wx_handle h, int enable);
 int wx_profile_reset(wx_handle h);
 int wx_profile_read(wx_handle h, wx_kernel_stat* out, int capacity, int* count);

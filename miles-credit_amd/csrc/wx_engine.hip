@@ -137,6 +137,7 @@ class EngineBase {
   virtual void profile_reset() = 0;
   virtual int profile_read(wx_kernel_stat* out, int cap) = 0;
   virtual void attach_post(PostBlock* p) = 0;
+  virtual bool query(const std::string& key, int64_t* v) = 0;
   virtual void band_enable(int rank, int nranks) = 0;
   virtual void band_info(int* own_row0, int* own_rows, int64_t* send_bytes, int64_t* recv_bytes, int* n_exchanges) = 0;
   virtual void band_set_staging(void* send, int64_t send_bytes, void* recv, int64_t recv_bytes) = 0;
@@ -152,7 +153,12 @@ class EngineBase {
 template <typename T>
 class Engine : public EngineBase {
  public:
-  explicit Engine(const wx_config& c, int dev) : cfg(c) {
+  // split_mma (T = float only; wx_config.precision WX_PREC_FP32_SPLIT): fp32 storage, LayerNorm / softmax / GroupNorm / attention as the
+  // exact-f32 engine, but every implicit GEMM runs split-bf16 arithmetic on the 2.5 PF pipe -- x = x_hi + x_lo, W = W_hi + W_lo (split
+  // once at load), three bf16 MFMAs per product with fp32 accumulation (wx_gemm.h, SPLIT).  Measured error against the reference's
+  // fp32 forward: ~1e-5 of max|y| (base weights), 5-7e-5 on the stress families -- inside the stated 1e-4 tolerance.
+  bool split_mma = false;
+  explicit Engine(const wx_config& c, int dev, bool split = false) : split_mma(split && sizeof(T) == 4), cfg(c) {
     device = dev;
     derive();
     build_spec();
@@ -164,6 +170,7 @@ class Engine : public EngineBase {
     if (b_cstream_own && b_cstream) (void)hipStreamDestroy(b_cstream);
     if (b_ev_pack) { (void)hipEventDestroy(b_ev_pack); (void)hipEventDestroy(b_ev_done); }
     roll_invalidate();
+    if (side_stream) { (void)hipStreamDestroy(side_stream); (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); }
     if (roll_stream) { (void)hipStreamDestroy(roll_stream); (void)hipEventDestroy(roll_ev_in); (void)hipEventDestroy(roll_ev_out); }
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -446,7 +453,8 @@ class Engine : public EngineBase {
     return off;
   }
   int64_t push_w(const std::vector<double>& rows, int n, int64_t k) {
-    while (wt_host.size() % 8) wt_host.push_back(Elem<T>::from_f(0.f));
+    // 16-byte blocks; split-bf16 arithmetic: whole 32-float K chunks (the split arena re-encodes the arena chunk by chunk)
+    while (wt_host.size() % (split_mma ? 32 : 8)) wt_host.push_back(Elem<T>::from_f(0.f));
     const int64_t off = (int64_t)wt_host.size();
     wt_host.resize(off + (int64_t)n * k);
     for (int64_t i = 0; i < (int64_t)n * k; ++i) wt_host[off + i] = Elem<T>::from_f((float)rows[i]);
@@ -902,6 +910,28 @@ class Engine : public EngineBase {
     f_dev = (float*)dalloc(f_host.size() * sizeof(float) + 256);
     WX_HIP(hipMemcpy(wt_dev, wt_host.data(), wt_host.size() * sizeof(T), hipMemcpyHostToDevice));
     WX_HIP(hipMemcpy(f_dev, f_host.data(), f_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    if constexpr (sizeof(T) == 4) {
+      if (split_mma) {
+        // the split arena: same offsets, same bytes per 32-float chunk -- [hi fragments g = 0..3 | lo fragments g = 0..3], fragment g =
+        // the eight k values {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3} a lane of k-group g feeds to v_mfma_f32_16x16x32_bf16
+        // (the same two 16-byte slots of the fp32 activation row the exact-f32 path reads in its two sub-steps).  Every weight row of
+        // a layer with cin % 32 == 0 is a whole number of chunks from a chunk-aligned start (push_w); other layers keep the f32 MFMA.
+        while (wt_host.size() % 32) wt_host.push_back(0.f);
+        std::vector<uint16_t> sp(wt_host.size() * 2);
+        for (size_t c0 = 0; c0 < wt_host.size(); c0 += 32)
+          for (int g = 0; g < 4; ++g)
+            for (int e = 0; e < 8; ++e) {
+              const float w = wt_host[c0 + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))];
+              const bf16_t hi = f2bf(w);
+              const bf16_t lo = f2bf(w - bf2f(hi));
+              sp[c0 * 2 + g * 8 + e] = hi;
+              sp[c0 * 2 + 32 + g * 8 + e] = lo;
+            }
+        if (ws_dev) { (void)hipFree(ws_dev); allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)ws_dev)); ws_dev = nullptr; }
+        ws_dev = (T*)dalloc(sp.size() * sizeof(uint16_t) + 256);
+        WX_HIP(hipMemcpy(ws_dev, sp.data(), sp.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      }
+    }
     std::vector<T>().swap(wt_host);
     alloc_activations();
     finalized = true;
@@ -915,6 +945,7 @@ class Engine : public EngineBase {
     allocs.push_back(p);
     return p;
   }
+  T* ws_dev = nullptr;       // split_mma: the weight arena re-encoded as bf16 (hi, lo) fragments, same offsets as wt_dev
   T* xin = nullptr;          // packed, halo'd input
   T* xin_planar = nullptr;   // chunk-planar copy for the LDS-patch CrossEmbed kernel (wx_embed.h)
   T* cat[3] = {nullptr, nullptr, nullptr};   // [HW_s][2*C_s]: [up-block output | encoder stream]
@@ -993,6 +1024,15 @@ class Engine : public EngineBase {
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
   bool blk_hidden = false;      // set around a FeedForward's two gemm() calls: the hidden tensor is k-blocked [4C/32][M][32] (layer 1 writes
                                 // it, layer 2 reads it: full cache lines per LDS-DMA piece; ff2 47.9 -> 45.0 us, ff1 56.6 -> 53.8 us)
+  // Row window (round 5): attention() / feedforward() / gemm() work on map rows [rw0, rw0 + rwn) of the current stage instead of the whole
+  // map when rwn >= 0 -- the half-maps of the two-stream schedule below.  Every buffer a sub-block touches is indexed by token, so a
+  // window is a pointer offset: the stream, q|k|v and the hidden tensor (scratch, 4 C per token: the halves' regions are disjoint),
+  // attn_o, the LayerNorm partials.  rule_rows: the row count the kernel-selection rules see (the whole map's: a half runs the kernels
+  // the whole map would, so the outputs stay bit-identical to the one-stream step).
+  int rw0 = 0, rwn = -1;
+  int64_t rule_rows = 0;
+  int64_t rw_tok0(int s) const { return rwn >= 0 ? (int64_t)rw0 * sw[s] : 0; }
+  int rw_rows(int s) const { return rwn >= 0 ? rwn : sh[s]; }
   int last_stat_slots = 0;      // partial slots per row the last statistics-producing gemm() wrote
   int stat_tiles_ready = 0;     // > 0: `statpart` holds partials of the current stream contents (that many per row)
   bool use_patch = true, planar_xin = true;
@@ -1182,6 +1222,15 @@ class Engine : public EngineBase {
   int cur_stage = -1;   // appended to kernel-class names while profiling ("gemm_ff1.s2")
 
   void profile(int on) override { prof_on = on != 0; detail_on = on > 1; family_on = on > 2; }
+  int64_t n_two_stream_stages = 0;   // of the last forward
+  int64_t n_split_gemms = 0;         // GEMM launches of the last forward that ran split-bf16 arithmetic
+  bool query(const std::string& key, int64_t* v) override {
+    if (key == "two_stream_stages") { *v = n_two_stream_stages; return true; }
+    if (key == "launches") { *v = prof_on ? (int64_t)pending.size() : -1; return true; }
+    if (key == "precision") { *v = sizeof(T) == 2 ? WX_PREC_BF16 : (split_mma ? WX_PREC_FP32_SPLIT : WX_PREC_FP32); return true; }
+    if (key == "split_gemms") { *v = n_split_gemms; return true; }
+    return false;
+  }
   void profile_reset() override { drain(); stats.clear(); }
   void drain() {
     if (pending.empty()) return;
@@ -1309,12 +1358,19 @@ class Engine : public EngineBase {
     p.act = act; p.res = res; p.res_ld = res_ld; p.out = out; p.out_ld = out_ld;
     p.out_mode = out_mode; p.cout = cout; p.py = py; p.px = px; p.dbg = dbg_flags;
     const double m = (double)out_h * out_w;
+    if constexpr (sizeof(T) == 4) {
+      if (split_mma && w.cin % 32 == 0 && !dbg_flags && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr)) {
+        p.split = 1;
+        p.wt = ws_dev + w.wt;
+        ++n_split_gemms;
+      }
+    }
     if (gemm_par) {   // the four parity convs of a ConvTranspose k4 s2 p1 (out_mode 2): one launch when the fast path takes it
       const ConvW* gp = gemm_par;
       gemm_par = nullptr;
       if (merge_parity && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr) && !dbg_flags && w.n <= 128) {
         p.n_par = 4;
-        for (int q = 0; q < 4; ++q) p.wt_par[q] = wt_dev + gp[q].wt;
+        for (int q = 0; q < 4; ++q) p.wt_par[q] = (p.split ? ws_dev : wt_dev) + gp[q].wt;
         const double fl4 = 4.0 * 2.0 * m * w.n * w.kh * w.kw * w.cin_true;
         const double by4 = (4.0 * m * w.n + (double)in_h * in_w * w.cin_true + 4.0 * w.n * w.kh * w.kw * w.cin) * sizeof(T);
         timed(cls, fl4, by4, [&] { launch_conv_gemm<T>(p, zero_page, cur_stream, gemm_cfg); });
@@ -1346,11 +1402,13 @@ class Engine : public EngineBase {
       // weight-stationary kernel (wx_gemm_wreg.h: the wave's weight slice in registers, activations streamed tile by tile, one barrier
       // per tile).  tools/gemm_wreg_probe, M = 2500: to_qkv 11.5 us against 16.1 (persistent kernel) -- at M = 20 000 the two tie, so the
       // unsharded model keeps the persistent kernel.  Bitwise the same outputs; row partials in N / 32 slots instead of N / 128.
+      const int64_t sel_rows = rule_rows > 0 ? rule_rows : (int64_t)out_h * out_w;   // what the selection rules see (row windows: the whole map)
+      const int64_t st_tok0 = rwn >= 0 && cur_stage >= 0 && cur_stage < 4 ? rw_tok0(cur_stage) : 0;
       {
         const int64_t rows = (int64_t)out_h * out_w;
         const bool ln_v = rs && !res && !want_stats && w.colsum >= 0, res_v = !rs && res && want_stats && fuse_ln && act == 0;
         if (use_wreg && use_dma && w.wt_kb >= 0 && one && w.cin == 512 && w.n % WREG_BN == 0 && w.bias >= 0 && out_mode == 0 && !want_gn && !dbg_flags &&
-            !blk_hidden && rows >= wreg_min_rows && rows < wreg_max_rows && (ln_v || (res_v && w.n / 32 <= WREG_MAXT)) &&
+            !blk_hidden && rwn < 0 && rows >= wreg_min_rows && rows < wreg_max_rows && (ln_v || (res_v && w.n / 32 <= WREG_MAXT)) &&
             wreg_gemm_ok(rows, w.n, w.cin, p.stat_tiles, ln_v)) {
           StreamGemmParams q;
           std::memset(&q, 0, sizeof(q));
@@ -1369,18 +1427,18 @@ class Engine : public EngineBase {
       // residual layers with N = 512 / 1024 (to_out, FeedForward layer 2 of stages 2 and 3): 160 x 128 tiles, two workgroups per CU
       // (47.9 vs 58.3 us on layer 2, 21.0 vs 23.2 us on to_out; bitwise equal to the 128 x 128 kernel's output)
       if (use_stream && use_dma && w.wt_kb >= 0 && one && !rs && res && act == 0 && out_mode == 0 && want_stats && fuse_ln && !want_gn &&
-          !dbg_flags && (w.n == 512 || w.n == 1024) && w.bias >= 0 && (int64_t)out_h * out_w >= stream_min_rows &&
+          !dbg_flags && (w.n == 512 || w.n == 1024) && w.bias >= 0 && sel_rows >= stream_min_rows &&
           stream_gemm_ok((int64_t)out_h * out_w, w.n, w.cin, 128)) {
         StreamGemmParams q;
         std::memset(&q, 0, sizeof(q));
         q.a = reinterpret_cast<const bf16_t*>(in); q.lda = in_ld; q.w = reinterpret_cast<const bf16_t*>(wt_dev + w.wt_kb);
         q.M = out_h * out_w; q.N = w.n; q.K = w.cin; q.bias = p.bias;
         q.res = reinterpret_cast<const bf16_t*>(res); q.res_ld = res_ld;
-        q.stat_out = stat_dst(q.M, w.n / 64); q.stat_slots = w.n / 64;
+        q.stat_out = stat_dst(st_tok0 + q.M, w.n / 64) + st_tok0 * (w.n / 64); q.stat_slots = w.n / 64;
         q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
         q.a_blk = blk_hidden ? 1 : 0; q.a_rows = q.M;
         // at most one 160 x 128 tile per CU and a deep K (stage 3 of the 0.25-degree model): the loader / consumer form of the kernel
-        const bool lc = use_stream_lc && stream_gemm_lc_pays(q.M, q.N, q.K, 5);
+        const bool lc = use_stream_lc && stream_gemm_lc_pays(sel_rows, q.N, q.K, 5);
         cur_family = lc ? "stream_lc" : "stream";
         timed(cls, flops, bytes, [&] {
           if (lc) launch_gemm_stream_n128_lc<5, 8>(q, cur_stream);
@@ -1390,7 +1448,7 @@ class Engine : public EngineBase {
         return true;
       }
       if (use_stream && use_dma && w.wt_kb >= 0 && w.n % 256 == 0 && one && rs && !res && out_mode == 0 && !want_stats && !want_gn && !dbg_flags &&
-          (int64_t)out_h * out_w >= stream_min_rows && stream_gemm_ok((int64_t)out_h * out_w, w.n, w.cin)) {
+          sel_rows >= stream_min_rows && stream_gemm_ok((int64_t)out_h * out_w, w.n, w.cin)) {
         StreamGemmParams q;
         std::memset(&q, 0, sizeof(q));
         q.a = reinterpret_cast<const bf16_t*>(in); q.lda = in_ld; q.w = reinterpret_cast<const bf16_t*>(wt_dev + w.wt_kb);
@@ -1410,6 +1468,7 @@ class Engine : public EngineBase {
       }
     }
     if (blk_hidden) throw StateError("k-blocked hidden tensor requested but the GEMM fell back to the row-major kernel");
+    if (rwn >= 0) throw StateError("row-window launch fell to the generic kernel (the two-stream schedule runs on the persistent GEMMs only)");
     // split-K for plain deep-K launches that cannot fill the chip (stage-3 CrossEmbed k = 4: 160 tiles walking K = 8192; every
     // CrossEmbed GEMM of the 1-degree grid): 128 x 128 tiles x S K-ranges, fp32 partial sums, fixed-order finish kernel
     if (!rs && !res && act == 0 && out_mode == 0 && !p.gn_out && conv_gemm_is_dma<T>(p, zero_page)) {
@@ -1462,7 +1521,9 @@ class Engine : public EngineBase {
   // LayerNorm statistics of the stream: either the partials the last producing GEMM left (stat_tiles_ready > 0)
   // or a fresh two-pass ln_stats launch (stage entry, slow-path producers).
   const float2* stream_stats(const T* x, int64_t ld, int c, int m) {
-    if (stat_tiles_ready > 0) return statpart;
+    const int64_t t0 = rwn >= 0 && cur_stage >= 0 && cur_stage < 4 ? rw_tok0(cur_stage) : 0;
+    if (stat_tiles_ready > 0) return statpart + t0 * stat_tiles_ready;
+    if (rwn >= 0) throw StateError("row-window launch without LayerNorm partials from its producer");
     ln_stats(x, ld, c, m);
     return rowstat;
   }
@@ -1485,11 +1546,14 @@ class Engine : public EngineBase {
            (a.kind == 0 || a.kind == 1) && a.qkv.cin == cfg.dim[s] && a.out.cin == cfg.dim[s];
   }
   void attention(const AttnL& a, int s, const std::string& dbg_name, bool defer_out = false, bool qkv_ready = false) {
-    const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
-    T* x = stream_ptr(s);
-    const int64_t ld = stream_ld(s);
+    const int c = cfg.dim[s], h = rw_rows(s), w = sw[s], m = h * w;
+    const int64_t ld = stream_ld(s), t0 = rw_tok0(s);
+    T* x = stream_ptr(s) + t0 * ld;
+    T* const scratch = this->scratch + t0 * 4 * c;   // the window's own q|k|v region
+    T* const attn_o = this->attn_o + t0 * c;
     if constexpr (sizeof(T) == 2) {
       if (attn_block_ok(a, s)) {
+        if (rwn >= 0) throw StateError("attention block kernel on a row window");
         if (defer_out || qkv_ready) throw StateError("attention block: the fused feed-forward variants must be off for this layer");
         AttnBlockParams bp;
         bp.x = reinterpret_cast<bf16_t*>(x); bp.ld = ld;
@@ -1549,9 +1613,12 @@ class Engine : public EngineBase {
            ff_fused_supported(c, 4 * c) && small_map_tokens(s) && cdiv(m, (int64_t)(c == 128 ? 128 : 64)) <= ff_split_tiles && f.w2.bias >= 0 && f.w1.colsum >= 0;
   }
   void feedforward(const FFL& f, int s, const std::string& dbg_name, const AttnL* pre = nullptr) {
-    const int c = cfg.dim[s], h = sh[s], w = sw[s], m = h * w;
-    T* x = stream_ptr(s);
-    const int64_t ld = stream_ld(s);
+    const int c = cfg.dim[s], h = rw_rows(s), w = sw[s], m = h * w;
+    const int64_t ld = stream_ld(s), t0 = rw_tok0(s);
+    T* x = stream_ptr(s) + t0 * ld;
+    T* const scratch = this->scratch + t0 * 4 * c;   // the window's own hidden tensor
+    if (rwn >= 0 && (pre || (sizeof(T) == 2 && f.pack >= 0 && fuse_ff && ff_big_enough())))
+      throw StateError("fused feed-forward on a row window");
     if constexpr (sizeof(T) == 2) {
       if (f.pack >= 0 && fuse_ff && ff_big_enough() && !ff_split_ok(f, s, pre)) {
         FFParams fp{};
@@ -1602,7 +1669,7 @@ class Engine : public EngineBase {
     const float2* rs = stream_stats(x, ld, c, m);
     // both layers on the persistent GEMM (stage 2 of the 0.25-degree model): the hidden tensor between them goes k-blocked
     blk_hidden = sizeof(T) == 2 && use_stream && use_dma && fuse_ln && !dbg_flags && f.w1.wt_kb >= 0 && f.w2.wt_kb >= 0 && c == 512 &&
-                 m >= stream_min_rows && f.w2.bias >= 0;
+                 (rule_rows > 0 ? rule_rows : (int64_t)m) >= stream_min_rows && f.w2.bias >= 0;
     gemm("gemm_ff1", f.w1, x, h, w, ld, 1, 0, 0, h, w, scratch, 4 * c, rs, 1, nullptr, 0);
     const bool st = gemm("gemm_ff2", f.w2, scratch, h, w, 4 * c, 1, 0, 0, h, w, x, ld, nullptr, 0, x, ld, 0, 0, 0, 0, true);
     blk_hidden = false;
@@ -1774,8 +1841,101 @@ class Engine : public EngineBase {
     if (share) stat_tiles_ready = all_made ? total_slots : 0;
   }
   // a4-a7: the transformer blocks of stage s on the rows the stream currently holds
+  // ---- two-stream half-map schedule (round 5) ------------------------------------------------------------------------------------------
+  // The deep stages' launches leave wave slots idle: the stage-2 short attention is 3 200 tasks for 4 096 slots (one round whose length
+  // is one task's dependent chain), stage 3's GEMMs are one tile per CU -- two forecasts in flight recover 5-7 % from them.
+  // The same slots are filled from ONE forecast: every kernel of a sub-block chain (to_qkv -> attention -> to_out -> FeedForward 1 -> 2)
+  // is row-independent at window-row granularity, so the chain runs as two half-maps of whole window rows on two streams -- the second
+  // (engine-owned) stream forks from and joins the caller's stream through one event pair.  Short sub-blocks split (contiguous window
+  // rows); a dilated long sub-block (window > 1) needs every row of both halves and runs whole on the caller's stream between a join
+  // and the next fork; a 1-token long window (stage 3) is pointwise, so that stage forks once and joins once.  Same kernels, same
+  // tiles per row (rule_rows), so the outputs are bit-identical to the one-stream step (tests/test_variants_gpu.py).
+  // MEASURED (MI355X, C3 bf16, same box, alternating arms, tools/ab_time.py; gpurun_out/r5a): one stream 8.06-8.16 ms/step; two streams
+  // 8.39 (both stages), 8.18 (stage 2 only), 8.30 (stage 3 only), 8.25 / 8.18 with the side stream at low / high priority -- every form
+  // LOSES 1.5-3 %: a half-size launch costs the same prologue / epilogue and loses tile-level balance, the persistent GEMMs fill the
+  // register file (two 256-VGPR waves per SIMD) so the other half's attention only ever backfills a tail, and that is worth less than
+  // the halved launches cost.  (Two whole forecasts in flight gain 5-7 % because their launches keep full size and the overlapping
+  // kernels are of different kinds.)  OFF by default; WX_TWO_STREAM=1 keeps it testable (bit-identical, tests/test_variants_gpu.py).
+  int two_stream = getenv("WX_TWO_STREAM") ? atoi(getenv("WX_TWO_STREAM")) : 0;   // 0 off; 1 on where it applies; 2 / 3: stages with a dilated / pointwise long window only (probes)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool two_stream_ok(int s) const {
+    if (sizeof(T) != 2 || !two_stream || band_on || dbg_on || prof_on || dbg_flags || !use_stream || !use_dma || !fuse_ln) return false;
+    if (cfg.dim_head != 32 || cfg.dim[s] < 512 || (int64_t)sh[s] * sw[s] < stream_min_rows) return false;
+    const StageL& st = stages[s];
+    if (st.blocks.empty()) return false;
+    const int wsz = st.blocks[0].sa.wsz;
+    if (wsz <= 1 || sh[s] / wsz < 2) return false;
+    const bool pointwise_long = st.blocks[0].la.wsz == 1;
+    if ((two_stream == 2 && pointwise_long) || (two_stream == 3 && !pointwise_long)) return false;   // probes: one kind of stage only
+    for (const BlockL& bl : st.blocks)
+      if (attn_block_ok(bl.sa, s) || attn_block_ok(bl.la, s) || bl.sf.pack >= 0 || bl.lf.pack >= 0 || bl.sa.wsz != wsz) return false;
+    return true;
+  }
+  void side_ensure() {
+    if (side_stream) return;
+    if (const char* e = getenv("WX_TWO_STREAM_PRIO")) {   // probe: the side stream at the lowest (1) / highest (2) priority
+      int lo = 0, hi = 0;
+      WX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      WX_HIP(hipStreamCreateWithPriority(&side_stream, hipStreamNonBlocking, atoi(e) == 2 ? hi : lo));
+    } else {
+      WX_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    }
+    WX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    WX_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+  void stage_blocks_two_stream(int s) {
+    const StageL& st = stages[s];
+    side_ensure();
+    hipStream_t main_s = cur_stream;
+    const int wsz = st.blocks[0].sa.wsz, wr = sh[s] / wsz;
+    const int rows_a = (wr - wr / 2) * wsz, rows_b = sh[s] - rows_a;   // the caller's stream takes the larger half
+    const bool pointwise_long = st.blocks[0].la.wsz == 1;
+    rule_rows = (int64_t)sh[s] * sw[s];
+    auto fork = [&] { WX_HIP(hipEventRecord(ev_fork, main_s)); WX_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0)); };
+    auto join = [&] { WX_HIP(hipEventRecord(ev_join, side_stream)); WX_HIP(hipStreamWaitEvent(main_s, ev_join, 0)); };
+    // the (host-side) LayerNorm-partial bookkeeping of a chain: both halves start from the same state and must end in the same one
+    auto half = [&](int r0, int rn, hipStream_t strm, auto&& body) {
+      const int save_ready = stat_tiles_ready, save_slots = last_stat_slots;
+      rw0 = r0; rwn = rn; cur_stream = strm;
+      body();
+      rw0 = 0; rwn = -1; cur_stream = main_s;
+      const int end_ready = stat_tiles_ready, end_slots = last_stat_slots;
+      stat_tiles_ready = save_ready; last_stat_slots = save_slots;
+      return std::make_pair(end_ready, end_slots);
+    };
+    auto both = [&](auto&& body) {
+      fork();
+      const auto ea = half(0, rows_a, main_s, body);
+      const auto eb = half(rows_a, rows_b, side_stream, body);
+      join();
+      if (ea != eb) throw StateError("two-stream schedule: the halves left different LayerNorm-partial states");
+      stat_tiles_ready = ea.first; last_stat_slots = ea.second;
+    };
+    if (pointwise_long) {
+      both([&] {
+        for (const BlockL& bl : st.blocks) {
+          attention(bl.sa, s, "");
+          feedforward(bl.sf, s, "");
+          attention(bl.la, s, "");
+          feedforward(bl.lf, s, "");
+        }
+      });
+    } else {
+      for (const BlockL& bl : st.blocks) {
+        both([&] {
+          attention(bl.sa, s, "");
+          feedforward(bl.sf, s, "");
+        });
+        attention(bl.la, s, "");
+        feedforward(bl.lf, s, "");
+      }
+    }
+    rule_rows = 0;
+  }
   void stage_blocks(int s) {
     const StageL& st = stages[s];
+    if (two_stream_ok(s) && stat_tiles_ready > 0) { stage_blocks_two_stream(s); ++n_two_stream_stages; return; }
     const std::string sp = "layers." + std::to_string(s);
     bool qkv_made = false;  // the previous fused kernel already produced this attention's q|k|v
     for (size_t d = 0; d < st.blocks.size(); ++d) {
@@ -1799,6 +1959,8 @@ class Engine : public EngineBase {
     feedforward(f, s, "", df ? &a : nullptr);
   }
   void core(const float* x_item) {
+    n_two_stream_stages = 0;
+    n_split_gemms = 0;
     // a1: pack + earth halo
     pack_input(x_item, xin, xin_planar, Hp + 2 * halo, 0, Hp, halo, 0, cfg.image_height);
     capture("pad", xin + ((int64_t)halo * (Wp + 2 * halo) + halo) * cpad0, Hp, Wp, C_in, cpad0, Wp + 2 * halo);
@@ -2716,6 +2878,7 @@ int wx_create(const wx_config* cfg, int device, wx_handle* out) {
     WX_HIP(hipSetDevice(device));
     std::unique_ptr<wx_engine> h(new wx_engine);
     if (cfg->precision == WX_PREC_FP32) h->impl.reset(new wx::Engine<float>(*cfg, device));
+    else if (cfg->precision == WX_PREC_FP32_SPLIT) h->impl.reset(new wx::Engine<float>(*cfg, device, /*split=*/true));
     else if (cfg->precision == WX_PREC_BF16) h->impl.reset(new wx::Engine<wx::bf16_t>(*cfg, device));
     else throw wx::ConfigError("wx_create: unknown precision");
     *out = h.release();
@@ -2869,6 +3032,13 @@ int wx_band_plan_partition(wx_band_plan p, int which, int32_t* starts) {
 int wx_set_debug(wx_handle h, int enable) { return guarded([&] { WX_NEED(h); h->impl->set_debug(enable); }); }
 int wx_debug_read(wx_handle h, const char* name, float* host_out, int64_t capacity, int64_t shape[3]) {
   return guarded([&] { WX_NEED(h); if (!name || !shape) throw wx::ConfigError("wx_debug_read: null argument"); h->impl->debug_read(name, host_out, capacity, shape); });
+}
+int wx_query(wx_handle h, const char* key, int64_t* value) {
+  return guarded([&] {
+    WX_NEED(h);
+    if (!key || !value) throw wx::ConfigError("wx_query: null argument");
+    if (!h->impl->query(key, value)) throw wx::ConfigError(std::string("wx_query: unknown key '") + key + "'");
+  });
 }
 int wx_profile(wx_handle h, int enable) { return guarded([&] { WX_NEED(h); h->impl->profile(enable); }); }
 int wx_profile_reset(wx_handle h) { return guarded([&] { WX_NEED(h); h->impl->profile_reset(); }); }

@@ -62,6 +62,12 @@ struct ConvGemmParams {
   // Consecutive workgroups take the four parities of one M-tile, so the input rows come out of L2 three times out of four.
   int n_par;
   const void* wt_par[4];
+  // split-bf16 arithmetic on fp32 storage (round 5, T = float, KB = 128 only): `wt` then points into the SPLIT weight arena -- every
+  // 32-float K chunk of a weight row re-encoded in place as [hi: 4 fragments x 8 bf16 | lo: 4 fragments x 8 bf16] (128 bytes either
+  // way, so the staging does not change) -- and the K loop runs three bf16 MFMAs per product (hi.hi + hi.lo + lo.hi, fp32
+  // accumulate) on activation fragments split in registers.  With `rowstat` the LayerNorm is applied to the activation fragment
+  // BEFORE the split ((x - mean) * rstd; no mean * colsum cancellation in the epilogue, which then only adds the bias).
+  int split;
 };
 #ifdef WX_GEMM_TRACE
 __device__ __forceinline__ void trace_stamp(const ConvGemmParams& p, int slot) {
@@ -388,9 +394,25 @@ __device__ __forceinline__ void dma_wait_allow() { asm volatile("s_waitcnt vmcnt
 // BM = BN = 128 is exactly the MFMA rate (64 FLOP per staged byte x 64 B/clk = 4096 FLOP/clk/CU): the 4-wave tile is
 // L1-bound by construction.  BM = 256 (8 waves, 4 x 2) stages 25 % fewer bytes per FLOP; two such workgroups and a
 // 3-stage ring fit a CU (2 x 74 KB LDS, 16 waves).
-template <typename T, int BM, int BN, int KB, bool ONE, int NST, bool TAPIN>
+// fragment of 8 fp32 activations (k = 4 g .. 4 g + 3 | 16 + 4 g .. 16 + 4 g + 3 of a 32-float K chunk) -> (hi, lo) bf16 fragments:
+// hi = RNE_bf16(x), lo = RNE_bf16(x - hi) -- x - hi is exact in fp32, so |x - hi - lo| <= 2^-18 |x|.  24 VALU instructions.
+__device__ __forceinline__ void split_bf16x8(const float (&v)[8], uint4& hi, uint4& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+    const float r0 = v[2 * i] - __builtin_bit_cast(float, h[i] << 16);
+    const float r1 = v[2 * i + 1] - __builtin_bit_cast(float, h[i] & 0xffff0000u);
+    l[i] = pack_bf16x2(r0, r1);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <typename T, int BM, int BN, int KB, bool ONE, int NST, bool TAPIN, bool SPLIT = false>
 __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 : 3) : 2)) void conv_gemm_dma_kernel(
     const ConvGemmParams p, const char* __restrict__ zero_page) {
+  static_assert(!SPLIT || (sizeof(T) == 4 && KB == 128), "split-bf16 arithmetic: fp32 storage, 32-float K steps");
   constexpr int WMR = 64;               // rows (pixels) per wave
   constexpr int WAVES_M = BM / WMR;     // 2 or 4
   constexpr int NW = WAVES_M * 2;       // waves per workgroup
@@ -609,6 +631,14 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
   }
   dma_wait_all();
   __syncthreads();
+  // split path: LayerNorm of this lane's activation rows, applied to the fragments before they are split
+  const bool ln_rows = SPLIT && p.rowstat != nullptr;
+  float ln_mean[FM], ln_rstd[FM];
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const float2 st = SPLIT ? *reinterpret_cast<const float2*>(s_par + 256 + 2 * (wm * WMR + b * 16 + li)) : make_float2(0.f, 1.f);
+    ln_mean[b] = st.x; ln_rstd[b] = st.y;
+  }
   const int nk_run = (p.dbg & 4) ? ks_lo : ks_hi;
   trace_stamp(p, 1);
   int cur_i = 0, nxt_i = NST - 1;  // ring indices of the stage being computed / being filled
@@ -621,6 +651,35 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
 #else
     if (ks + NST - 1 < ks_hi) issue((unsigned)(nxt_i * STAGE), ks + NST - 1);
 #endif
+    if constexpr (SPLIT) {
+      // one 32-float K chunk: the activation fragment of lane (li, g) is the two 16-byte slots the exact-f32 path reads in its two
+      // sub-steps (k = 4 g .. 4 g + 3 and 16 + 4 g ..); the weight row holds the matching hi fragment in slot g and lo in slot 4 + g
+      uint4 xh[FM], xl[FM], wh[FN], wl[FN];
+#pragma unroll
+      for (int a = 0; a < FN; ++a) {
+        wh[a] = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * KB + soff[0]);
+        wl[a] = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * KB + soff[1]);
+      }
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        const float4 t0 = *reinterpret_cast<const float4*>(cur + x_base + b * 16 * KB + soff[0]);
+        const float4 t1 = *reinterpret_cast<const float4*>(cur + x_base + b * 16 * KB + soff[1]);
+        float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        if (ln_rows) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (v[e] - ln_mean[b]) * ln_rstd[b];
+        }
+        split_bf16x8(v, xh[b], xl[b]);
+      }
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+          acc[a][b] = mma_sub<bf16_t>(wl[a], xh[b], acc[a][b]);
+          acc[a][b] = mma_sub<bf16_t>(wh[a], xl[b], acc[a][b]);
+          acc[a][b] = mma_sub<bf16_t>(wh[a], xh[b], acc[a][b]);
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < SUBS; ++s) {
       uint4 xf[FM], wf[FN];
@@ -639,6 +698,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = mma_sub<T>(wf[a], xf[b], acc[a][b]);
+    }
     }
     // step ks+1 must have landed; with 3 stages step ks+2 (just issued) may stay in flight
     WX_TICK(tk1);
@@ -715,10 +775,15 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 
 #pragma unroll
       for (int a = 0; a < FN; ++a) {
         float v[4];
-        v[0] = rstd * (acc[a][b][0] - mean * cs4[a].x) + bias4[a].x;
-        v[1] = rstd * (acc[a][b][1] - mean * cs4[a].y) + bias4[a].y;
-        v[2] = rstd * (acc[a][b][2] - mean * cs4[a].z) + bias4[a].z;
-        v[3] = rstd * (acc[a][b][3] - mean * cs4[a].w) + bias4[a].w;
+        if constexpr (SPLIT) {   // the LayerNorm was applied to the operand
+          v[0] = acc[a][b][0] + bias4[a].x; v[1] = acc[a][b][1] + bias4[a].y;
+          v[2] = acc[a][b][2] + bias4[a].z; v[3] = acc[a][b][3] + bias4[a].w;
+        } else {
+          v[0] = rstd * (acc[a][b][0] - mean * cs4[a].x) + bias4[a].x;
+          v[1] = rstd * (acc[a][b][1] - mean * cs4[a].y) + bias4[a].y;
+          v[2] = rstd * (acc[a][b][2] - mean * cs4[a].z) + bias4[a].z;
+          v[3] = rstd * (acc[a][b][3] - mean * cs4[a].w) + bias4[a].w;
+        }
         acc[a][b] = f32x4_t{v[0], v[1], v[2], v[3]};
       }
     }
@@ -913,13 +978,13 @@ __global__ __launch_bounds__(256) void conv_gemm_finish_kernel(const ConvGemmPar
   float s1 = 0.f, s2 = 0.f;
   if (n < p.n) {
     const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 acc = p.rowstat ? make_float4(0.f, 0.f, 0.f, 0.f) : b4;
+    float4 acc = (p.rowstat && !p.split) ? make_float4(0.f, 0.f, 0.f, 0.f) : b4;
     for (int y = 0; y < p.k_splits; ++y) {
       const float4 v = *reinterpret_cast<const float4*>(p.partial + ((int64_t)y * M + m) * p.n + n);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     float v[4] = {acc.x, acc.y, acc.z, acc.w};
-    if (p.rowstat) {
+    if (p.rowstat && !p.split) {   // split path: the LayerNorm went into the operand
       const float2 st = row_stats(p, m);
       const float4 cs = *reinterpret_cast<const float4*>(p.colsum + n);
       v[0] = st.y * (v[0] - st.x * cs.x) + b4.x;
@@ -949,12 +1014,12 @@ __global__ __launch_bounds__(256) void conv_gemm_finish_kernel(const ConvGemmPar
   }
 }
 
-template <typename T, int BM, int BN, int KB, bool ONE, int NST, bool TAPIN = false>
+template <typename T, int BM, int BN, int KB, bool ONE, int NST, bool TAPIN = false, bool SPLIT = false>
 inline void launch_conv_gemm_dma_v(const ConvGemmParams& p, const void* zero_page, hipStream_t stream) {
   constexpr int STAGES = NST * (BM + BN) * KB;
   constexpr int CT = BM * BN * (int)sizeof(T);
   constexpr int LDS = (STAGES > CT ? STAGES : CT) + 1024 + BM * 8;  // + epilogue parameter block
-  auto kern = conv_gemm_dma_kernel<T, BM, BN, KB, ONE, NST, TAPIN>;
+  auto kern = conv_gemm_dma_kernel<T, BM, BN, KB, ONE, NST, TAPIN, SPLIT>;
   static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -1010,6 +1075,15 @@ inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page,
   static const int deep_max = getenv("WX_GEMM_DEEP_TILES") ? atoi(getenv("WX_GEMM_DEEP_TILES")) : 0;
   const bool deep = KB == 128 && !three && !(p.dbg & 512) &&
                     (int64_t)cdiv(p.out_h * p.out_w, 128) * (p.n_par == 4 ? 4 : cdiv(p.n, BN)) * (p.partial ? p.k_splits : 1) <= deep_max;
+  if constexpr (sizeof(T) == 4 && KB == 128) {
+    if (p.split) {   // split-bf16 arithmetic (fp32 storage): the same three address forms on the 2-stage ring
+      if (one) launch_conv_gemm_dma_v<T, 128, BN, KB, true, 2, false, true>(p, zero_page, stream);
+      else if (p.cin * (int)sizeof(T) / KB >= 8) launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2, true, true>(p, zero_page, stream);
+      else launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2, false, true>(p, zero_page, stream);
+      return;
+    }
+  }
+  if (p.split) throw std::runtime_error("conv_gemm: split-bf16 arithmetic needs fp32 storage and 128-byte K steps");
   if (one) {
     if constexpr (KB == 64 && BN == 128 && sizeof(T) == 2) {
       if ((p.dbg & 512) && !p.gn_out) {  // experiment switch: 256-row tiles
@@ -1051,6 +1125,10 @@ inline void launch_conv_gemm(const ConvGemmParams& p, const void* zero_page, hip
     const int64_t tiles = (int64_t)cdiv(p.out_h * p.out_w, 128) * cdiv(p.n, p.n >= 96 ? 128 : 64);
     (void)ktot_bytes;
     bool kb64 = row_bytes % 128 != 0 || tiles >= 512;
+    if (p.split) {
+      if (row_bytes % 128 != 0) throw std::runtime_error("conv_gemm: split-bf16 arithmetic needs cin % 32 == 0");
+      kb64 = false;
+    }
     // k x k convolutions on big maps walk a deep K per tile (9 C / 16 C elements): there the longer K step wins although the launch has
     // tiles to spare (round 3, per class on C3: 3 x 3 at 80 000 / 320 000 rows 122 -> 109 / 121 -> 115 us, CrossEmbed k = 4 at 320 000 rows
     // 110 -> 89 us, merged ConvTranspose-k4 parity convs 261 -> 244 us; FuXi's 3 x 3 convs at 51 200 rows: forward 13.0 -> 11.9 ms).  Smaller
@@ -1061,7 +1139,7 @@ inline void launch_conv_gemm(const ConvGemmParams& p, const void* zero_page, hip
       if (row_bytes % 128 == 0 && ((taps >= 9 && p.stride == 1 && rows >= 50000) || (taps >= 4 && rows >= 200000))) kb64 = false;
     }
     if (gemm_cfg == 1 && row_bytes % 128 == 0) kb64 = false;
-    if (gemm_cfg == 2) kb64 = true;
+    if (gemm_cfg == 2 && !p.split) kb64 = true;
     if ((p.n >= 96 || (p.n_par == 4 && p.n > 64)) && gemm_cfg != 3) {   // merged parity convs need ONE N-tile per parity: 65..128 channels take BN = 128
       if (kb64) launch_conv_gemm_dma<T, 128, 64>(p, zero_page, stream);
       else launch_conv_gemm_dma<T, 128, 128>(p, zero_page, stream);

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("WX_LIBRARY") or os.path.join(_HERE, "libwxengine.so")
 
 WX_ABI_VERSION = 2
 ARCH = {"crossformer": 0, "wxformer": 1, "crossformer_upconv": 2}
-PREC = {"fp32": 0, "bf16": 1}
+PREC = {"fp32": 0, "bf16": 1, "fp32s": 2}   # fp32s: fp32 storage, split-bf16 GEMM arithmetic (WX_PREC_FP32_SPLIT)
 
 
 class wx_config(C.Structure):
@@ -87,6 +87,7 @@ _PROTOTYPES = {
     "wx_band_plan_partition": ([C.c_void_p, C.c_int, C.POINTER(C.c_int32)], C.c_int),
     "wx_set_debug": ([C.c_void_p, C.c_int], C.c_int),
     "wx_debug_read": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)], C.c_int),
+    "wx_query": ([C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)], C.c_int),
     "wx_profile": ([C.c_void_p, C.c_int], C.c_int),
     "wx_profile_reset": ([C.c_void_p], C.c_int),
     "wx_profile_read": ([C.c_void_p, C.POINTER(wx_kernel_stat), C.c_int, C.POINTER(C.c_int)], C.c_int),
@@ -387,6 +388,15 @@ class WXEngine:
         out = np.empty((shape[0], shape[1], shape[2]), dtype=np.float32)
         _check(self.lib.wx_debug_read(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, shape))
         return out
+
+    def query(self, key: str) -> int:
+        """One integer fact about the engine / its last forward (include/wxengine.h wx_query)."""
+        v = C.c_int64(0)
+        _check(self.lib.wx_query(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
+
+    def info(self) -> dict:
+        return {k: self.query(k) for k in ("two_stream_stages", "launches", "precision", "split_gemms")}
 
     def profile(self, on) -> None:
         """0 off, 1 per kernel class, 2 per kernel class and stage ("gemm_ff1.s2")."""

@@ -293,3 +293,26 @@ def test_attention_block_full_size():
     got, want = y[0, :, 0, ::s, ::s].numpy().astype(np.float64), g["y"].astype(np.float64)
     l2 = np.linalg.norm(got - want) / np.linalg.norm(want)
     assert l2 <= 2e-2 and np.abs(got - want).max() <= 5e-2 * np.abs(want).max(), f"rel-L2 {l2:.3e}"
+
+
+@pytest.mark.parametrize("name", ["T5", "C1", "C3"])
+def test_two_stream_half_maps_bit_identical(name):
+    """Round 5: the sub-block chains of the C >= 512 stages run as two half-maps of whole window rows on two streams (the caller's and an
+    engine-owned one, forked / joined by an event pair; wx_engine.hip stage_blocks_two_stream).  Every kernel is row-independent at
+    window-row granularity and a half runs the kernels and tiles the whole map would (rule_rows), so the step must be BIT-identical to
+    the one-stream schedule (WX_TWO_STREAM=0) -- on the headline model itself (C3: stage 2 = 5 + 5 window rows per short sub-block,
+    stage 3 = 3 + 2 window rows forked once) and, forced onto small maps with WX_STREAM_MIN_ROWS=0, on T5 (1 + 1 window rows at stage
+    2) and C1's stage 3 -- and bit-identical run to run (race screen: three forwards)."""
+    cfg = named_config(name)
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    force = {} if name == "C3" else {"WX_STREAM_MIN_ROWS": "0"}
+    two = _engine(name, "bf16", {**force, "WX_TWO_STREAM": "1"})
+    one = _engine(name, "bf16", {**force, "WX_TWO_STREAM": "0"})
+    y1 = _forward(one, x)
+    y2 = _forward(two, x)
+    assert torch.isfinite(y2).all()
+    assert torch.equal(y1, y2), f"{name}: two-stream step differs from the one-stream step (max {float((y1 - y2).abs().max()):.3e})"
+    for _ in range(3):
+        assert torch.equal(_forward(two, x), y2), f"{name}: two-stream step is not deterministic (race between the streams)"
+    # the schedule was actually taken: the engine reports its side stream
+    assert two.info().get("two_stream_stages", 0) >= 1 and one.info().get("two_stream_stages", 0) == 0
