@@ -69,7 +69,10 @@ struct EmbedPatchParams {
 #endif
 // NW waves share one patch: NW = 8 (512 threads, 2 waves per SIMD, 4 fragments each) lets one wave's LDS/L1
 // latency hide under its partner's MFMAs; NW = 4 (8 fragments each) halves the weight-fragment L1 traffic.
-template <typename T, int NW, int TH>
+// TO = element type of the output stream (round 5: the split-bf16 mode of the fp32 engine runs the bf16 instantiation over a
+// K-concatenated operand pair -- planes [x_hi | x_lo | x_hi] against weights [W_hi | W_hi | W_lo], i.e. hi.hi + lo.hi + hi.lo in
+// the one fp32 accumulator -- and stores fp32)
+template <typename T, int NW, int TH, typename TO = T>
 __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatchParams p, const char* __restrict__ zero_page) {
   constexpr int KS = 32, TW = 32;
   constexpr int PH = 2 * TH + KS - 2, PW = 2 * TW + KS - 2;
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
     return;
   }
   // ---- epilogue: + bias, 4 consecutive channels per lane, each 4-channel slot to the stream channel the table names ----------------------
-  T* __restrict__ orow = reinterpret_cast<T*>(p.out_row);
+  TO* __restrict__ orow = reinterpret_cast<TO*>(p.out_row);
   int sc[4];
   float4 bq[4];
 #pragma unroll
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
     for (int a = 0; a < 4; ++a) {
       if (sc[a] < 0) continue;
       float v[4] = {av[a][0] + bq[a].x, av[a][1] + bq[a].y, av[a][2] + bq[a].z, av[a][3] + bq[a].w};
-      store4<T>(orow + pix + sc[a], v);
+      store4<TO>(orow + pix + sc[a], v);
     }
   }
 }
@@ -345,12 +348,12 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const EmbedPatchParam
   store4<T>(reinterpret_cast<T*>(p.out_row) + pix * p.out_ld + ch, v);
 }
 
-template <typename T, int NW, int TH>
+template <typename T, int NW, int TH, typename TO = T>
 inline void launch_embed_patch_part(EmbedPatchParams p, int row0, int rows, const void* zero_page, hipStream_t stream) {
   constexpr int PH = 2 * TH + 30, PW = 2 * 32 + 30;
   constexpr int NT = NW * 64;
   constexpr int LDS = (((PH * PW) + NT - 1) / NT) * NT * 16;
-  auto kern = embed_patch_kernel<T, NW, TH>;
+  auto kern = embed_patch_kernel<T, NW, TH, TO>;
   static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -364,7 +367,7 @@ inline void launch_embed_patch_part(EmbedPatchParams p, int row0, int rows, cons
   WX_HIP(hipGetLastError());
   if (p.partial) {
     const int64_t work = (int64_t)p.part_rows * p.out_w * 16;
-    hipLaunchKernelGGL(embed_finish_kernel<T>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, stream, p, n_split);
+    hipLaunchKernelGGL(embed_finish_kernel<TO>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, stream, p, n_split);
     WX_HIP(hipGetLastError());
   }
 }
@@ -385,34 +388,34 @@ inline int embed_patch_tail_rows(int out_h, int out_w, int chunks, int n_cu = 25
   if (full_rounds < 1 || r1 >= tile_rows || rem <= 0 || cdiv(rem, 8) * tiles_x > n_cu) return 0;
   return 2 * cdiv(rem, 16) * tiles_x <= n_cu ? rem : 0;
 }
-template <typename T>
+template <typename T, typename TO = T>
 inline void launch_embed_patch(const EmbedPatchParams& p, const void* zero_page, hipStream_t stream, int n_cu = 256) {
-  if (p.dbg & 256) { EmbedPatchParams q = p; q.partial = nullptr; launch_embed_patch_part<T, 4, 16>(q, 0, p.out_h, zero_page, stream); return; }  // A/B switch
+  if (p.dbg & 256) { EmbedPatchParams q = p; q.partial = nullptr; launch_embed_patch_part<T, 4, 16, TO>(q, 0, p.out_h, zero_page, stream); return; }  // A/B switch
   const int tiles_x = cdiv(p.out_w, 32), tile_rows = cdiv(p.out_h, 16);
   if (!(p.dbg & 8192) && tile_rows * tiles_x < n_cu / 2) {
     // small maps (1 degree: 120 x 192 outputs = 48 tiles of 16 rows on 256 CUs): more, smaller tiles
     // 8-row tiles of 4 waves (two rows per wave, vertical fragment reuse): 46 staged patch rows for 8 output rows instead of 38 for 4.
     // 1-degree model, with the caller's four-way chunk split: 122 us against 190 us for the 4-row tiles (8 waves x 8 rows: 180, 4 x 16: 189).
-    launch_embed_patch_part<T, 4, 8>(p, 0, p.out_h, zero_page, stream);   // p.partial set by the caller: chunk split on top
+    launch_embed_patch_part<T, 4, 8, TO>(p, 0, p.out_h, zero_page, stream);   // p.partial set by the caller: chunk split on top
     return;
   }
-  if (p.partial) { EmbedPatchParams q = p; q.partial = nullptr; launch_embed_patch<T>(q, zero_page, stream, n_cu); return; }
+  if (p.partial) { EmbedPatchParams q = p; q.partial = nullptr; launch_embed_patch<T, TO>(q, zero_page, stream, n_cu); return; }
   const int full_rounds = (tile_rows * tiles_x) / n_cu;
   const int r1 = (full_rounds * n_cu) / tiles_x;            // tile rows that fill whole rounds
   const int rem = p.out_h - 16 * r1;
   if (!(p.dbg & 8192) && full_rounds >= 1 && r1 < tile_rows && rem > 0 && cdiv(rem, 8) * tiles_x <= n_cu) {
-    launch_embed_patch_part<T, 8, 16>(p, 0, 16 * r1, zero_page, stream);
+    launch_embed_patch_part<T, 8, 16, TO>(p, 0, 16 * r1, zero_page, stream);
     if (p.tail_partial && embed_patch_tail_rows(p.out_h, p.out_w, p.cpad / (16 / (int)sizeof(T)), n_cu) == rem) {
       // the tail as 16-row tiles over HALF the channel chunks each (one round of <= 256 workgroups) + the fixed-order finish
       EmbedPatchParams q = p;
       q.partial = p.tail_partial;
       q.chunk_per = cdiv(p.cpad / (16 / (int)sizeof(T)), 2);
-      launch_embed_patch_part<T, 8, 16>(q, 16 * r1, rem, zero_page, stream);
+      launch_embed_patch_part<T, 8, 16, TO>(q, 16 * r1, rem, zero_page, stream);
       return;
     }
-    launch_embed_patch_part<T, WX_EMBED_TAIL_NW, 8>(p, 16 * r1, rem, zero_page, stream);
+    launch_embed_patch_part<T, WX_EMBED_TAIL_NW, 8, TO>(p, 16 * r1, rem, zero_page, stream);
   } else {
-    launch_embed_patch_part<T, 8, 16>(p, 0, p.out_h, zero_page, stream);
+    launch_embed_patch_part<T, 8, 16, TO>(p, 0, p.out_h, zero_page, stream);
   }
 }
 

@@ -61,7 +61,7 @@ struct ConvW {          // one repacked GEMM operand in the weight arena
 struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1, bias_tb = -1; int wsz = 0, kind = 0; };
 struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1, pack_pp = -1; const AttnL* next = nullptr; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset; pack_pre: the same preceded by the attention's Wout blocks
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
-struct PatchW { int64_t wt = -1, bias = -1; int n = 0; };  // LDS-patch CrossEmbed branch (wx_embed.h)
+struct PatchW { int64_t wt = -1, bias = -1, wt16 = -1; int n = 0; };   // wt16: split-bf16 mode, offset in the 16-bit patch arena  // LDS-patch CrossEmbed branch (wx_embed.h)
 struct StageL {
   std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks;
   bool ride4 = false;                            // stage 0: the k = 4 branch rides in the LDS-patch kernel's spare accumulator rows
@@ -553,8 +553,30 @@ class Engine : public EngineBase {
   // `extra`: channels [x0, x0 + xn) of the smaller kernel `xkey` (size xk) as accumulator rows n .. n + xn - 1, their taps zero-padded
   // into the middle of this k x k window (same centre: crossformer.py:128-152 padding (k - stride) / 2) -- see EmbedPatchParams::slot_tab
   PatchW make_patch(const std::string& p, int n, int cin, int cpad, int k, const std::string& xkey = "", int xk = 0, int x0 = 0, int xn = 0) {
+    PatchW pw;
+    pw.n = n;
+    if (split_mma) {
+      // split-bf16 mode: the bf16 instantiation of the patch kernel over the K-concatenated operand pair -- weights [W_hi | W_hi | W_lo]
+      // against planes [x_hi | x_lo | x_hi] (pack_input): 3 x cpad / 8 chunks of the bf16 layout, in their own 16-bit arena
+      const std::vector<double> r8 = patch_rows(p, n, cin, cpad, k, 8, xkey, xk, x0, xn);
+      while (sp16_host.size() % 8) sp16_host.push_back(0);
+      pw.wt16 = (int64_t)sp16_host.size();
+      sp16_host.resize(sp16_host.size() + 3 * r8.size());
+      uint16_t* d = sp16_host.data() + pw.wt16;
+      for (size_t i = 0; i < r8.size(); ++i) {
+        const float w = (float)r8[i];
+        const bf16_t hi = f2bf(w), lo = f2bf(w - bf2f(hi));
+        d[i] = hi; d[r8.size() + i] = hi; d[2 * r8.size() + i] = lo;
+      }
+    }
+    const std::vector<double> rows = patch_rows(p, n, cin, cpad, k, 16 / (int)sizeof(T), xkey, xk, x0, xn);
+    pw.wt = push_w(rows, 1, (int64_t)rows.size());
+    return pw;
+  }
+  std::vector<uint16_t> sp16_host;   // split_mma: bf16 patch weights (make_patch)
+  uint16_t* sp16_dev = nullptr;
+  std::vector<double> patch_rows(const std::string& p, int n, int cin, int cpad, int k, int CC, const std::string& xkey, int xk, int x0, int xn) {
     const std::vector<double> w = folded(p, false);
-    constexpr int CC = 16 / (int)sizeof(T);
     const int chunks = cpad / CC, k4n = k / 4, nfr = (k == 8) ? 2 : 1;  // fragment counts the kernel is built for
     std::vector<double> rows((size_t)chunks * k * k4n * nfr * 64 * CC, 0.0);
     auto at = [&](int ch, int ky, int kx, int o, int e) -> double& {
@@ -580,10 +602,7 @@ class Engine : public EngineBase {
                 if (c < cin) at(ch, ky + d, kx + d, n + o, e) = wx[(((int64_t)(x0 + o) * cin + c) * xk + ky) * xk + kx];
               }
     }
-    PatchW pw;
-    pw.n = n;
-    pw.wt = push_w(rows, 1, (int64_t)rows.size());
-    return pw;
+    return rows;
   }
   // ConvTranspose2d k2 s2: W[ci][co][dy][dx] -> rows n = (dy*2+dx)*cout + co, K = ci; bias expanded x4
   ConvW make_convt2(const std::string& p, int cin, int cout) {
@@ -930,6 +949,11 @@ class Engine : public EngineBase {
         if (ws_dev) { (void)hipFree(ws_dev); allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)ws_dev)); ws_dev = nullptr; }
         ws_dev = (T*)dalloc(sp.size() * sizeof(uint16_t) + 256);
         WX_HIP(hipMemcpy(ws_dev, sp.data(), sp.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        if (!sp16_host.empty()) {
+          sp16_dev = (uint16_t*)dalloc(sp16_host.size() * sizeof(uint16_t) + 256);
+          WX_HIP(hipMemcpy(sp16_dev, sp16_host.data(), sp16_host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+          std::vector<uint16_t>().swap(sp16_host);
+        }
       }
     }
     std::vector<T>().swap(wt_host);
@@ -946,6 +970,7 @@ class Engine : public EngineBase {
     return p;
   }
   T* ws_dev = nullptr;       // split_mma: the weight arena re-encoded as bf16 (hi, lo) fragments, same offsets as wt_dev
+  char* xs_planes = nullptr; // split_mma: the packed input as bf16 planes [x_hi | x_lo | x_hi] (PackParams::split_planar)
   T* xin = nullptr;          // packed, halo'd input
   T* xin_planar = nullptr;   // chunk-planar copy for the LDS-patch CrossEmbed kernel (wx_embed.h)
   T* cat[3] = {nullptr, nullptr, nullptr};   // [HW_s][2*C_s]: [up-block output | encoder stream]
@@ -1050,6 +1075,10 @@ class Engine : public EngineBase {
     if (use_patch && planar_xin) {
       xin_planar = (T*)dalloc(xin_elems * sizeof(T));
       WX_HIP(hipMemset(xin_planar, 0, xin_elems * sizeof(T)));
+    }
+    if (split_mma && use_patch && sp16_dev) {
+      xs_planes = (char*)dalloc((size_t)xin_elems * 2 * 3);
+      WX_HIP(hipMemset(xs_planes, 0, (size_t)xin_elems * 2 * 3));
     }
     int64_t max_sc = 0, max_ao = 0, max_hw = 0;
     for (int s = 0; s < 4; ++s) {
@@ -1739,6 +1768,7 @@ class Engine : public EngineBase {
     p.halo = halo; p.cpad = cpad0; p.dst_planar = dst_planar; p.Hb = Hb;
     p.row0 = row0; p.src_row0 = src_row0; p.src_rows = src_rows; p.dst_row = dst_row;
     p.mirror = cfg.pad_activate == 2;
+    p.split_planar = (split_mma && dst == xin && xs_planes) ? xs_planes : nullptr;
     if (nrows <= 0) return;
     timed("pack_input", 0.0, (double)C_in * nrows * cfg.image_width * 4.0 + (double)nrows * Wp * cpad0 * sizeof(T), [&] {
       hipLaunchKernelGGL(pack_input_kernel<T>, dim3(cdiv(Wp, 64), nrows), dim3(256), 0, cur_stream, p);
@@ -1821,7 +1851,24 @@ class Engine : public EngineBase {
             ep.tail_partial = embed_tail;
           }
         }
+        const bool split_patch = split_mma && xs_planes && in == xin && !dbg_flags;
+        if (split_patch) {   // the bf16 kernel over the K-concatenated (hi, lo) operands, fp32 out
+          ep.xin = nullptr; ep.xin_planar = xs_planes; ep.cpad = 3 * cpad0;
+          ep.wt32 = ep.wt16 = ep.wt8 = nullptr;
+          for (size_t j = 0; j < st.embed.size(); ++j) {
+            const PatchW& pw = st.patch[j];
+            if (pw.wt16 < 0) continue;
+            if (st.embed_k[j] == 32) ep.wt32 = sp16_dev + pw.wt16;
+            if (st.embed_k[j] == 16) ep.wt16 = sp16_dev + pw.wt16;
+            if (st.embed_k[j] == 8) ep.wt8 = sp16_dev + pw.wt16;
+          }
+          if (ep.chunk_per) ep.chunk_per = cdiv(3 * cpad0 / 8, embed_split_ways);
+          ++n_split_gemms;
+        }
         timed("embed_patch", fl, (double)(in_h * Wp) * cpad0 * sizeof(T) + (double)sh[0] * sw[0] * 64 * sizeof(T), [&] {
+          if constexpr (sizeof(T) == 4) {
+            if (split_patch) { launch_embed_patch<bf16_t, float>(ep, zero_page, cur_stream); return; }
+          }
           launch_embed_patch<T>(ep, zero_page, cur_stream);
         });
       } else if (s == 0)
@@ -2139,6 +2186,7 @@ class Engine : public EngineBase {
       throw ConfigError("lat-band mode: the upsample_v_conv decoder variant is not wired (crossformer and wxformer are)");
     if (e.cfg.frames != 1 || e.cfg.output_frames != 1) throw ConfigError("lat-band mode needs frames == output_frames == 1");
     if (e.cfg.dim_head != 32) throw ConfigError("lat-band mode needs dim_head == 32");
+    if (e.split_mma) throw ConfigError("lat-band mode: the split-bf16 precision is not wired (fp32 and bf16 are)");
   }
 
   void band_enable(int rank, int n) override {

@@ -413,15 +413,18 @@ template <typename T, int BM, int BN, int KB, bool ONE, int NST, bool TAPIN, boo
 __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : ((KB == 64 && sizeof(T) == 2) ? (NST == 2 ? 4 : 3) : 2)) void conv_gemm_dma_kernel(
     const ConvGemmParams p, const char* __restrict__ zero_page) {
   static_assert(!SPLIT || (sizeof(T) == 4 && KB == 128), "split-bf16 arithmetic: fp32 storage, 32-float K steps");
-  constexpr int WMR = 64;               // rows (pixels) per wave
+  // SPLIT: 4 x 1 waves of 32 pixels x BN channels instead of 2 x 2 of 64 x BN/2 -- a wave then splits only its own activation
+  // fragments (2 per K step instead of 4, each needed by no other wave: half the conversion VALU per MFMA)
+  constexpr int WMR = SPLIT ? 32 : 64;  // rows (pixels) per wave
   constexpr int WAVES_M = BM / WMR;     // 2 or 4
-  constexpr int NW = WAVES_M * 2;       // waves per workgroup
+  constexpr int WAVES_N = SPLIT ? 1 : 2;
+  constexpr int NW = WAVES_M * WAVES_N; // waves per workgroup
   constexpr int NT = NW * 64;
   constexpr int BKE = KB / (int)sizeof(T);
   constexpr int PPR = KB / 16;          // 16-byte slots per staged row
   constexpr int RPI = 64 / PPR;         // rows moved by one DMA wave-instruction
   constexpr int SUBS = KB / 64;
-  constexpr int WN = BN / 2;            // 2x2 waves, wave tile 64 pixels x WN channels
+  constexpr int WN = BN / WAVES_N;      // 2x2 waves, wave tile 64 pixels x WN channels
   constexpr int FM = WMR / 16, FN = WN / 16;
   constexpr int A_I = BM / (NW * RPI);  // DMA instructions per wave per K step (activations / weights)
   constexpr int B_I = BN / (NW * RPI);

@@ -162,14 +162,15 @@ def test_wx_rollout_argument_errors():
 BF16_BOUND = 2e-2           # the single-step bf16 bar of tests/test_engine_gpu.py, held at every step of the rollout
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])
 @pytest.mark.parametrize("name", ["C1", "C3S", "C3"])
 def test_full_length_rollout_vs_reference_trajectory(name, prec):
     """C1: BASELINE config 2 (24 steps on the 1-degree grid).  C3S: 8 steps on the 0.25-degree grid (721 x 1440, the small-width
     model of credit_smoke_test_v2_025deg.yml) -- reference trajectory only: torch's fp64 CPU convolution of the k = 32 CrossEmbed
     branch needs 157 GB at that size, so the fp64 floor of that fixture is NaN and the fp32 gate is 1e-4 * t alone.  C3: the HEADLINE
-    workload itself -- 6 steps of the full-width 124 M-parameter model of wxformer_era5_025deg_6hr.yml (BASELINE config 3), reference
-    fp32 trajectory (about 40 s of CPU per step to generate)."""
+    workload itself -- ALL 40 steps of BASELINE config 3 (round 5; rounds 2-4 held 6) of the full-width 124 M-parameter model of
+    wxformer_era5_025deg_6hr.yml, reference fp32 trajectory (about 50 s of CPU per step to generate; strided samples, 5.9 MB).
+    fp32s = the split-bf16 mode (fp32 storage, three bf16 MFMAs per product): held to the fp32 bound."""
     path = os.path.join(GOLD, f"rollout_{name}.npz")
     if not os.path.isfile(path):
         pytest.skip(f"tests/golden/rollout_{name}.npz not generated (tools/make_goldens.py --only roll{name})")
@@ -183,7 +184,8 @@ def test_full_length_rollout_vs_reference_trajectory(name, prec):
         y, _, xn = eng.step(x, frcs[t], want_phys=False)
         ys.append(y[0, :, 0, ::s, ::s].cpu().numpy().astype(np.float64))
         x = xn
-    ref, o64, floor = g["y"].astype(np.float64), g["y64"].astype(np.float64), g["ref_vs_fp64_rel_l2"]
+    ref, floor = g["y"].astype(np.float64), g["ref_vs_fp64_rel_l2"]
+    o64 = g["y64"].astype(np.float64) if g["y64"].size else ref      # no fp64 trajectory at this size: the reference alone
     rel = [float(np.linalg.norm(ys[t] - ref[t]) / np.linalg.norm(ref[t])) for t in range(n)]
     rel64 = [float(np.linalg.norm(ys[t] - o64[t]) / np.linalg.norm(o64[t])) for t in range(n)]
     print(f"\n{prec} engine, {name}, {n}-step rollout: rel-L2 per step vs the reference trajectory | vs the fp64 oracle | reference vs fp64")
@@ -191,14 +193,14 @@ def test_full_length_rollout_vs_reference_trajectory(name, prec):
         print(f"  t={t + 1:2d}  {rel[t]:.3e}  {rel64[t]:.3e}  {floor[t]:.3e}")
     assert all(np.isfinite(v) for v in rel)
     for t in range(n):
-        if prec == "fp32":
+        if prec in ("fp32", "fp32s"):
             bound = 1e-4 * (t + 1) if np.isnan(floor[t]) else max(1e-4 * (t + 1), 4.0 * floor[t])
-            assert rel[t] <= bound, f"fp32 step {t + 1}: {rel[t]:.3e} (bound {bound:.3e})"
+            assert rel[t] <= bound, f"{prec} step {t + 1}: {rel[t]:.3e} (bound {bound:.3e})"
         else:
             assert rel[t] <= BF16_BOUND, f"bf16 step {t + 1}: rel-L2 {rel[t]:.3e}"
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])
 def test_stress_family_rollout_vs_reference_trajectory(prec):
     """8 autoregressive steps of the 1-degree model on the "stress" weight family (attention logits +-40, pre-GELU 1e2; wxengine/synth.py
     FAMILIES) against the reference's own loop (tools/make_goldens.py --only rollC1stress).  This family amplifies a perturbation by
@@ -220,8 +222,8 @@ def test_stress_family_rollout_vs_reference_trajectory(prec):
         rel = float(np.linalg.norm(yt - ref[t]) / np.linalg.norm(ref[t]))
         print(f"  t={t + 1:2d}  {rel:.3e}  {floor[t]:.3e}  {ac[t]:.3e}")
         assert np.isfinite(rel)
-        if prec == "fp32":
+        if prec in ("fp32", "fp32s"):
             bound = max(1e-4 * (t + 1), 8.0 * floor[t])
-            assert rel <= bound, f"fp32 step {t + 1}: {rel:.3e} (bound {bound:.3e})"
+            assert rel <= bound, f"{prec} step {t + 1}: {rel:.3e} (bound {bound:.3e})"
         else:
             assert rel <= ac[t], f"bf16 step {t + 1}: rel-L2 {rel:.3e} above the reference's own bf16-autocast error {ac[t]:.3e}"
