@@ -43,7 +43,16 @@ def main():
         fam[family(k)]["fetch_kb"] += v
     for k, (n, v) in write.items():
         fam[family(k)]["write_kb"] += v
-    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 "
+    # the library these counters belong to: bench.py prints `traffic: null` + a stale note when the library it loaded has another hash
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miles-credit_amd"))
+    try:
+        import build as wx_build
+        wxsrc = wx_build.built_hash()
+    except Exception:
+        wxsrc = None
+    out = {"wxsrc": wxsrc,
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 "
                      "--warmup 1 --no-cpu-baseline --no-roofline",
            "corrections": "FETCH_SIZE x2 on gfx950 (128-byte requests tallied as 64 B); WRITE_SIZE uncalibrated; KB -> bytes x1024",
            "kernels": {}}
