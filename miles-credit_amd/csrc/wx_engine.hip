@@ -3035,6 +3035,7 @@ int wx_band_plan_create(const wx_config* cfg, int nranks, wx_band_plan* out) {
     if (!cfg || !out) throw wx::ConfigError("wx_band_plan_create: null argument");
     if (nranks < 1) throw wx::ConfigError("wx_band_plan_create: nranks must be >= 1");
     std::unique_ptr<wx_band_plan_s> p(new wx_band_plan_s);
+    if (cfg->precision == WX_PREC_FP32_SPLIT) throw wx::ConfigError("lat-band mode: the split-bf16 precision is not wired (fp32 and bf16 are)");
     if (cfg->precision == WX_PREC_FP32) {
       wx::Engine<float> e(*cfg, -1);
       wx::Engine<float>::band_check_supported(e);
