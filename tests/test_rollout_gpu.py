@@ -38,7 +38,7 @@ def make_engine(name, prec, tracer=None, denorm=False, family="base"):
     return cfg, eng
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])
 @pytest.mark.parametrize("name", ["T0", "T1"])
 @pytest.mark.parametrize("graph", ["0", "1"])
 def test_wx_rollout_is_bit_identical_to_a_loop_of_wx_step(name, prec, graph, monkeypatch):
@@ -114,7 +114,7 @@ def test_captured_step_graphs_are_dropped_when_the_step_glue_changes(monkeypatch
     assert all(torch.equal(a, b) for a, b in zip(outs, want)) and torch.equal(xf, xl)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])
 def test_step_outputs_at_addresses_that_are_not_16_byte_aligned(prec):
     """ADVICE round 2 (tail alignment): a raw C-ABI caller may hand wx_step output pointers that are only 4-byte aligned (an offset view
     of a larger allocation); the tail kernel's 16-byte store path must not be taken then.  Same bits as with aligned outputs."""

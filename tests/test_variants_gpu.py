@@ -40,7 +40,7 @@ def _forward(eng, x):
     return eng.forward(x).clone()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])
 def test_split_variants_match_unsplit(prec):
     cfg = named_config("C1")
     x = torch.from_numpy(synth_input(cfg)).cuda()
@@ -50,15 +50,15 @@ def test_split_variants_match_unsplit(prec):
     assert torch.equal(y_on, y_on2), "the split launches must be deterministic (fixed summation order)"
     scale = float(y_off.abs().max())
     err = float((y_on - y_off).abs().max())
-    if prec == "fp32":
-        assert err <= 2e-5 * scale, f"split vs unsplit (fp32): {err:.3e} of {scale:.3e}"
+    if prec in ("fp32", "fp32s"):
+        assert err <= 2e-5 * scale, f"split vs unsplit ({prec}): {err:.3e} of {scale:.3e}"
     else:
         l2 = float(torch.linalg.norm((y_on - y_off).double()) / torch.linalg.norm(y_off.double()))
         assert l2 <= 1e-2, f"split vs unsplit (bf16) rel-L2 {l2:.3e}"
-    assert not torch.equal(y_on, y_off) or prec == "fp32", "the variants should actually differ in summation order (is the split taken?)"
+    assert not torch.equal(y_on, y_off) or prec in ("fp32", "fp32s"), "the variants should actually differ in summation order (is the split taken?)"
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])
 def test_merged_parity_convs_bit_identical(prec):
     cfg = named_config("C1")   # type: crossformer -> ConvTranspose k4 s2 p1 as the last up-block
     x = torch.from_numpy(synth_input(cfg)).cuda()
@@ -67,7 +67,7 @@ def test_merged_parity_convs_bit_identical(prec):
     assert torch.equal(_forward(merged, x), _forward(separate, x))
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])
 def test_launch_count_reducers_on_small_maps(prec):
     """1-degree grid (launch-bound: ~5 us of dispatch floor per kernel): (a) one convolution per CrossEmbed of stages 1-3, the k = 2
     branch zero-padded into the k = 4 window; (b) the stage-0 k = 4 branch in the spare accumulator rows of the LDS-patch kernel;
@@ -82,9 +82,9 @@ def test_launch_count_reducers_on_small_maps(prec):
     y_on, y_on2, y_off = _forward(on, x), _forward(on, x), _forward(off, x)
     assert torch.equal(y_on, y_on2)
     scale = float(y_off.abs().max())
-    if prec == "fp32":
+    if prec in ("fp32", "fp32s"):
         err = float((y_on - y_off).abs().max())
-        assert err <= 2e-5 * scale, f"reducers on vs off (fp32): {err:.3e} of {scale:.3e}"
+        assert err <= 2e-5 * scale, f"reducers on vs off ({prec}): {err:.3e} of {scale:.3e}"
     else:
         l2 = float(torch.linalg.norm((y_on - y_off).double()) / torch.linalg.norm(y_off.double()))
         assert l2 <= 1e-2, f"reducers on vs off (bf16) rel-L2 {l2:.3e}"
