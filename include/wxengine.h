@@ -385,7 +385,7 @@ typedef struct wx_kernel_stat {
  /* wx_query: one integer fact about the engine / its LAST forward, by name -- which schedule and precision variant actually ran (what a
  * parity test needs to prove it exercised the path it names; the reference has no counterpart: its "schedule" is ATen's).  Keys:
  *   "two_stream_stages"  stages of the last forward whose sub-block chains ran as two half-maps on two streams (round 5)
- *   "launches"           kernel launches of the last forward (counted when wx_profile is on, else -1)
+ *   "launches"           kernel launches of the last forward
  *   "precision"          the wx_config precision the engine was created with
  *   "split_gemms"        GEMM launches of the last forward that ran split-bf16 arithmetic (WX_PREC_FP32_SPLIT)
  * Unknown key -> WX_ERR_INVALID. */

@@ -59,6 +59,8 @@ struct EmbedPatchParams {
   // big maps: the last, partly filled round of 16-row tiles (0.25 degrees: 125 of 625 tiles) is launched with a two-way chunk split
   // instead of as 8-row tiles -- tail_partial = a buffer of 2 x tail rows x out_w x 64 floats, or nullptr (launch_embed_patch)
   float* tail_partial;
+  int plane_wrap;      // > 0 (planar input only): channel chunk ch >= plane_wrap reads plane ch - plane_wrap -- the split-bf16 mode's
+                       // K-concatenation [x_hi | x_lo | x_hi] over two stored plane groups
 };
 
 #ifndef WX_EMBED_TAIL_NW
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, 1) void embed_patch_kernel(const EmbedPatc
         const int by = by0 + py, bx = bx0 + px;
         const bool ok = idx < NPIX && by >= 0 && by < p.Hb && bx >= 0 && bx < p.Wb;
         const char* src = !ok ? zero_page
-                          : planar ? planar + (((int64_t)ch * p.Hb + by) * p.Wb + bx) * 16
+                          : planar ? planar + (((int64_t)(p.plane_wrap > 0 && ch >= p.plane_wrap ? ch - p.plane_wrap : ch) * p.Hb + by) * p.Wb + bx) * 16
                                    : xin + ((int64_t)by * p.Wb + bx) * pix_bytes + ch * 16;
         lds_dma16(src, smem + (it * NT + wave * 64) * 16);
       }

@@ -970,7 +970,8 @@ class Engine : public EngineBase {
     return p;
   }
   T* ws_dev = nullptr;       // split_mma: the weight arena re-encoded as bf16 (hi, lo) fragments, same offsets as wt_dev
-  char* xs_planes = nullptr; // split_mma: the packed input as bf16 planes [x_hi | x_lo | x_hi] (PackParams::split_planar)
+  char* xs_planes = nullptr; // split_mma: the packed input as bf16 planes [x_hi | x_lo] (PackParams::split_planar); the patch kernel's third
+                             // chunk group wraps around to x_hi (EmbedPatchParams::plane_wrap)
   T* xin = nullptr;          // packed, halo'd input
   T* xin_planar = nullptr;   // chunk-planar copy for the LDS-patch CrossEmbed kernel (wx_embed.h)
   T* cat[3] = {nullptr, nullptr, nullptr};   // [HW_s][2*C_s]: [up-block output | encoder stream]
@@ -1072,13 +1073,12 @@ class Engine : public EngineBase {
     const int64_t xin_elems = (int64_t)(Hp + 2 * halo + 2) * (Wp + 2 * halo + 2) * cpad0;
     xin = (T*)dalloc(xin_elems * sizeof(T));
     WX_HIP(hipMemset(xin, 0, xin_elems * sizeof(T)));
-    if (use_patch && planar_xin) {
+    if (split_mma && use_patch && sp16_dev) {   // the patch kernel reads the bf16 (hi, lo) planes: no fp32 planar copy in this mode
+      xs_planes = (char*)dalloc((size_t)xin_elems * 2 * 2);
+      WX_HIP(hipMemset(xs_planes, 0, (size_t)xin_elems * 2 * 2));
+    } else if (use_patch && planar_xin) {
       xin_planar = (T*)dalloc(xin_elems * sizeof(T));
       WX_HIP(hipMemset(xin_planar, 0, xin_elems * sizeof(T)));
-    }
-    if (split_mma && use_patch && sp16_dev) {
-      xs_planes = (char*)dalloc((size_t)xin_elems * 2 * 3);
-      WX_HIP(hipMemset(xs_planes, 0, (size_t)xin_elems * 2 * 3));
     }
     int64_t max_sc = 0, max_ao = 0, max_hw = 0;
     for (int s = 0; s < 4; ++s) {
@@ -1253,9 +1253,10 @@ class Engine : public EngineBase {
   void profile(int on) override { prof_on = on != 0; detail_on = on > 1; family_on = on > 2; }
   int64_t n_two_stream_stages = 0;   // of the last forward
   int64_t n_split_gemms = 0;         // GEMM launches of the last forward that ran split-bf16 arithmetic
+  int64_t n_launches = 0;            // timed() calls of the last forward (one per kernel launch or launch + finish pair)
   bool query(const std::string& key, int64_t* v) override {
     if (key == "two_stream_stages") { *v = n_two_stream_stages; return true; }
-    if (key == "launches") { *v = prof_on ? (int64_t)pending.size() : -1; return true; }
+    if (key == "launches") { *v = n_launches; return true; }
     if (key == "precision") { *v = sizeof(T) == 2 ? WX_PREC_BF16 : (split_mma ? WX_PREC_FP32_SPLIT : WX_PREC_FP32); return true; }
     if (key == "split_gemms") { *v = n_split_gemms; return true; }
     return false;
@@ -1288,6 +1289,7 @@ class Engine : public EngineBase {
   }
   template <typename F>
   void timed(const char* name, double flops, double bytes, F&& fn) {
+    ++n_launches;
     if (!prof_on) { cur_family = nullptr; fn(); return; }
     const int idx = (int)pending.size();
     while ((int)ev_pool.size() <= idx) {
@@ -1853,7 +1855,7 @@ class Engine : public EngineBase {
         }
         const bool split_patch = split_mma && xs_planes && in == xin && !dbg_flags;
         if (split_patch) {   // the bf16 kernel over the K-concatenated (hi, lo) operands, fp32 out
-          ep.xin = nullptr; ep.xin_planar = xs_planes; ep.cpad = 3 * cpad0;
+          ep.xin = nullptr; ep.xin_planar = xs_planes; ep.cpad = 3 * cpad0; ep.plane_wrap = 2 * cpad0 / 8;   // chunks [2n, 3n) re-read the x_hi planes
           ep.wt32 = ep.wt16 = ep.wt8 = nullptr;
           for (size_t j = 0; j < st.embed.size(); ++j) {
             const PatchW& pw = st.patch[j];
@@ -1935,6 +1937,10 @@ class Engine : public EngineBase {
     const StageL& st = stages[s];
     side_ensure();
     hipStream_t main_s = cur_stream;
+    struct Restore {   // a throw inside a half must not leave the engine on the side stream / inside a row window
+      Engine* e; hipStream_t s;
+      ~Restore() { e->rw0 = 0; e->rwn = -1; e->rule_rows = 0; e->cur_stream = s; }
+    } restore{this, main_s};
     const int wsz = st.blocks[0].sa.wsz, wr = sh[s] / wsz;
     const int rows_a = (wr - wr / 2) * wsz, rows_b = sh[s] - rows_a;   // the caller's stream takes the larger half
     const bool pointwise_long = st.blocks[0].la.wsz == 1;
@@ -2008,6 +2014,7 @@ class Engine : public EngineBase {
   void core(const float* x_item) {
     n_two_stream_stages = 0;
     n_split_gemms = 0;
+    n_launches = 0;
     // a1: pack + earth halo
     pack_input(x_item, xin, xin_planar, Hp + 2 * halo, 0, Hp, halo, 0, cfg.image_height);
     capture("pad", xin + ((int64_t)halo * (Wp + 2 * halo) + halo) * cpad0, Hp, Wp, C_in, cpad0, Wp + 2 * halo);
