@@ -40,6 +40,7 @@ struct AttnParams {
                                   // multiplied by logit_scale[head] (already clamped / exponentiated, x log2 e for bf16)
   float scale;                    // bf16 engine: scale * log2(e), and the bias table is pre-multiplied by log2(e)
   unsigned long long* trace;      // tools/attn_probe only (WX_ATTN_TRACE builds): [tasks][8] phase ticks
+  int mma3 = 0;                   // T = float, != 0 (round 5, WX_PREC_FP32_SPLIT): the M3 instantiations -- Q.K^T and P.V as split-bf16 arithmetic
   int pack;                       // windows per 16-token tile (1, or 16 / wsz^2 for the 2x2 windows of the long
                                   // attention at stage 2: four windows share one MFMA tile, the bias table is
                                   // block-diagonal with -1e30 between windows)
@@ -115,6 +116,17 @@ __device__ __forceinline__ void attn_lds_barrier() { asm volatile("s_waitcnt lgk
 #ifndef WX_ATTN_MFMA_SOFTMAX
 #define WX_ATTN_MFMA_SOFTMAX 1   // bf16: max subtraction and row sum on the matrix pipe (see the query loop)
 #endif
+// two 16-byte fragments of fp32 (4 + 4 values) -> (hi, lo) bf16 fragments of the same 8 values, in place (wx_gemm.h split_bf16x8)
+__device__ __forceinline__ void attn_split_pair(uint4& a, uint4& b) {
+  const float v[8] = {__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, a.y), __builtin_bit_cast(float, a.z), __builtin_bit_cast(float, a.w),
+                      __builtin_bit_cast(float, b.x), __builtin_bit_cast(float, b.y), __builtin_bit_cast(float, b.z), __builtin_bit_cast(float, b.w)};
+  split_bf16x8(v, a, b);
+}
+__device__ __forceinline__ f32x4_t attn_mma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x4_t acc) {
+  acc = mma_sub<bf16_t>(al, bh, acc);
+  acc = mma_sub<bf16_t>(ah, bl, acc);
+  return mma_sub<bf16_t>(ah, bh, acc);
+}
 constexpr int attn_min_waves(int nkf, int dh, int elem, bool sw) {
   return (elem == 2 && nkf <= 8 && dh <= 32) ? ((sw || WX_ATTN_PAIR) && nkf >= 7 ? 3 : WX_ATTN_MINW) : 1;   // the Swin-mode extras spill at 128 registers
 }
@@ -129,8 +141,13 @@ constexpr int attn_min_waves(int nkf, int dh, int elem, bool sw) {
 // table), so a fragment's bias is one subtraction + one ds_read_b128 straight into the MFMA accumulator instead of a ds_read_b128
 // of four offsets + four subtractions + four ds_read_b32; the block's table offset is loop-invariant (7 registers per lane).  The
 // bias gather was 63 of the ~260 instructions of a 16-query block; it is 14 (+ 4 selects for the padded key blocks).
-template <typename T, int NKF, bool SPLIT, bool BT, int DH = 32, bool SW = false, int B2W = 0>
+// M3 (round 5; T = float, the split-bf16 precision): Q.K^T and P.V on v_mfma_f32_16x16x32_bf16 -- pairs of 16-byte fp32 fragments (8 values
+// per lane) become (hi, lo) bf16 fragments IN the registers they were loaded into (K, V^T: once per task; Q, P: per query block), three
+// MFMAs per product instead of eight v_mfma_f32_16x16x4_f32, 2^x by v_exp_f32; loads, LDS images, statistics stay fp32.  A template
+// switch: as a run-time one both MFMA forms stay live and the kernel drops to one wave per SIMD.
+template <typename T, int NKF, bool SPLIT, bool BT, int DH = 32, bool SW = false, int B2W = 0, bool M3 = false>
 __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) void window_attn_kernel(const AttnParams p) {
+  static_assert(!M3 || (sizeof(T) == 4 && (DH * (int)sizeof(T) / 64) % 2 == 0 && !SPLIT), "split-bf16 attention: fp32 storage, whole fragment pairs");
   static_assert(B2W == 0 || (BT && !SW && !SPLIT && B2W % 2 == 0 && B2W * B2W <= NKF * 16 && (B2W * B2W) % 4 == 0), "2 x 2-block token order: BT kernels, even windows");
   constexpr int TBN = 1024;  // LDS bias table: [0, (2w-1)^2) the offsets, the rest -1e30 (padded keys index there)
   constexpr int D = DH;      // head dimension: 32 (CrossFormer), up to 128 (FuXi's Swin stage)
@@ -359,13 +376,25 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
       return *reinterpret_cast<const uint4*>(row + b * 16 + g * 4);
     }
   };
-  uint4 vf[VLDS ? 1 : NDF][VLDS ? 1 : NVF];
+  constexpr int NVFA = M3 ? NVF + (NVF & 1) : NVF;   // M3 pairs key fragments: an even count (the odd one out is a zero fragment)
+  uint4 vf[VLDS ? 1 : NDF][VLDS ? 1 : NVFA];
   if constexpr (!VLDS) {
 #pragma unroll
     for (int df = 0; df < NDF; ++df) {
 #pragma unroll
       for (int b = 0; b < NVF; ++b) vf[df][b] = read_vf(df, b);
+      if constexpr (NVFA > NVF) vf[df][NVFA - 1] = make_uint4(0u, 0u, 0u, 0u);
     }
+  }
+  if constexpr (M3) {   // Q / K pair the two halves of a 32-channel slice (4 g .. | 16 + 4 g ..), V^T / P pair two key fragments (16 j + 4 g .. | 16 (j + 1) + 4 g ..)
+#pragma unroll
+    for (int j = 0; j < NKF; ++j)
+#pragma unroll
+      for (int s = 0; s < QK_SUBS; s += 2) attn_split_pair(kf[j][s], kf[j][s + 1]);
+#pragma unroll
+    for (int df = 0; df < NDF; ++df)
+#pragma unroll
+      for (int b = 0; b < NVFA; b += 2) attn_split_pair(vf[df][b], vf[df][b + 1]);
   }
 
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
@@ -532,6 +561,10 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
         qf[s] = pack16<T>(v);
       }
     }
+    if constexpr (M3) {
+#pragma unroll
+      for (int s = 0; s < QK_SUBS; s += 2) attn_split_pair(qf[s], qf[s + 1]);
+    }
     // Scores/probabilities live in plain float arrays (not ext-vector elements): hipcc (ROCm 7.2) was
     // observed to fold element writes `vec[r] = expf(..)` so that all four PV B-operands read element 0.
     float sv[NKF][4];
@@ -586,8 +619,13 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
         sv[j][0] = a[0]; sv[j][1] = a[1]; sv[j][2] = a[2]; sv[j][3] = a[3];
       } else {
         f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (M3) {   // qf was split above: (qf[s], qf[s + 1]) = (hi, lo)
 #pragma unroll
-        for (int s = 0; s < QK_SUBS; ++s) a = mma_sub<T>(kf[j][s], qf[s], a);
+          for (int s = 0; s < QK_SUBS; s += 2) a = attn_mma3(kf[j][s], kf[j][s + 1], qf[s], qf[s + 1], a);
+        } else {
+#pragma unroll
+          for (int s = 0; s < QK_SUBS; ++s) a = mma_sub<T>(kf[j][s], qf[s], a);
+        }
         sv[j][0] = a[0] * p.scale + bb.x;
         sv[j][1] = a[1] * p.scale + bb.y;
         sv[j][2] = a[2] * p.scale + bb.z;
@@ -661,7 +699,8 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
           // bf16 mode: probabilities are rounded to bf16 for the PV MFMA anyway -> one v_exp_f32 (2^x) instead of
           // libm's ~12-instruction expf; fp32 mode keeps the exact path
           if constexpr (sizeof(T) == 2) sv[j][r] = __builtin_amdgcn_exp2f(sv[j][r] - mx);  // log2(e) folded into scale / bias
-          else sv[j][r] = expf(sv[j][r] - mx);
+          else if constexpr (M3) sv[j][r] = __builtin_amdgcn_exp2f((sv[j][r] - mx) * 1.4426950408889634f);   // v_exp_f32 (1 ulp): the
+          else sv[j][r] = expf(sv[j][r] - mx);                                                                // probabilities are split to hi + lo bf16 next
           sum += sv[j][r];
         }
       }
@@ -695,6 +734,20 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
         if constexpr (WX_ATTN_MFMA_SOFTMAX) osum = mma_sub<T>(make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u), pf, osum);
       }
       if constexpr (WX_ATTN_MFMA_SOFTMAX) sum = osum[0];
+    } else if constexpr (M3) {
+#pragma unroll
+      for (int b = 0; b < NVFA; b += 2) {
+        float pv[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pv[r] = sv[b][r];
+          pv[4 + r] = (b + 1 < NKF) ? sv[(b + 1 < NKF) ? b + 1 : 0][r] : 0.f;
+        }
+        uint4 ph, pl;
+        split_bf16x8(pv, ph, pl);
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) oacc[df] = attn_mma3(vf[df][b], vf[df][b + 1], ph, pl, oacc[df]);
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < NKF; ++j) {
@@ -742,7 +795,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
 #endif
 }
 
-template <typename T, int NKF, bool SPLIT, bool BT = false, int DH = 32, bool SW = false, int B2W = 0>
+template <typename T, int NKF, bool SPLIT, bool BT = false, int DH = 32, bool SW = false, int B2W = 0, bool M3 = false>
 inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
   if ((int64_t)p.H * p.W >= (1 << 24) || (int64_t)p.ld_qkv * (int64_t)sizeof(T) >= (1 << 24) || p.ld_out >= (1 << 24) ||
       (int64_t)p.H * p.W * p.ld_qkv * (int64_t)sizeof(T) >= (int64_t(1) << 32))
@@ -756,7 +809,7 @@ inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
 #endif
   constexpr int TB2 = B2W > 0 ? ((2 * B2W - 1) * (2 * B2W - 1) + 7) / 8 * 8 : 0;
   constexpr int LDS = (SPLIT ? 1 : 4) * DH * VT_COLS * (int)sizeof(T) + (B2W > 0 ? TB2 * 16 + NKF * 16 * 4 : BT ? 1024 * 4 + NKF * 16 * 4 : 0) + NKF * 16 * 4;
-  auto kern = window_attn_kernel<T, NKF, SPLIT, BT, DH, SW, B2W>;
+  auto kern = window_attn_kernel<T, NKF, SPLIT, BT, DH, SW, B2W, M3>;
   static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -796,6 +849,17 @@ inline void launch_window_attn(const AttnParams& p, hipStream_t stream, int spli
   const bool bt = p.tb != nullptr && p.pack == 1 && split_mode != 3;   // split_mode 3: A/B switch back to the [NP][NP] table
   const bool split = nkf >= 4 && split_mode == 2;  // measured slower on every C3 launch (0.535 vs 0.471 ms at stage 2): experiment only
   (void)tasks;
+  if constexpr (sizeof(T) == 4) {
+    if (p.mma3 && bt && !split) {   // split-bf16 precision: the table-path instantiations of the windows the models use; others stay exact-f32
+      switch (nkf) {
+        case 2: launch_window_attn_n<T, 2, false, true, 32, false, 0, true>(p, stream); return;
+        case 4: launch_window_attn_n<T, 4, false, true, 32, false, 0, true>(p, stream); return;
+        case 7: launch_window_attn_n<T, 7, false, true, 32, false, 0, true>(p, stream); return;   // (the 2 x 2-block bias order: 214 vs 205 us here)
+        case 8: launch_window_attn_n<T, 8, false, true, 32, false, 0, true>(p, stream); return;
+        default: break;
+      }
+    }
+  }
   switch (nkf) {
     case 1: launch_window_attn_n<T, 1, false>(p, stream); break;
     case 2:

@@ -1611,6 +1611,7 @@ class Engine : public EngineBase {
       p.H = h; p.W = w; p.C = c; p.heads = c / cfg.dim_head; p.wsz = a.wsz; p.kind = attn_kind_override >= 0 ? attn_kind_override : a.kind;
       p.scale = (float)(1.0 / std::sqrt((double)cfg.dim_head));   // fp32 engine only: the bf16 engine's q already carries scale * log2(e)
       p.pack = attn_pack(a.wsz);
+      p.mma3 = split_mma ? 1 : 0;
       const double n = (double)a.wsz * a.wsz;
       timed("window_attn", 4.0 * m * n * c, 4.0 * m * c * sizeof(T), [&] {
         if (cfg.dim_head == 32) launch_window_attn<T>(p, cur_stream, attn_split);
