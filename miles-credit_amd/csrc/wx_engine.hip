@@ -1253,6 +1253,7 @@ class Engine : public EngineBase {
   void profile(int on) override { prof_on = on != 0; detail_on = on > 1; family_on = on > 2; }
   int64_t n_two_stream_stages = 0;   // of the last forward
   int64_t n_split_gemms = 0;         // GEMM launches of the last forward that ran split-bf16 arithmetic
+  int split_bn64 = getenv("WX_SPLIT_BN64") ? atoi(getenv("WX_SPLIT_BN64")) : 1;   // 0: never the 64-column tiles of the badly quantised residual layers
   int64_t n_launches = 0;            // timed() calls of the last forward (one per kernel launch or launch + finish pair)
   bool query(const std::string& key, int64_t* v) override {
     if (key == "two_stream_stages") { *v = n_two_stream_stages; return true; }
@@ -1526,8 +1527,19 @@ class Engine : public EngineBase {
         p.k_splits = S;
       }
     }
+    if constexpr (sizeof(T) == 4) {
+      // fp32 storage (both arithmetic modes), residual 1 x 1 layers whose 128 x 128 tiles fill the last round of the 512 workgroup slots badly (0.25-degree stage 2:
+      // N = 512 -> 628 tiles = 1.23 rounds): 128 x 64 tiles (1 256 of them: 2.45 half-length rounds; three workgroups per CU)
+      // (measured, C3: FeedForward 2 of stage 2 2.74 -> 2.36 ms, to_out 1.03 -> 0.88; 64-column tiles EVERYWHERE lose -- to_qkv 1.82 -> 1.99,
+      // FeedForward 1 2.59 -> 2.84: half the MFMAs per split activation fragment)
+      if (!p.partial && split_bn64 && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr) && p.n_par != 4 && w.n >= 96 && w.n % 64 == 0 && (w.n <= 512 || !p.stat_out) && stat_share_stride == 0) {
+        const int64_t tiles = cdiv((int64_t)out_h * out_w, (int64_t)128) * cdiv(w.n, 128);
+        const double rounds = (double)tiles / 512.0;
+        if (tiles > 512 && rounds < 1.5) p.bn64 = 1;
+      }
+    }
     timed(cls, flops, bytes, [&] { launch_conv_gemm<T>(p, use_dma ? zero_page : nullptr, cur_stream, gemm_cfg); });
-    last_stat_slots = p.partial ? conv_gemm_finish_slots(w.n) : conv_gemm_n_tiles(w.n);
+    last_stat_slots = p.partial ? conv_gemm_finish_slots(w.n) : (p.bn64 ? cdiv(w.n, 64) : conv_gemm_n_tiles(w.n));
     return made_stats;
   }
   void upsample2x(const T* in, int h, int w, int64_t in_ld, int c) {

@@ -68,6 +68,7 @@ struct ConvGemmParams {
   // accumulate) on activation fragments split in registers.  With `rowstat` the LayerNorm is applied to the activation fragment
   // BEFORE the split ((x - mean) * rstd; no mean * colsum cancellation in the epilogue, which then only adds the bias).
   int split;
+  int bn64;   // 64-column tiles although n >= 96 (the fp32 engines ask for it where 128-column tiles quantise badly; stat slots = n / 64)
 };
 #ifdef WX_GEMM_TRACE
 __device__ __forceinline__ void trace_stamp(const ConvGemmParams& p, int slot) {
@@ -1146,7 +1147,7 @@ inline void launch_conv_gemm(const ConvGemmParams& p, const void* zero_page, hip
     }
     if (gemm_cfg == 1 && row_bytes % 128 == 0) kb64 = false;
     if (gemm_cfg == 2 && !p.split) kb64 = true;
-    if ((p.n >= 96 || (p.n_par == 4 && p.n > 64)) && gemm_cfg != 3) {   // merged parity convs need ONE N-tile per parity: 65..128 channels take BN = 128
+    if ((p.n >= 96 || (p.n_par == 4 && p.n > 64)) && gemm_cfg != 3 && !p.bn64) {   // merged parity convs need ONE N-tile per parity: 65..128 channels take BN = 128
       if (kb64) launch_conv_gemm_dma<T, 128, 64>(p, zero_page, stream);
       else launch_conv_gemm_dma<T, 128, 128>(p, zero_page, stream);
     } else {
