@@ -360,8 +360,8 @@ def main():
                       "split_gemm_launches_per_step": engs.query("split_gemms"),
                       "max_dev_from_exact_f32_engine": round(dev_rel, 9),
                       "finite_outputs": bool(torch.isfinite(y_phys).all().item()),
-                      "note": f"tolerance mode: max|y - reference| <= 1e-4 max|reference| (measured 9.3e-6 on this workload's golden; "
-                              f"tests/test_engine_gpu.py, both stress families <= 6.3e-5); max|y_phys - exact-f32 engine| after {n32} steps "
+                      "note": f"tolerance mode: max|y - reference| <= 1e-4 max|reference| (measured 1.04e-5 on this workload's golden; "
+                              f"tests/test_engine_gpu.py, both stress families <= 6.5e-5); max|y_phys - exact-f32 engine| after {n32} steps "
                               f"of this run = {dev_rel:.2e} of max|y_phys|"}
         del engs
 
