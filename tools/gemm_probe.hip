@@ -13,6 +13,13 @@
 #include "wx_gemm.h"
 
 using namespace wx;
+#ifdef WX_PROBE_F32S   // the split-bf16 path of the fp32 engine (timing only: the weight buffer is not split-encoded)
+typedef float elem_t;
+static inline elem_t to_elem(float f) { return f; }
+#else
+typedef uint16_t elem_t;
+static inline elem_t to_elem(float f) { return f2bf(f); }
+#endif
 
 static void* dalloc(size_t n) {
   void* p;
@@ -30,13 +37,13 @@ int main(int argc, char** argv) {
   const int stat = argc > 7 ? atoi(argv[7]) : 0, cfg = argc > 8 ? atoi(argv[8]) : 0, dbg = argc > 9 ? atoi(argv[9]) : 0;
   std::mt19937 rng(1);
   std::uniform_real_distribution<float> u(-1.f, 1.f);
-  std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K);
-  for (auto& v : hx) v = f2bf(u(rng));
-  for (auto& v : hw) v = f2bf(u(rng) * 0.05f);
-  uint16_t* x = (uint16_t*)dalloc(hx.size() * 2);
-  uint16_t* w = (uint16_t*)dalloc(hw.size() * 2);
-  uint16_t* y = (uint16_t*)dalloc((size_t)M * N * 2);
-  uint16_t* r = (uint16_t*)dalloc((size_t)M * N * 2);
+  std::vector<elem_t> hx((size_t)M * K), hw((size_t)N * K);
+  for (auto& v : hx) v = to_elem(u(rng));
+  for (auto& v : hw) v = to_elem(u(rng) * 0.05f);
+  elem_t* x = (elem_t*)dalloc(hx.size() * sizeof(elem_t));
+  elem_t* w = (elem_t*)dalloc(hw.size() * sizeof(elem_t));
+  elem_t* y = (elem_t*)dalloc((size_t)M * N * sizeof(elem_t));
+  elem_t* r = (elem_t*)dalloc((size_t)M * N * sizeof(elem_t));
   const int NP = (N + 127) / 128 * 128;
   float* bias = (float*)dalloc(NP * 4);
   float* colsum = (float*)dalloc(NP * 4);
@@ -46,13 +53,13 @@ int main(int argc, char** argv) {
   WX_HIP(hipMemset(zero, 0, 256));
   WX_HIP(hipMemset(bias, 0, NP * 4));
   WX_HIP(hipMemset(colsum, 0, NP * 4));
-  WX_HIP(hipMemset(r, 0, (size_t)M * N * 2));
+  WX_HIP(hipMemset(r, 0, (size_t)M * N * sizeof(elem_t)));
   {
     std::vector<float2> rs(M, make_float2(0.f, 1.f));
     WX_HIP(hipMemcpy(rowstat, rs.data(), (size_t)M * 8, hipMemcpyHostToDevice));
   }
-  WX_HIP(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
-  WX_HIP(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+  WX_HIP(hipMemcpy(x, hx.data(), hx.size() * sizeof(elem_t), hipMemcpyHostToDevice));
+  WX_HIP(hipMemcpy(w, hw.data(), hw.size() * sizeof(elem_t), hipMemcpyHostToDevice));
 
   ConvGemmParams p;
   std::memset(&p, 0, sizeof(p));
@@ -60,17 +67,20 @@ int main(int argc, char** argv) {
   p.out_h = 1; p.out_w = M; p.wt = w; p.n = N; p.n_alloc = N; p.bias = bias;
   if (ln) { p.rowstat = rowstat; p.colsum = colsum; p.stat_tiles = 0; p.stat_inv_c = 1.f / K; }
   if (stat) p.stat_out = statout;
+  #ifdef WX_PROBE_F32S
+  p.split = 1;
+#endif
   p.act = act; p.res = res ? r : nullptr; p.res_ld = N; p.out = y; p.out_ld = N; p.dbg = dbg;
 
   hipStream_t st;
   WX_HIP(hipStreamCreate(&st));
-  for (int i = 0; i < 3; ++i) launch_conv_gemm<uint16_t>(p, zero, st, cfg);
+  for (int i = 0; i < 3; ++i) launch_conv_gemm<elem_t>(p, zero, st, cfg);
   hipEvent_t e0, e1;
   WX_HIP(hipEventCreate(&e0));
   WX_HIP(hipEventCreate(&e1));
   const int reps = 20;
   WX_HIP(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) launch_conv_gemm<uint16_t>(p, zero, st, cfg);
+  for (int i = 0; i < reps; ++i) launch_conv_gemm<elem_t>(p, zero, st, cfg);
   WX_HIP(hipEventRecord(e1, st));
   WX_HIP(hipStreamSynchronize(st));
   float ms;
@@ -86,7 +96,7 @@ int main(int argc, char** argv) {
   unsigned long long* tr = (unsigned long long*)dalloc(blocks * 128);
   WX_HIP(hipMemset(tr, 0, blocks * 128));
   p.trace = tr;
-  launch_conv_gemm<uint16_t>(p, zero, st, cfg);
+  launch_conv_gemm<elem_t>(p, zero, st, cfg);
   WX_HIP(hipStreamSynchronize(st));
   std::vector<unsigned long long> h(blocks * 16);
   WX_HIP(hipMemcpy(h.data(), tr, blocks * 128, hipMemcpyDeviceToHost));
