@@ -2206,7 +2206,6 @@ class Engine : public EngineBase {
       throw ConfigError("lat-band mode: the upsample_v_conv decoder variant is not wired (crossformer and wxformer are)");
     if (e.cfg.frames != 1 || e.cfg.output_frames != 1) throw ConfigError("lat-band mode needs frames == output_frames == 1");
     if (e.cfg.dim_head != 32) throw ConfigError("lat-band mode needs dim_head == 32");
-    if (e.split_mma) throw ConfigError("lat-band mode: the split-bf16 precision is not wired (fp32 and bf16 are)");
   }
 
   void band_enable(int rank, int n) override {
@@ -3055,8 +3054,7 @@ int wx_band_plan_create(const wx_config* cfg, int nranks, wx_band_plan* out) {
     if (!cfg || !out) throw wx::ConfigError("wx_band_plan_create: null argument");
     if (nranks < 1) throw wx::ConfigError("wx_band_plan_create: nranks must be >= 1");
     std::unique_ptr<wx_band_plan_s> p(new wx_band_plan_s);
-    if (cfg->precision == WX_PREC_FP32_SPLIT) throw wx::ConfigError("lat-band mode: the split-bf16 precision is not wired (fp32 and bf16 are)");
-    if (cfg->precision == WX_PREC_FP32) {
+    if (cfg->precision == WX_PREC_FP32 || cfg->precision == WX_PREC_FP32_SPLIT) {   // the plan depends on geometry, not on arithmetic
       wx::Engine<float> e(*cfg, -1);
       wx::Engine<float>::band_check_supported(e);
       p->plan.build(wx::Engine<float>::band_model(e, nranks));

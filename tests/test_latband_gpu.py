@@ -58,12 +58,16 @@ def _close(a, b, prec, l2_tol=1e-2, max_tol=5e-2, fp32_tol=1e-5):
     assert torch.isfinite(a).all()
     if prec == "fp32":
         assert err <= fp32_tol * scale, f"fp32 sharded vs unsharded: {err:.3e} (scale {scale:.3e})"
+    elif prec == "fp32s":
+        # split-bf16 arithmetic: a band rank's stage-0 CrossEmbed runs the exact-f32 patch kernel (its input planes are not split) and
+        # its GEMM tiles group rows differently, so the two runs differ by the mode's own product error (~1e-5), not by summation order
+        assert err <= 5e-5 * scale, f"fp32s sharded vs unsharded: {err:.3e} (scale {scale:.3e})"
     else:
         l2 = ((a - b).norm() / b.norm()).item()
         assert l2 <= l2_tol and err <= max_tol * scale, f"bf16 sharded vs reference: rel-L2 {l2:.3e} max {err:.3e} (scale {scale:.3e})"
 
 
-@pytest.mark.parametrize("name,prec,n", [("T0", "fp32", 2), ("T0", "fp32", 3), ("T1", "fp32", 3), ("T1", "fp32", 8), ("T1", "bf16", 2),
+@pytest.mark.parametrize("name,prec,n", [("T0", "fp32", 2), ("T0", "fp32", 3), ("T1", "fp32", 3), ("T1", "fp32", 8), ("T1", "bf16", 2), ("T1", "fp32s", 3), ("C1", "fp32s", 5),
                                          ("C1", "fp32", 5), ("C1", "bf16", 4), ("T0W", "fp32", 2), ("T0W", "fp32", 3), ("C1W", "fp32", 4),
                                          ("C1W", "bf16", 5)])
 def test_sharded_step_equals_unsharded(name, prec, n):
