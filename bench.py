@@ -431,6 +431,21 @@ def main():
                            "'timm' = timm's SwinTransformerV2Block as the reference builds it (state-dict keys of a reference checkpoint; parity "
                            "of the block itself unpinned: timm absent, SURVEY 8(c)); 'cr' = credit/models/swin.py's block (pinned)"}
         del m5
+        if not args.no_fp32:   # the same forward in the fast mode that meets the fp32 tolerance (round 5: wx_fuxi_create takes WX_PREC_FP32_SPLIT)
+            torch.cuda.empty_cache()
+            ms5 = FuxiHIP(precision="fp32s", device=local_rank, cfg=cfg5)
+            ms5.load_state_dict(synth_fuxi_state_dict(cfg5))
+            ms5(x5, y5)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                ms5(x5, y5)
+            torch.cuda.synchronize()
+            e5s = (time.perf_counter() - t1) / 3
+            config5["fp32_split"] = {"value": round(1.0 / e5s, 2), "unit": "forwards/sec", "ms_per_forward": round(1e3 * e5s, 3),
+                                     "dtype": "fp32 storage, split-bf16 GEMM arithmetic", "finite_outputs": bool(torch.isfinite(y5).all().item()),
+                                     "note": "exact-f32 engine: 77 ms per forward (tools/fuxi_time.py fp32 3); measured 1.6e-5 of max|y| from it"}
+            del ms5
 
     if rank == 0:
         total_steps = args.steps * world

@@ -51,7 +51,8 @@ enum wx_precision {
   WX_PREC_FP32_SPLIT = 2   /* f32 storage, LN / softmax / GN / attention as WX_PREC_FP32; every implicit GEMM as split-bf16 arithmetic:
                             * x = x_hi + x_lo, W = W_hi + W_lo, three v_mfma_f32_16x16x32_bf16 per product (hi.hi + hi.lo + lo.hi),
                             * fp32 accumulate -- the fast mode that still meets the fp32 tolerance against the reference (whose
-                            * inference is fp32 with TF32 off, credit/seed.py:24-25).  wx_create only (not the Swin / FuXi handles). */
+                            * inference is fp32 with TF32 off, credit/seed.py:24-25).  wx_create (incl. lat-band mode), wx_swin_create and wx_fuxi_create take it
+                            * (their attention kernels stay exact fp32 outside the CrossFormer windows); wx_winattn_create takes FP32 / BF16. */
 };
 
 /* The YAML `model:` mapping of the reference constructor

@@ -937,15 +937,7 @@ class Engine : public EngineBase {
         // a layer with cin % 32 == 0 is a whole number of chunks from a chunk-aligned start (push_w); other layers keep the f32 MFMA.
         while (wt_host.size() % 32) wt_host.push_back(0.f);
         std::vector<uint16_t> sp(wt_host.size() * 2);
-        for (size_t c0 = 0; c0 < wt_host.size(); c0 += 32)
-          for (int g = 0; g < 4; ++g)
-            for (int e = 0; e < 8; ++e) {
-              const float w = wt_host[c0 + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))];
-              const bf16_t hi = f2bf(w);
-              const bf16_t lo = f2bf(w - bf2f(hi));
-              sp[c0 * 2 + g * 8 + e] = hi;
-              sp[c0 * 2 + 32 + g * 8 + e] = lo;
-            }
+        split_encode_chunks(wt_host.data(), wt_host.size(), sp.data());
         if (ws_dev) { (void)hipFree(ws_dev); allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)ws_dev)); ws_dev = nullptr; }
         ws_dev = (T*)dalloc(sp.size() * sizeof(uint16_t) + 256);
         WX_HIP(hipMemcpy(ws_dev, sp.data(), sp.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -3298,7 +3290,7 @@ int wx_swin_create(const wx_swin_desc* d, int device, wx_swin_handle* out) {
     if (!d || !out) throw wx::ConfigError("null argument");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw wx::HipError("no HIP device visible: wxengine has no CPU fallback");
-    if (d->precision != WX_PREC_FP32 && d->precision != WX_PREC_BF16) throw wx::ConfigError("swin: unknown precision");
+    if (d->precision != WX_PREC_FP32 && d->precision != WX_PREC_BF16 && d->precision != WX_PREC_FP32_SPLIT) throw wx::ConfigError("swin: unknown precision");
     if (d->depth < 1 || d->H < 1 || d->W < 1 || d->heads < 1 || d->wsz_y < 1 || d->wsz_x < 1) throw wx::ConfigError("swin: bad geometry");
     wx::SwinDesc sd{d->H, d->W, d->C, d->heads, d->wsz_y, d->wsz_x, d->depth, d->hidden, d->shift_y, d->shift_x, d->mask_value, d->ln_eps};
     if (d->mask_axes != 0 && d->mask_axes != 1 && d->mask_axes != 3) throw wx::ConfigError("swin: mask_axes must be 1 (latitude) or 3 (both axes)");
@@ -3306,7 +3298,7 @@ int wx_swin_create(const wx_swin_desc* d, int device, wx_swin_handle* out) {
     auto w = std::make_unique<wx_swin>();
     try {
       if (d->precision == WX_PREC_BF16) w->impl = std::make_unique<wx::SwinStage<wx::bf16_t>>(sd, device);
-      else w->impl = std::make_unique<wx::SwinStage<float>>(sd, device);
+      else w->impl = std::make_unique<wx::SwinStage<float>>(sd, device, d->precision == WX_PREC_FP32_SPLIT);
     } catch (const std::runtime_error& e) {
       throw wx::ConfigError(e.what());
     }
@@ -3346,7 +3338,7 @@ int wx_fuxi_create(const wx_fuxi_desc* d, int device, wx_fuxi_handle* out) {
     if (!d || !out) throw wx::ConfigError("null argument");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw wx::HipError("no HIP device visible: wxengine has no CPU fallback");
-    if (d->precision != WX_PREC_FP32 && d->precision != WX_PREC_BF16) throw wx::ConfigError("fuxi: unknown precision");
+    if (d->precision != WX_PREC_FP32 && d->precision != WX_PREC_BF16 && d->precision != WX_PREC_FP32_SPLIT) throw wx::ConfigError("fuxi: unknown precision");
     if (d->H < 1 || d->W < 1 || d->C_in < 1 || d->C_out < 1 || d->frames < 1 || d->patch_h < 1 || d->patch_w < 1 || d->dim < 1 || d->heads < 1 ||
         d->window < 1 || d->depth < 1 || d->groups_down < 1 || d->groups_up < 1)
       throw wx::ConfigError("fuxi: bad geometry");
@@ -3356,7 +3348,7 @@ int wx_fuxi_create(const wx_fuxi_desc* d, int device, wx_fuxi_handle* out) {
     auto w = std::make_unique<wx_fuxi>();
     try {
       if (d->precision == WX_PREC_BF16) w->impl = std::make_unique<wx::FuxiModel<wx::bf16_t>>(fd, device);
-      else w->impl = std::make_unique<wx::FuxiModel<float>>(fd, device);
+      else w->impl = std::make_unique<wx::FuxiModel<float>>(fd, device, d->precision == WX_PREC_FP32_SPLIT);
     } catch (const wx::HipError&) { throw; } catch (const std::runtime_error& e) {
       throw wx::ConfigError(e.what());
     }

@@ -162,7 +162,11 @@ struct FuxiModel : FuxiBase {
     allocs.push_back(p);
     return p;
   }
-  FuxiModel(const FuxiDesc& desc, int dev) : d(desc), device(dev) {
+  // split (T = float; WX_PREC_FP32_SPLIT): every convolution / Linear of the forward and of the stage runs split-bf16 arithmetic from a
+  // re-encoded shadow copy of its weight (wx_swin.h SwinStage::split); GroupNorm, LayerNorm, the patch reshapes and the attention stay fp32
+  bool split = false;
+  std::map<const void*, T*> split_of;
+  FuxiModel(const FuxiDesc& desc, int dev, bool split_mma = false) : d(desc), device(dev), split(split_mma && sizeof(T) == 4) {
     if (d.H % d.ph || d.W % d.pw) throw std::runtime_error("fuxi: the image must be a multiple of the patch");
     Hp = d.H / d.ph; Wp = d.W / d.pw;
     if (Hp % 2 || Wp % 2) throw std::runtime_error("fuxi: the patch grid must be even (DownBlock halves it, UpBlock doubles it back)");
@@ -181,7 +185,7 @@ struct FuxiModel : FuxiBase {
     if (Hs <= d.wsz) sd.shift_y = 0;
     if (Ws <= d.wsz) sd.shift_x = 0;
     sd.mask_axes = d.stage_variant == 1 ? 3 : 1;   // timm's block masks the longitude seam too
-    stage = std::make_unique<SwinStage<T>>(sd, device);
+    stage = std::make_unique<SwinStage<T>>(sd, device, split);
     const size_t dim = d.dim, Mp = (size_t)Hp * Wp, Md = (size_t)Hd * Wd, Ms = (size_t)Hs * Ws;
     auto wT = [&](size_t n) { return (T*)dalloc(n * sizeof(T)); };
     auto wf = [&](size_t n) { float* p = (float*)dalloc(n * 4); return p; };
@@ -208,6 +212,15 @@ struct FuxiModel : FuxiBase {
     std::vector<T> t(h.size());
     for (size_t i = 0; i < h.size(); ++i) t[i] = Elem<T>::from_f(h[i]);
     WX_HIP(hipMemcpy(dst, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice));
+    if constexpr (sizeof(T) == 4) {
+      if (split && h.size() % 32 == 0) {   // rows of k x k x cin floats: conv() takes the shadow only when cin % 32 == 0 (whole chunks per tap)
+        std::vector<uint16_t> sp(h.size() * 2);
+        split_encode_chunks(h.data(), h.size(), sp.data());
+        T*& shadow = split_of[dst];
+        if (!shadow) shadow = (T*)dalloc(h.size() * sizeof(T));
+        WX_HIP(hipMemcpy(shadow, sp.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+      }
+    }
   }
   static void need(int64_t n, int64_t want, const std::string& k) {
     if (n != want) throw std::runtime_error("fuxi: " + k + " has " + std::to_string(n) + " elements, expected " + std::to_string(want));
@@ -318,6 +331,10 @@ struct FuxiModel : FuxiBase {
     if (gn) {   // GroupNorm partials from the epilogue (fast path only: dim % 64 == 0 guarantees it)
       if (!conv_gemm_is_dma<T>(p, zero_page)) throw std::runtime_error("fuxi: GroupNorm partials need the LDS-DMA GEMM path");
       p.gn_out = gn_part;
+    }
+    if constexpr (sizeof(T) == 4) {
+      const auto it = split_of.find(w);
+      if (it != split_of.end() && cin % 32 == 0 && conv_gemm_is_dma<T>(p, zero_page)) { p.split = 1; p.wt = it->second; }
     }
     launch_conv_gemm<T>(p, zero_page, s, 0);
   }

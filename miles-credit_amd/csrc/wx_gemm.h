@@ -1110,6 +1110,20 @@ inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page,
   }
 }
 
+// Host side of ConvGemmParams::split: n floats (n % 32 == 0; rows of K floats, K % 32 == 0, from a chunk-aligned start) -> the same bytes
+// re-encoded 32-float chunk by chunk as [hi fragments g = 0..3 | lo fragments g = 0..3], fragment g = the eight k values
+// {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3} a lane of k-group g feeds to v_mfma_f32_16x16x32_bf16; hi = RNE_bf16(w), lo = RNE_bf16(w - hi)
+inline void split_encode_chunks(const float* src, size_t n, uint16_t* dst) {
+  for (size_t c0 = 0; c0 + 32 <= n; c0 += 32)
+    for (int g = 0; g < 4; ++g)
+      for (int e = 0; e < 8; ++e) {
+        const float w = src[c0 + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))];
+        const bf16_t hi = f2bf(w);
+        dst[c0 * 2 + g * 8 + e] = hi;
+        dst[c0 * 2 + 32 + g * 8 + e] = f2bf(w - bf2f(hi));
+      }
+}
+
 // Does this launch take the fast (LDS-DMA) path?  (The engine needs to know: only that path emits LN partials.)
 template <typename T>
 inline bool conv_gemm_is_dma(const ConvGemmParams& p, const void* zero_page) {

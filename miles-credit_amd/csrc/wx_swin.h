@@ -12,6 +12,7 @@
 // the BRANCH output, then added to the stream -- as one wave per token (`ln_residual_kernel`: the row lives in registers, two-pass
 // statistics in fp32, one read of branch + stream and one write of the stream), and the stage object that owns the weights.
 #pragma once
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -121,7 +122,12 @@ struct SwinStage : SwinStageBase {
     allocs.push_back(p);
     return p;
   }
-  SwinStage(const SwinDesc& desc, int dev) : d(desc), device(dev) {
+  // split (T = float; WX_PREC_FP32_SPLIT): the four Linear layers run split-bf16 arithmetic -- every GEMM weight gets a re-encoded shadow copy
+  // (wx_gemm.h split_encode_chunks) that `linear` hands to the implicit-GEMM kernel with ConvGemmParams::split; the attention kernel
+  // (general head dimension, seam mask, cosine mode) and the LayerNorm kernels stay exact fp32
+  bool split = false;
+  std::map<const void*, T*> split_of;
+  SwinStage(const SwinDesc& desc, int dev, bool split_mma = false) : d(desc), device(dev), split(split_mma && sizeof(T) == 4) {
     constexpr int VEC = 16 / (int)sizeof(T);
     if (d.C % 64 || d.hidden % 64 || d.C % d.heads) throw std::runtime_error("swin: C and hidden must be multiples of 64, C of heads");
     const int hd = d.C / d.heads;
@@ -172,6 +178,15 @@ struct SwinStage : SwinStageBase {
     std::vector<T> h((size_t)n);
     for (int64_t i = 0; i < n; ++i) h[i] = Elem<T>::from_f(src[i]);
     WX_HIP(hipMemcpy(dst, h.data(), (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+    if constexpr (sizeof(T) == 4) {
+      if (split && K > 0 && K % 32 == 0 && n % 32 == 0) {
+        std::vector<uint16_t> sp((size_t)n * 2);
+        split_encode_chunks(src, (size_t)n, sp.data());
+        T*& shadow = split_of[dst];
+        if (!shadow) shadow = (T*)dalloc((size_t)n * sizeof(T));
+        WX_HIP(hipMemcpy(shadow, sp.data(), (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+      }
+    }
     if (dst_kb) {   // the same rounded values, [K / 32][N][32]
       const int64_t N = n / K;
       std::vector<T> t((size_t)n);
@@ -259,6 +274,10 @@ struct SwinStage : SwinStageBase {
     const int M = d.H * d.W;
     p.in = in; p.in_h = 1; p.in_w = M; p.in_ld = K; p.cin = K; p.kh = p.kw = 1; p.stride = 1;
     p.out_h = 1; p.out_w = M; p.wt = w; p.n = N; p.n_alloc = N; p.bias = bias; p.act = act; p.out = out; p.out_ld = N;
+    if constexpr (sizeof(T) == 4) {
+      const auto it = split_of.find(w);
+      if (it != split_of.end() && K % 32 == 0 && conv_gemm_is_dma<T>(p, zero_page)) { p.split = 1; p.wt = it->second; }
+    }
     launch_conv_gemm<T>(p, zero_page, s, 0);
   }
   void apply(const void* x_in, void* x_out, hipStream_t s) override {
