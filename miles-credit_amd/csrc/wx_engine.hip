@@ -61,7 +61,7 @@ struct ConvW {          // one repacked GEMM operand in the weight arena
 struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1, bias_tb = -1; int wsz = 0, kind = 0; };
 struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1, pack_pp = -1; const AttnL* next = nullptr; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset; pack_pre: the same preceded by the attention's Wout blocks
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
-struct PatchW { int64_t wt = -1, bias = -1, wt16 = -1; int n = 0; };   // wt16: split-bf16 mode, offset in the 16-bit patch arena  // LDS-patch CrossEmbed branch (wx_embed.h)
+struct PatchW { int64_t wt = -1, bias = -1, wt16 = -1; int n = 0; };   // LDS-patch CrossEmbed branch (wx_embed.h); wt16: split-bf16 mode, offset in the 16-bit patch arena
 struct StageL {
   std::vector<ConvW> embed; std::vector<int> embed_k; std::vector<PatchW> patch; std::vector<BlockL> blocks;
   bool ride4 = false;                            // stage 0: the k = 4 branch rides in the LDS-patch kernel's spare accumulator rows
@@ -153,10 +153,11 @@ class EngineBase {
 template <typename T>
 class Engine : public EngineBase {
  public:
-  // split_mma (T = float only; wx_config.precision WX_PREC_FP32_SPLIT): fp32 storage, LayerNorm / softmax / GroupNorm / attention as the
-  // exact-f32 engine, but every implicit GEMM runs split-bf16 arithmetic on the 2.5 PF pipe -- x = x_hi + x_lo, W = W_hi + W_lo (split
-  // once at load), three bf16 MFMAs per product with fp32 accumulation (wx_gemm.h, SPLIT).  Measured error against the reference's
-  // fp32 forward: ~1e-5 of max|y| (base weights), 5-7e-5 on the stress families -- inside the stated 1e-4 tolerance.
+  // split_mma (T = float only; wx_config.precision WX_PREC_FP32_SPLIT): fp32 storage, LayerNorm / softmax statistics / GroupNorm as the
+  // exact-f32 engine, but every implicit GEMM (wx_gemm.h SPLIT), the stage-0 CrossEmbed (the bf16 patch kernel over K-concatenated
+  // (hi, lo) planes, wx_embed.h) and the attention's Q.K^T / P.V (wx_attn.h M3) run split-bf16 arithmetic on the 2.5 PF pipe --
+  // x = x_hi + x_lo, W = W_hi + W_lo (split once at load), three bf16 MFMAs per product with fp32 accumulation.  Measured error against
+  // the reference's fp32 forward: ~1e-5 of max|y| (base weights), 5-7e-5 on the stress families -- inside the stated 1e-4 tolerance.
   bool split_mma = false;
   explicit Engine(const wx_config& c, int dev, bool split = false) : split_mma(split && sizeof(T) == 4), cfg(c) {
     device = dev;

@@ -1081,9 +1081,7 @@ inline void launch_conv_gemm_dma(const ConvGemmParams& p, const void* zero_page,
                     (int64_t)cdiv(p.out_h * p.out_w, 128) * (p.n_par == 4 ? 4 : cdiv(p.n, BN)) * (p.partial ? p.k_splits : 1) <= deep_max;
   if constexpr (sizeof(T) == 4 && KB == 128) {
     if (p.split) {   // split-bf16 arithmetic (fp32 storage): the same three address forms on the 2-stage ring
-      static const int split_nst = getenv("WX_SPLIT_NST") ? atoi(getenv("WX_SPLIT_NST")) : 2;   // probe: 3 / 4 = deeper ring, one workgroup per CU
-      if (one && split_nst == 3) { launch_conv_gemm_dma_v<T, 128, BN, KB, true, 3, false, true>(p, zero_page, stream); return; }
-      if (one && split_nst == 4) { launch_conv_gemm_dma_v<T, 128, BN, KB, true, 4, false, true>(p, zero_page, stream); return; }
+      // (a 3- / 4-stage ring with one workgroup per CU: 24.4 -> 29.4 / 30.1 ms per C3 forward, docs/history/r05_negative_results.md)
       if (one) launch_conv_gemm_dma_v<T, 128, BN, KB, true, 2, false, true>(p, zero_page, stream);
       else if (p.cin * (int)sizeof(T) / KB >= 8) launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2, true, true>(p, zero_page, stream);
       else launch_conv_gemm_dma_v<T, 128, BN, KB, false, 2, false, true>(p, zero_page, stream);
