@@ -120,6 +120,22 @@ __device__ inline uint4 pack16<bf16_t>(const float* in) {
 }
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// The same function for the split-bf16 precision's fused FeedForward (wx_ff_split.h), where the activation sits in the K loop's shadow and
+// libm's erff (~80 VALU) would bound the kernel: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32,
+//   gelu(x) = max(x, 0) - |x| P(t) exp(-x^2 / 2) / 2,   t = 1 / (1 + p |x| / sqrt 2),
+// 13 VALU + 2 transcendental; max |gelu_as - gelu| = 4.7e-7 over [-12, 12] in fp32 evaluation, the erff form's own 4.5e-7
+// (tests/test_host_models.py::test_gelu_as_host_model restates it in numpy).
+__device__ inline float gelu_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // exp(-x^2 / 2)
+  float pl = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+  pl = fmaf(pl, t, 0.5f * 1.421413741f);
+  pl = fmaf(pl, t, 0.5f * -0.284496736f);
+  pl = fmaf(pl, t, 0.5f * 0.254829592f);
+  pl *= t;
+  return fmaxf(x, 0.f) - fminf(ax, 16.f) * (pl * e);
+}
 // GELU for the bf16 engine: x * sigmoid(g(xc)), xc = clamp(x, -8, 8), g an odd degree-5 polynomial fitted to logit(Phi(x)) (minimax on
 // |x sigmoid(g(x)) - gelu(x)|, x in [-7, 7]): |gelu_fast - gelu| <= 2.6e-5 in fp32 evaluation -- 1/150 of a bf16 ulp at 1 --
 // as 1 / (1 + exp2(xc * q(xc^2))) with -log2(e) folded into q.  7 VALU + 2 transcendental ops per element (v_exp_f32, v_rcp_f32).

@@ -27,6 +27,7 @@
 #include "wx_gemm.h"
 #include "wx_gemm_stream.h"
 #include "wx_gemm_wreg.h"
+#include "wx_ff_split.h"
 #include "wx_attn_block.h"
 #include "wx_swin.h"
 #include "wx_fuxi.h"
@@ -986,6 +987,8 @@ class Engine : public EngineBase {
   int ff_split_tiles = getenv("WX_FF_SPLIT_TILES") ? atoi(getenv("WX_FF_SPLIT_TILES")) : 32;   // pixel tiles, at most
   int ff_split_max = getenv("WX_FF_SPLIT") ? atoi(getenv("WX_FF_SPLIT")) : 8;   // hidden ranges of the split fused FeedForward (0 / 1: off)
   bool attn_pack2 = !getenv("WX_NO_ATTN_PACK2");
+  int ff_split_tw = getenv("WX_FF_SPLIT_TW") ? atoi(getenv("WX_FF_SPLIT_TW")) : 0;   // 0: by map size
+  bool ff_split_fused = !getenv("WX_NO_FF_SPLIT_FUSED");   // split-bf16 precision: the C = 128 FeedForward as one launch (wx_ff_split.h)
   bool embed_tail_split = !getenv("WX_NO_EMBED_TAIL_SPLIT");
   float* embed_tail = nullptr;
   size_t embed_tail_bytes = 0;
@@ -1246,6 +1249,7 @@ class Engine : public EngineBase {
   void profile(int on) override { prof_on = on != 0; detail_on = on > 1; family_on = on > 2; }
   int64_t n_two_stream_stages = 0;   // of the last forward
   int64_t n_split_gemms = 0;         // GEMM launches of the last forward that ran split-bf16 arithmetic
+  int64_t n_ff_split_fused = 0;      // ... of which FeedForward sub-blocks in one launch (wx_ff_split.h; counted as two GEMMs above)
   int split_bn64 = getenv("WX_SPLIT_BN64") ? atoi(getenv("WX_SPLIT_BN64")) : 1;   // 0: never the 64-column tiles of the badly quantised residual layers
   int64_t n_launches = 0;            // timed() calls of the last forward (one per kernel launch or launch + finish pair)
   bool query(const std::string& key, int64_t* v) override {
@@ -1253,6 +1257,7 @@ class Engine : public EngineBase {
     if (key == "launches") { *v = n_launches; return true; }
     if (key == "precision") { *v = sizeof(T) == 2 ? WX_PREC_BF16 : (split_mma ? WX_PREC_FP32_SPLIT : WX_PREC_FP32); return true; }
     if (key == "split_gemms") { *v = n_split_gemms; return true; }
+    if (key == "ff_split_fused") { *v = n_ff_split_fused; return true; }
     return false;
   }
   void profile_reset() override { drain(); stats.clear(); }
@@ -1704,6 +1709,25 @@ class Engine : public EngineBase {
       }
     }
     const float2* rs = stream_stats(x, ld, c, m);
+    if constexpr (sizeof(T) == 4) {
+      // split-bf16 precision, C = 128: both layers in one launch, the hidden tensor stays in registers (wx_ff_split.h)
+      if (split_mma && ff_split_fused && !dbg_flags && ws_dev && ff_split_supported(c, f.w1.n) && f.w1.cin == c && f.w2.cin == 4 * c &&
+          f.w1.kh == 1 && f.w2.kh == 1 && f.w1.bias >= 0 && f.w2.bias >= 0 && f.w1.colsum >= 0) {
+        FFSplitParams q{};
+        q.x = reinterpret_cast<float*>(x); q.ld = ld; q.M = m; q.hidden = 4 * c;
+        q.w1s = reinterpret_cast<const float*>(ws_dev + f.w1.wt); q.b1 = f_dev + f.w1.bias;
+        q.w2s = reinterpret_cast<const float*>(ws_dev + f.w2.wt); q.b2 = f_dev + f.w2.bias;
+        q.rowstat = rs; q.stat_tiles = stat_tiles_ready; q.stat_inv_c = 1.0f / (float)c;
+        q.stat_out = fuse_ln ? stat_dst(t0 + m, 1) + t0 : nullptr;
+        n_split_gemms += 2;
+        ++n_ff_split_fused;
+        timed("ff_split_fused", 16.0 * m * c * c, 2.0 * m * c * sizeof(T) + 8.0 * c * c * sizeof(T), [&] { launch_ff_split(c, q, cur_stream, ff_split_tw ? ff_split_tw : (cdiv(m, 128) >= 512 ? 2 : 1)); });
+        stat_tiles_ready = q.stat_out ? 1 : 0;
+        last_stat_slots = 1;
+        capture(dbg_name, x, h, w, c, ld, w);
+        return;
+      }
+    }
     // both layers on the persistent GEMM (stage 2 of the 0.25-degree model): the hidden tensor between them goes k-blocked
     blk_hidden = sizeof(T) == 2 && use_stream && use_dma && fuse_ln && !dbg_flags && f.w1.wt_kb >= 0 && f.w2.wt_kb >= 0 && c == 512 &&
                  (rule_rows > 0 ? rule_rows : (int64_t)m) >= stream_min_rows && f.w2.bias >= 0;
@@ -2020,6 +2044,7 @@ class Engine : public EngineBase {
   void core(const float* x_item) {
     n_two_stream_stages = 0;
     n_split_gemms = 0;
+    n_ff_split_fused = 0;
     n_launches = 0;
     // a1: pack + earth halo
     pack_input(x_item, xin, xin_planar, Hp + 2 * halo, 0, Hp, halo, 0, cfg.image_height);
