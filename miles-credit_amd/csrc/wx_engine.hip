@@ -988,7 +988,8 @@ class Engine : public EngineBase {
   int ff_split_max = getenv("WX_FF_SPLIT") ? atoi(getenv("WX_FF_SPLIT")) : 8;   // hidden ranges of the split fused FeedForward (0 / 1: off)
   bool attn_pack2 = !getenv("WX_NO_ATTN_PACK2");
   int ff_split_tw = getenv("WX_FF_SPLIT_TW") ? atoi(getenv("WX_FF_SPLIT_TW")) : 0;   // 0: by map size
-  bool ff_split_fused = !getenv("WX_NO_FF_SPLIT_FUSED");   // split-bf16 precision: the C = 128 FeedForward as one launch (wx_ff_split.h)
+  bool ff_split_fused = !getenv("WX_NO_FF_SPLIT_FUSED");   // split-bf16 precision: the C = 128 / 256 FeedForward as one launch (wx_ff_split.h)
+  bool ff_split_256 = !getenv("WX_NO_FF_SPLIT_256");
   bool embed_tail_split = !getenv("WX_NO_EMBED_TAIL_SPLIT");
   float* embed_tail = nullptr;
   size_t embed_tail_bytes = 0;
@@ -1710,8 +1711,8 @@ class Engine : public EngineBase {
     }
     const float2* rs = stream_stats(x, ld, c, m);
     if constexpr (sizeof(T) == 4) {
-      // split-bf16 precision, C = 128: both layers in one launch, the hidden tensor stays in registers (wx_ff_split.h)
-      if (split_mma && ff_split_fused && !dbg_flags && ws_dev && ff_split_supported(c, f.w1.n) && f.w1.cin == c && f.w2.cin == 4 * c &&
+      // split-bf16 precision, C = 128 / 256: both layers in one launch, the hidden tensor stays in registers (wx_ff_split.h)
+      if (split_mma && ff_split_fused && !dbg_flags && ws_dev && ff_split_supported(c, f.w1.n) && (c == 128 || ff_split_256) && f.w1.cin == c && f.w2.cin == 4 * c &&
           f.w1.kh == 1 && f.w2.kh == 1 && f.w1.bias >= 0 && f.w2.bias >= 0 && f.w1.colsum >= 0) {
         FFSplitParams q{};
         q.x = reinterpret_cast<float*>(x); q.ld = ld; q.M = m; q.hidden = 4 * c;

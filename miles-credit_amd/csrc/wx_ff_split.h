@@ -51,14 +51,18 @@ struct FFSplitParams {
   int hidden;            // 4 C
 };
 
-template <int C, int TW>
+template <int C, int TW, int HC>
 __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p) {
   constexpr int NW = 4;
-  static_assert(C == 128, "the stage geometry below (16 KB stages for both layers) is written for C = 128");
-  constexpr int HC = 128;                 // hidden units per chunk
+  static_assert(HC == 128 || HC == 64, "hidden units per chunk");
+  static_assert(C == 128 || (C == 256 && TW == 1), "16 KB stages: 128 weight rows x one K chunk; C = 256 has the registers for one token fragment");
   constexpr int KS1 = C / 32;             // layer-1 K steps per chunk
+  constexpr int KPS = 128 / HC;           // ... per layer-1 stage (HC = 64: a stage holds 64 hidden rows x two K chunks)
+  constexpr int S1 = KS1 / KPS;           // layer-1 stages per chunk
   constexpr int KS2 = HC / 32;            // layer-2 K steps per chunk
   constexpr int FN1 = HC / 16, FN2 = C / 16;
+  constexpr int NH = C / 128;             // layer-2 stages per K chunk (128 output channels each)
+  constexpr int SPC = S1 + KS2 * NH;      // stages per hidden chunk
   constexpr int STAGE = 128 * 128;        // 128 weight rows x one 128-byte K chunk
   constexpr int NST = 3;                  // 2 and 4 time the same
   constexpr int PCS = STAGE / 1024 / NW;  // DMA pieces per wave and stage
@@ -70,9 +74,10 @@ __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, g = lane >> 4;
   const int nch = p.hidden / HC;
-  const int total = nch * (KS1 + KS2);
+  const int total = nch * SPC;
 
-  // ---- weight ring: stage s = (chunk, r): r < KS1 -> W1' rows [chunk * 128, + 128) x K chunk r;  else W2 rows [0, C) x K chunk chunk * 4 + (r - KS1)
+  // ---- weight ring: stage s = (chunk, r): r < KS1 -> W1' rows [chunk * 128, + 128) x K chunk r;  else, q = r - KS1, W2 rows
+  //      [128 (q % NH), + 128) x K chunk chunk * 4 + q / NH
   const int lrow = lane >> 3, lslot = lane & 7;
   // piece i of a wave covers stage rows (i * NW + wave) * 8 + lrow: the slot swizzle ((row >> 1) & 7) is the same for every i, so one
   // per-lane offset per layer serves all pieces and the 32-row steps between them go into the scalar base
@@ -90,17 +95,21 @@ __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p)
   auto issue = [&]() {
     const unsigned so = i_stage * STAGE;
     if constexpr (WX_FFS_DBG & 32) {
-    } else if (i_r < KS1) {
-      const char* sb = w1b + ((int64_t)i_c * HC * C + i_r * 32) * 4;
+    } else if (i_r < S1) {
+      const char* sb = w1b + ((int64_t)i_c * HC * C + i_r * KPS * 32) * 4;
 #pragma unroll
-      for (int i = 0; i < PCS; ++i) lds_dma16_sv(sb + (int64_t)i * NW * 8 * C * 4, off1, dst[i] + so);
+      for (int i = 0; i < PCS; ++i) {   // stage row 32 i + ..: hidden row (32 i) % HC of K chunk (32 i) / HC
+        const int rr = (32 * i) % HC, kc = (32 * i) / HC;
+        lds_dma16_sv(sb + (int64_t)rr * C * 4 + kc * 128, off1, dst[i] + so);
+      }
     } else {
-      const char* sb = w2b + ((int64_t)i_c * HC + (i_r - KS1) * 32) * 4;
+      const int q = i_r - S1;   // K chunk q / NH of this hidden chunk, output channels [128 (q % NH), + 128)
+      const char* sb = w2b + ((int64_t)(q % NH) * 128 * p.hidden + (int64_t)i_c * HC + (q / NH) * 32) * 4;
 #pragma unroll
       for (int i = 0; i < PCS; ++i) lds_dma16_sv(sb + (int64_t)i * NW * 8 * p.hidden * 4, off2, dst[i] + so);
     }
     i_stage = (i_stage + 1 == NST) ? 0 : i_stage + 1;
-    if (++i_r == KS1 + KS2) { i_r = 0; ++i_c; }
+    if (++i_r == SPC) { i_r = 0; ++i_c; }
   };
 
   // ---- prologue: biases -> LDS, this lane's token row -> registers ------------------------------------------------------------------
@@ -178,27 +187,30 @@ __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p)
   for (int c = 0; c < nch; ++c) {
     // ---- layer 1 of this chunk: acc1[a] (hidden units c * 128 + a * 16 + 4 g ..) over the C channels --------------------------------
 #pragma unroll
-    for (int r = 0; r < KS1; ++r) {
+    for (int r = 0; r < S1; ++r) {
       if (issued < total) { issue(); ++issued; }
       const char* cur = smem + c_stage * STAGE;
 #pragma unroll
-      for (int a = 0; a < FN1; ++a) {
-        uint4 wh, wl;
-        if constexpr (WX_FFS_DBG & 4) { wh = xh[0][r]; wl = xl[0][r]; }
-        else {
-          wh = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * 128 + so0);
-          wl = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * 128 + so1);
-        }
+      for (int kc = 0; kc < KPS; ++kc)
 #pragma unroll
-        for (int b = 0; b < TW; ++b) {
-          if constexpr (WX_FFS_DBG & 2) { acc1[a][b][0] += __builtin_bit_cast(float, wh.x ^ wl.y); }
+        for (int a = 0; a < FN1; ++a) {
+          const int ks = r * KPS + kc;
+          uint4 wh, wl;
+          if constexpr (WX_FFS_DBG & 4) { wh = xh[0][ks]; wl = xl[0][ks]; }
           else {
-            acc1[a][b] = mma_sub<bf16_t>(wl, xh[b][r], acc1[a][b]);
-            acc1[a][b] = mma_sub<bf16_t>(wh, xl[b][r], acc1[a][b]);
-            acc1[a][b] = mma_sub<bf16_t>(wh, xh[b][r], acc1[a][b]);
+            wh = *reinterpret_cast<const uint4*>(cur + w_base + (kc * HC + a * 16) * 128 + so0);
+            wl = *reinterpret_cast<const uint4*>(cur + w_base + (kc * HC + a * 16) * 128 + so1);
+          }
+#pragma unroll
+          for (int b = 0; b < TW; ++b) {
+            if constexpr (WX_FFS_DBG & 2) { acc1[a][b][0] += __builtin_bit_cast(float, wh.x ^ wl.y); }
+            else {
+              acc1[a][b] = mma_sub<bf16_t>(wl, xh[b][ks], acc1[a][b]);
+              acc1[a][b] = mma_sub<bf16_t>(wh, xl[b][ks], acc1[a][b]);
+              acc1[a][b] = mma_sub<bf16_t>(wh, xh[b][ks], acc1[a][b]);
+            }
           }
         }
-      }
       finish_step();
     }
     // ---- + bias, GELU (exact); the values stay in acc1: they are layer 2's activation fragments ----------------------------------------
@@ -213,37 +225,43 @@ __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p)
     // ---- layer 2: K chunk j of this hidden chunk = fragments (2 j, 2 j + 1) of acc1 ------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < KS2; ++j) {
-      if (issued < total) { issue(); ++issued; }
-      const char* cur = smem + c_stage * STAGE;
       uint4 hh[TW], hl[TW];
 #pragma unroll
-      for (int b = 0; b < TW; ++b) {
-        const float v[8] = {acc1[2 * j][b][0], acc1[2 * j][b][1], acc1[2 * j][b][2], acc1[2 * j][b][3],
-                            acc1[2 * j + 1][b][0], acc1[2 * j + 1][b][1], acc1[2 * j + 1][b][2], acc1[2 * j + 1][b][3]};
-        if constexpr (WX_FFS_DBG & 8) {
-          hh[b] = uint4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
-          hl[b] = uint4{__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
-        } else split_bf16x8(v, hh[b], hl[b]);
-      }
+      for (int h = 0; h < NH; ++h) {
+        if (issued < total) { issue(); ++issued; }
+        const char* cur = smem + c_stage * STAGE;
+        if (h == 0) {
 #pragma unroll
-      for (int a = 0; a < FN2; ++a) {
-        uint4 wh, wl;
-        if constexpr (WX_FFS_DBG & 4) { wh = hh[0]; wl = hl[0]; }
-        else {
-          wh = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * 128 + so0);
-          wl = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * 128 + so1);
-        }
-#pragma unroll
-        for (int b = 0; b < TW; ++b) {
-          if constexpr (WX_FFS_DBG & 2) { acc2[a][b][0] += __builtin_bit_cast(float, wh.x ^ wl.y ^ hh[b].x ^ hl[b].y); }
-          else {
-            acc2[a][b] = mma_sub<bf16_t>(wl, hh[b], acc2[a][b]);
-            acc2[a][b] = mma_sub<bf16_t>(wh, hl[b], acc2[a][b]);
-            acc2[a][b] = mma_sub<bf16_t>(wh, hh[b], acc2[a][b]);
+          for (int b = 0; b < TW; ++b) {
+            const float v[8] = {acc1[2 * j][b][0], acc1[2 * j][b][1], acc1[2 * j][b][2], acc1[2 * j][b][3],
+                                acc1[2 * j + 1][b][0], acc1[2 * j + 1][b][1], acc1[2 * j + 1][b][2], acc1[2 * j + 1][b][3]};
+            if constexpr (WX_FFS_DBG & 8) {
+              hh[b] = uint4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+              hl[b] = uint4{__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
+            } else split_bf16x8(v, hh[b], hl[b]);
           }
         }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          uint4 wh, wl;
+          if constexpr (WX_FFS_DBG & 4) { wh = hh[0]; wl = hl[0]; }
+          else {
+            wh = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * 128 + so0);
+            wl = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * 128 + so1);
+          }
+#pragma unroll
+          for (int b = 0; b < TW; ++b) {
+            f32x4_t& d = acc2[h * 8 + a][b];
+            if constexpr (WX_FFS_DBG & 2) { d[0] += __builtin_bit_cast(float, wh.x ^ wl.y ^ hh[b].x ^ hl[b].y); }
+            else {
+              d = mma_sub<bf16_t>(wl, hh[b], d);
+              d = mma_sub<bf16_t>(wh, hl[b], d);
+              d = mma_sub<bf16_t>(wh, hh[b], d);
+            }
+          }
+        }
+        finish_step();
       }
-      finish_step();
     }
 #pragma unroll
     for (int a = 0; a < FN1; ++a)
@@ -279,12 +297,15 @@ __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p)
   }
 }
 
-inline bool ff_split_supported(int c, int hidden) { return c == 128 && hidden == 4 * c; }
+inline bool ff_split_supported(int c, int hidden) { return (c == 128 || c == 256) && hidden == 4 * c; }
 
-template <int TW>
+#ifndef WX_FFS_HC
+#define WX_FFS_HC 128
+#endif
+template <int C, int TW>
 inline void launch_ff_split_tw(const FFSplitParams& p, hipStream_t stream) {
-  const int LDS = 3 * 128 * 128 + (p.hidden + 128) * 4;
-  auto kern = ff_split_kernel<128, TW>;
+  const int LDS = 3 * 128 * 128 + (p.hidden + C) * 4;
+  auto kern = ff_split_kernel<C, TW, WX_FFS_HC>;
   static uint64_t attr_done_mask = 0;
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -293,11 +314,13 @@ inline void launch_ff_split_tw(const FFSplitParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(p.M, 64 * TW)), dim3(256), LDS, stream, p);
   WX_HIP(hipGetLastError());
 }
-// tw: token fragments per wave (2: 128-token workgroups; 1: 64-token ones, for maps too small to fill the chip with the larger tile)
+// tw: token fragments per wave (C = 128 only: 2 = 128-token workgroups; 1 = 64-token ones, for maps too small to fill the chip with the
+// larger tile; C = 256 always runs 1)
 inline void launch_ff_split(int c, const FFSplitParams& p, hipStream_t stream, int tw = 2) {
   if (!ff_split_supported(c, p.hidden)) throw std::runtime_error("ff_split: unsupported width");
-  if (tw == 2) launch_ff_split_tw<2>(p, stream);
-  else if (tw == 1) launch_ff_split_tw<1>(p, stream);
+  if (c == 256) launch_ff_split_tw<256, 1>(p, stream);
+  else if (tw == 2) launch_ff_split_tw<128, 2>(p, stream);
+  else if (tw == 1) launch_ff_split_tw<128, 1>(p, stream);
   else throw std::runtime_error("ff_split: unknown tile form");
 }
 

@@ -337,7 +337,7 @@ def test_split_precision_is_what_ran():
 
 
 def test_split_feedforward_one_launch():
-    """fp32s, C = 128 stages: the FeedForward sub-block runs as ONE launch (wx_ff_split.h: the hidden tensor never reaches HBM; GELU by
+    """fp32s, C = 128 / 256 stages: the FeedForward sub-block runs as ONE launch (wx_ff_split.h: the hidden tensor never reaches HBM; GELU by
     the Abramowitz-Stegun erf, 4.7e-7 absolute).  Against the two-GEMM form (WX_NO_FF_SPLIT_FUSED=1, libm erff) the forward differs by
     rounding order only (<= 2e-5 of max|y|, inside the mode's 1e-4 budget against the reference), the 64- and 128-token tile forms are
     bit-identical (a token's arithmetic does not depend on its tile), and wx_query says how many sub-blocks took the kernel."""
@@ -348,8 +348,11 @@ def test_split_feedforward_one_launch():
     tw1 = _engine("C1", "fp32s", {"WX_FF_SPLIT_TW": "1"})
     tw2 = _engine("C1", "fp32s", {"WX_FF_SPLIT_TW": "2"})
     yf, yp = _forward(fused, x), _forward(pair, x)
-    n128 = sum(2 * d for d, c in zip(cfg.depth, cfg.dim) if c == 128)
-    assert n128 > 0 and fused.query("ff_split_fused") == n128 and pair.query("ff_split_fused") == 0
+    n_sub = sum(2 * d for d, c in zip(cfg.depth, cfg.dim) if c in (128, 256))
+    assert n_sub > 0 and fused.query("ff_split_fused") == n_sub and pair.query("ff_split_fused") == 0
+    only128 = _engine("C1", "fp32s", {"WX_NO_FF_SPLIT_256": "1"})
+    _forward(only128, x)
+    assert only128.query("ff_split_fused") == sum(2 * d for d, c in zip(cfg.depth, cfg.dim) if c == 128)
     assert fused.query("split_gemms") == pair.query("split_gemms")
     assert fused.query("launches") < pair.query("launches")
     dev = float((yf - yp).abs().max() / yp.abs().max())

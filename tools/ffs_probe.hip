@@ -1,5 +1,5 @@
 // Dev tool (GPU box): the fused split-bf16 FeedForward (wx_ff_split.h) alone, on stage 0 of the 0.25-degree model (320 000 tokens, C = 128):
-// sampled fp64 check, HIP-event timing of both tile forms.  Build with -DWX_FFS_DBG=<bits> to take pieces out (see the header).
+// sampled fp64 check, HIP-event timing of both tile forms (ffs_probe <tokens> 256: stage 1, C = 256).  Build with -DWX_FFS_DBG=<bits> to take pieces out (see the header).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I miles-credit_amd/csrc tools/ffs_probe.hip -o tools/_build/ffs_probe
 #include <cmath>
 #include <cstdio>
@@ -18,13 +18,14 @@ static void* dalloc(size_t n) {
 }
 
 int main(int argc, char** argv) {
-  const int M = argc > 1 ? atoi(argv[1]) : 320000, C = 128, H = 512;
+  const int C = argc > 2 ? atoi(argv[2]) : 128, H = 4 * C;
+  const int M = argc > 1 ? atoi(argv[1]) : (C == 128 ? 320000 : 80000);
   std::mt19937 rng(11);
   std::normal_distribution<float> nd(0.f, 1.f);
   std::vector<float> hx((size_t)M * C), w1((size_t)H * C), w2((size_t)C * H), b1(H), b2(C);
   for (auto& v : hx) v = nd(rng);
-  for (auto& v : w1) v = nd(rng) * 0.09f;
-  for (auto& v : w2) v = nd(rng) * 0.045f;
+  for (auto& v : w1) v = nd(rng) / std::sqrt((float)C);
+  for (auto& v : w2) v = nd(rng) / std::sqrt((float)H);
   for (auto& v : b1) v = nd(rng) * 0.1f;
   for (auto& v : b2) v = nd(rng) * 0.1f;
   std::vector<float2> st(M);
@@ -54,6 +55,7 @@ int main(int argc, char** argv) {
   p.x = dx; p.ld = C; p.M = M; p.w1s = dw1; p.b1 = db1; p.w2s = dw2; p.b2 = db2; p.rowstat = dst; p.stat_tiles = 0; p.stat_inv_c = 1.f / C;
   p.stat_out = dso; p.hidden = H;
   for (int tw : {1, 2}) {
+    if (C == 256 && tw == 2) continue;
     WX_HIP(hipMemcpyAsync(dx, dx0, hx.size() * 4, hipMemcpyDeviceToDevice, s));
     launch_ff_split(C, p, s, tw);
     WX_HIP(hipStreamSynchronize(s));
