@@ -883,6 +883,12 @@ class Engine : public EngineBase {
               ffs[k]->pack_pp = pack_ff(*ffs[k], c, 4 * c, &prev[k]->out, &next[k]->qkv);
             }
         }
+      } else {   // fp32 storage: the split-bf16 one-launch FeedForward's to_qkv tail (wx_ff_split.h POST) reads the next attention's weights in place
+        std::vector<BlockL>& bs = stages[s].blocks;
+        for (size_t d = 0; d < bs.size(); ++d) {
+          if (bs[d].la.wsz > 1) bs[d].sf.next = &bs[d].la;
+          if (d + 1 < bs.size() && bs[d + 1].sa.wsz > 1) bs[d].lf.next = &bs[d + 1].sa;
+        }
       }
     }
     const int last = cfg.dim[3];
@@ -990,10 +996,13 @@ class Engine : public EngineBase {
   int ff_split_tw = getenv("WX_FF_SPLIT_TW") ? atoi(getenv("WX_FF_SPLIT_TW")) : 0;   // 0: by map size
   bool ff_split_fused = !getenv("WX_NO_FF_SPLIT_FUSED");   // split-bf16 precision: the C = 128 / 256 FeedForward as one launch (wx_ff_split.h)
   bool ff_split_256 = !getenv("WX_NO_FF_SPLIT_256");
+  bool ff_split_pre = !getenv("WX_NO_FF_SPLIT_PRE");       // ... with the attention's out-projection in front (its PRE form)
+  bool ff_split_post = !getenv("WX_NO_FF_SPLIT_POST");     // ... and the next attention's LayerNorm + to_qkv behind (its POST form)
   bool embed_tail_split = !getenv("WX_NO_EMBED_TAIL_SPLIT");
   float* embed_tail = nullptr;
   size_t embed_tail_bytes = 0;
   bool embed_ride4 = !getenv("WX_NO_EMBED_RIDE4");
+  bool pack_align = !getenv("WX_NO_PACK_ALIGN");   // pack_input: block origin shifted onto the source's 256-byte boundaries
   bool stat_share = !getenv("WX_NO_EMBED_STATS");
   int skinny_max = getenv("WX_SKINNY_MAX") ? atoi(getenv("WX_SKINNY_MAX")) : 8;          // K ranges per tile (0 / 1: off)
   int skinny_steps = getenv("WX_SKINNY_STEPS") ? std::max(1, atoi(getenv("WX_SKINNY_STEPS"))) : 2;   // 128-byte K steps per range, at least
@@ -1250,6 +1259,8 @@ class Engine : public EngineBase {
   void profile(int on) override { prof_on = on != 0; detail_on = on > 1; family_on = on > 2; }
   int64_t n_two_stream_stages = 0;   // of the last forward
   int64_t n_split_gemms = 0;         // GEMM launches of the last forward that ran split-bf16 arithmetic
+  int64_t n_ff_split_pre = 0;        // ... of which with the out-projection in front (three GEMMs)
+  int64_t n_ff_split_post = 0;       // ... of which also with the next to_qkv behind (four GEMMs)
   int64_t n_ff_split_fused = 0;      // ... of which FeedForward sub-blocks in one launch (wx_ff_split.h; counted as two GEMMs above)
   int split_bn64 = getenv("WX_SPLIT_BN64") ? atoi(getenv("WX_SPLIT_BN64")) : 1;   // 0: never the 64-column tiles of the badly quantised residual layers
   int64_t n_launches = 0;            // timed() calls of the last forward (one per kernel launch or launch + finish pair)
@@ -1259,6 +1270,8 @@ class Engine : public EngineBase {
     if (key == "precision") { *v = sizeof(T) == 2 ? WX_PREC_BF16 : (split_mma ? WX_PREC_FP32_SPLIT : WX_PREC_FP32); return true; }
     if (key == "split_gemms") { *v = n_split_gemms; return true; }
     if (key == "ff_split_fused") { *v = n_ff_split_fused; return true; }
+    if (key == "ff_split_pre") { *v = n_ff_split_pre; return true; }
+    if (key == "ff_split_post") { *v = n_ff_split_post; return true; }
     return false;
   }
   void profile_reset() override { drain(); stats.clear(); }
@@ -1647,8 +1660,32 @@ class Engine : public EngineBase {
     return cdiv(m, 64) >= ff_min_wgs;
   }
   bool ff_takes_out(const FFL& f) const { return sizeof(T) == 2 && fuse_ff && fuse_out && f.pack_pre >= 0 && !dbg_on && ff_big_enough() && cfg.dim_head == 32; }
-  bool ff_takes_out(const FFL& f, const AttnL& a) const { return ff_takes_out(f) && !attn_block_ok(a, cur_stage); }
-  bool ff_makes_qkv(const FFL& f) const { return ff_takes_out(f) && fuse_qkv && f.pack_pp >= 0 && !band_on && !(f.next && attn_block_ok(*f.next, cur_stage)); }
+  // split-bf16 precision: the one-launch FeedForward (wx_ff_split.h) of this layer ...
+  bool ff_split_fused_ok(const FFL& f, int c) const {
+    return sizeof(T) == 4 && split_mma && ff_split_fused && !dbg_flags && ws_dev && ff_split_supported(c, f.w1.n) && (c == 128 || ff_split_256) && f.w1.cin == c &&
+           f.w2.cin == 4 * c && f.w1.kh == 1 && f.w2.kh == 1 && f.w1.bias >= 0 && f.w2.bias >= 0 && f.w1.colsum >= 0;
+  }
+  // ... and whether it also applies the attention's out-projection + residual in front (its PRE form: to_out's launch, the write of x1 by
+  // one kernel and its read by the next are gone)
+  bool ff_split_takes_out(const FFL& f, const AttnL& a) const {
+    if (cur_stage < 0 || cur_stage > 3) return false;
+    const int c = cfg.dim[cur_stage];
+    return ff_split_fused_ok(f, c) && ff_split_pre && fuse_ln && !dbg_on && !band_on && rwn < 0 && a.out.cin == c && a.out.n == c && a.out.kh == 1 && a.out.kw == 1 && a.out.bias >= 0;
+  }
+  bool ff_takes_out(const FFL& f, const AttnL& a) const {
+    if constexpr (sizeof(T) == 4) return ff_split_takes_out(f, a);
+    return ff_takes_out(f) && !attn_block_ok(a, cur_stage);
+  }
+  bool ff_makes_qkv(const FFL& f) const {
+    if constexpr (sizeof(T) == 4) {   // split-bf16 precision: the to_qkv tail of the one-launch FeedForward (its POST form; rides on the PRE form)
+      if (cur_stage < 0 || cur_stage > 3 || !f.next) return false;
+      const int c = cfg.dim[cur_stage];
+      const ConvW& q = f.next->qkv;
+      return ff_split_fused_ok(f, c) && ff_split_pre && ff_split_post && fuse_ln && !dbg_on && !band_on && rwn < 0 && f.next->wsz > 1 && q.wt >= 0 && q.cin == c &&
+             q.n == 3 * c && q.kh == 1 && q.kw == 1 && q.bias >= 0 && q.colsum >= 0;
+    }
+    return ff_takes_out(f) && fuse_qkv && f.pack_pp >= 0 && !band_on && !(f.next && attn_block_ok(*f.next, cur_stage));
+  }
   bool ff_split_ok(const FFL& f, int s, const AttnL* pre) const {
     const int c = cfg.dim[s];
     const int64_t m = (int64_t)sh[s] * sw[s];
@@ -1709,20 +1746,34 @@ class Engine : public EngineBase {
         return;
       }
     }
-    const float2* rs = stream_stats(x, ld, c, m);
+    if (pre && !(sizeof(T) == 4 && ff_split_fused_ok(f, c))) throw StateError("feedforward: out-projection deferred to a layer that cannot take it");
+    const float2* rs = pre ? nullptr : stream_stats(x, ld, c, m);   // the PRE form takes the statistics of x1 itself
     if constexpr (sizeof(T) == 4) {
       // split-bf16 precision, C = 128 / 256: both layers in one launch, the hidden tensor stays in registers (wx_ff_split.h)
-      if (split_mma && ff_split_fused && !dbg_flags && ws_dev && ff_split_supported(c, f.w1.n) && (c == 128 || ff_split_256) && f.w1.cin == c && f.w2.cin == 4 * c &&
-          f.w1.kh == 1 && f.w2.kh == 1 && f.w1.bias >= 0 && f.w2.bias >= 0 && f.w1.colsum >= 0) {
+      if (ff_split_fused_ok(f, c)) {
         FFSplitParams q{};
         q.x = reinterpret_cast<float*>(x); q.ld = ld; q.M = m; q.hidden = 4 * c;
         q.w1s = reinterpret_cast<const float*>(ws_dev + f.w1.wt); q.b1 = f_dev + f.w1.bias;
         q.w2s = reinterpret_cast<const float*>(ws_dev + f.w2.wt); q.b2 = f_dev + f.w2.bias;
-        q.rowstat = rs; q.stat_tiles = stat_tiles_ready; q.stat_inv_c = 1.0f / (float)c;
+        q.rowstat = rs; q.stat_tiles = pre ? 0 : stat_tiles_ready; q.stat_inv_c = 1.0f / (float)c;
         q.stat_out = fuse_ln ? stat_dst(t0 + m, 1) + t0 : nullptr;
+        if (pre) {
+          q.o = reinterpret_cast<const float*>(attn_o + t0 * c); q.ld_o = c;
+          q.wos = reinterpret_cast<const float*>(ws_dev + pre->out.wt); q.bo = f_dev + pre->out.bias;
+          ++n_split_gemms;
+          ++n_ff_split_pre;
+        }
+        const bool post = pre && ff_makes_qkv(f);
+        if (post) {
+          q.qkv = reinterpret_cast<float*>(scratch); q.ld_qkv = 3 * c;
+          q.wqs = reinterpret_cast<const float*>(ws_dev + f.next->qkv.wt); q.bq = f_dev + f.next->qkv.bias;
+          ++n_split_gemms;
+          ++n_ff_split_post;
+        }
         n_split_gemms += 2;
         ++n_ff_split_fused;
-        timed("ff_split_fused", 16.0 * m * c * c, 2.0 * m * c * sizeof(T) + 8.0 * c * c * sizeof(T), [&] { launch_ff_split(c, q, cur_stream, ff_split_tw ? ff_split_tw : (cdiv(m, 128) >= 512 ? 2 : 1)); });
+        timed(post ? "out_ff_qkv_split_fused" : pre ? "out_ff_split_fused" : "ff_split_fused", (post ? 24.0 : pre ? 18.0 : 16.0) * m * c * c,
+              (post ? 6.0 : pre ? 3.0 : 2.0) * m * c * sizeof(T) + (post ? 12.0 : pre ? 9.0 : 8.0) * c * c * sizeof(T), [&] { launch_ff_split(c, q, cur_stream, ff_split_tw ? ff_split_tw : (cdiv(m, 128) >= 512 ? 2 : 1)); });
         stat_tiles_ready = q.stat_out ? 1 : 0;
         last_stat_slots = 1;
         capture(dbg_name, x, h, w, c, ld, w);
@@ -1803,8 +1854,12 @@ class Engine : public EngineBase {
     p.mirror = cfg.pad_activate == 2;
     p.split_planar = (split_mma && dst == xin && xs_planes) ? xs_planes : nullptr;
     if (nrows <= 0) return;
+    // channel group = all of cpad0 while its [cg][65] fp32 tile stays under 64 KB of LDS; block origin shifted so that the 256-byte source
+    // runs of the interior rows are line-aligned (wx_elem.h)
+    const int cg = std::min(cpad0, 224);
+    const int xshift = pack_align ? (64 - p.pl % 64) % 64 : 0;
     timed("pack_input", 0.0, (double)C_in * nrows * cfg.image_width * 4.0 + (double)nrows * Wp * cpad0 * sizeof(T), [&] {
-      hipLaunchKernelGGL(pack_input_kernel<T>, dim3(cdiv(Wp, 64), nrows), dim3(256), 0, cur_stream, p);
+      hipLaunchKernelGGL(pack_input_kernel<T>, dim3(cdiv(Wp + xshift, 64), nrows), dim3(256), (size_t)cg * 65 * sizeof(float), cur_stream, p, cg, xshift);
       WX_HIP(hipGetLastError());
     });
   }
@@ -2046,6 +2101,8 @@ class Engine : public EngineBase {
     n_two_stream_stages = 0;
     n_split_gemms = 0;
     n_ff_split_fused = 0;
+    n_ff_split_pre = 0;
+    n_ff_split_post = 0;
     n_launches = 0;
     // a1: pack + earth halo
     pack_input(x_item, xin, xin_planar, Hp + 2 * halo, 0, Hp, halo, 0, cfg.image_height);

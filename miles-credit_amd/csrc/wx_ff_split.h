@@ -49,10 +49,24 @@ struct FFSplitParams {
   float stat_inv_c;
   float2* stat_out;      // [M] (sum, sum sq) of the output rows, or nullptr
   int hidden;            // 4 C
+  // PRE instantiations (the attention's out-projection fused in front; crossformer.py:314-316 to_out + the residual of :351-356):
+  // x1 = x + Wout . o + bo replaces x before the block above -- o = the attention output [M][ld_o], Wout in the split arena's encoding,
+  // LayerNorm statistics of x1 taken in registers (two-pass); rowstat / stat_tiles are not read
+  const float* o;
+  int64_t ld_o;
+  const float* wos;      // split arena: [C][C] rows, chunk-encoded
+  const float* bo;       // [C]
+  // POST instantiations (the NEXT attention's LayerNorm + to_qkv fused behind; crossformer.py:285-289): q|k|v = Wqkv' . LN(x_out) + bq',
+  // LayerNorm statistics of the output rows two-pass in registers, the 3C columns as 3C / 128 more layer-1-shaped chunks of the ring
+  float* qkv;            // [M][ld_qkv] or nullptr
+  int64_t ld_qkv;
+  const float* wqs;      // split arena: [3C][C] rows (gain-folded), chunk-encoded
+  const float* bq;       // [3C] folded bias
 };
 
-template <int C, int TW, int HC>
+template <int C, int TW, int HC, bool PRE = false, bool POST = false>
 __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p) {
+  static_assert(!POST || HC == 128, "the to_qkv tail walks 128-column chunks");
   constexpr int NW = 4;
   static_assert(HC == 128 || HC == 64, "hidden units per chunk");
   static_assert(C == 128 || (C == 256 && TW == 1), "16 KB stages: 128 weight rows x one K chunk; C = 256 has the registers for one token fragment");
@@ -69,12 +83,17 @@ __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_b1 = reinterpret_cast<float*>(smem + NST * STAGE);   // [hidden]
   float* s_b2 = s_b1 + p.hidden;                                // [C]
+  float* s_bo = s_b2 + C;                                       // [C] (PRE)
+  constexpr int NPRE = PRE ? (C / 32) * NH : 0;                 // out-projection stages ahead of the feed-forward's: (K chunk j, 128 output channels h)
+  constexpr int NQC = 3 * C / 128;                              // POST: 128-column chunks of q|k|v
+  constexpr int NPOST = POST ? NQC * S1 : 0;                    // ... and their stages behind the feed-forward's
+  float* s_bq = s_bo + C;                                       // [3C] (POST)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, g = lane >> 4;
   const int nch = p.hidden / HC;
-  const int total = nch * SPC;
+  const int total = NPRE + nch * SPC + NPOST;
 
   // ---- weight ring: stage s = (chunk, r): r < KS1 -> W1' rows [chunk * 128, + 128) x K chunk r;  else, q = r - KS1, W2 rows
   //      [128 (q % NH), + 128) x K chunk chunk * 4 + q / NH
@@ -85,15 +104,35 @@ __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p)
   const unsigned piece = (unsigned)((lslot ^ stage_swz<128>(row0)) * 16);
   const unsigned off1 = (unsigned)(row0 * C * 4) + piece;
   const unsigned off2 = (unsigned)(row0 * p.hidden * 4) + piece;
+  const unsigned offo = (unsigned)(row0 * C * 4) + piece;
   unsigned dst[PCS];
 #pragma unroll
   for (int i = 0; i < PCS; ++i) dst[i] = lds_addr_sgpr(smem + (i * NW + wave) * 1024);
   const char* w1b = reinterpret_cast<const char*>(p.w1s);
   const char* w2b = reinterpret_cast<const char*>(p.w2s);
-  int i_c = 0, i_r = 0;
+  int i_c = 0, i_r = 0, i_pre = 0;
   unsigned i_stage = 0;
   auto issue = [&]() {
     const unsigned so = i_stage * STAGE;
+    if (PRE && i_pre < NPRE) {   // Wout rows [128 (i_pre % NH), + 128) x K chunk i_pre / NH
+      const char* sb = reinterpret_cast<const char*>(p.wos) + ((int64_t)(i_pre % NH) * 128 * C + (i_pre / NH) * 32) * 4;
+#pragma unroll
+      for (int i = 0; i < PCS; ++i) lds_dma16_sv(sb + (int64_t)i * NW * 8 * C * 4, offo, dst[i] + so);
+      ++i_pre;
+      i_stage = (i_stage + 1 == NST) ? 0 : i_stage + 1;
+      return;
+    }
+    if (POST && i_c >= nch) {   // Wqkv' rows [(i_c - nch) * 128, + 128) x K chunk(s) of stage i_r: layer 1's stage shape
+      const char* sb = reinterpret_cast<const char*>(p.wqs) + ((int64_t)(i_c - nch) * HC * C + i_r * KPS * 32) * 4;
+#pragma unroll
+      for (int i = 0; i < PCS; ++i) {
+        const int rr = (32 * i) % HC, kc = (32 * i) / HC;
+        lds_dma16_sv(sb + (int64_t)rr * C * 4 + kc * 128, off1, dst[i] + so);
+      }
+      i_stage = (i_stage + 1 == NST) ? 0 : i_stage + 1;
+      if (++i_r == S1) { i_r = 0; ++i_c; }
+      return;
+    }
     if constexpr (WX_FFS_DBG & 32) {
     } else if (i_r < S1) {
       const char* sb = w1b + ((int64_t)i_c * HC * C + i_r * KPS * 32) * 4;
@@ -115,23 +154,34 @@ __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p)
   // ---- prologue: biases -> LDS, this lane's token row -> registers ------------------------------------------------------------------
   for (int i = tid; i < p.hidden; i += 64 * NW) s_b1[i] = p.b1[i];
   if (tid < C) s_b2[tid] = p.b2[tid];
+  if (PRE && tid < C) s_bo[tid] = p.bo[tid];
+  if constexpr (POST)
+    for (int i = tid; i < 3 * C; i += 64 * NW) s_bq[i] = p.bq[i];
   int m[TW];
   bool row_ok[TW];
   uint4 xh[TW][KS1], xl[TW][KS1];
+  float4 xres[PRE ? TW : 1][PRE ? C / 16 : 1];   // PRE: the residual rows, requested here so that their latency passes under the out-projection's
+                                                // MFMAs (the registers are layer 1's accumulators, dead until then)
 #pragma unroll
   for (int b = 0; b < TW; ++b) {
     m[b] = blockIdx.x * (16 * NW * TW) + (wave * TW + b) * 16 + li;
     row_ok[b] = m[b] < p.M;
     m[b] = row_ok[b] ? m[b] : p.M - 1;   // rows beyond M re-read the last one (never stored)
-    const float* xrow = p.x + (int64_t)m[b] * p.ld;
+    if constexpr (PRE) {
+      const float* rrow = p.x + (int64_t)m[b] * p.ld;
+#pragma unroll
+      for (int a = 0; a < C / 16; ++a) xres[b][a] = *reinterpret_cast<const float4*>(rrow + a * 16 + g * 4);
+    }
+    const float* xrow = PRE ? p.o + (int64_t)m[b] * p.ld_o : p.x + (int64_t)m[b] * p.ld;   // PRE: the attention output's fragments first
     uint4 xr[KS1][2];   // [k step][channels 32 ks + 4 g .. | 32 ks + 16 + 4 g ..]
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
       xr[ks][0] = *reinterpret_cast<const uint4*>(xrow + ks * 32 + g * 4);
       xr[ks][1] = *reinterpret_cast<const uint4*>(xrow + ks * 32 + 16 + g * 4);
     }
-    float mean, rstd;
-    if (p.stat_tiles == 0) {
+    float mean = 0.f, rstd = 1.f;
+    if constexpr (PRE) {
+    } else if (p.stat_tiles == 0) {
       const float2 st = p.rowstat[m[b]];
       mean = st.x; rstd = st.y;
     } else {
@@ -184,6 +234,68 @@ __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p)
     c_stage = (c_stage + 1 == NST) ? 0 : c_stage + 1;
     ++step;
   };
+  if constexpr (PRE) {
+    // ---- x1 = x + Wout . o + bo: acc2[C][16 tokens] over the C attention-output channels (xh / xl hold o's fragments) -------------------
+#pragma unroll
+    for (int j = 0; j < KS1; ++j) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if (issued < total) { issue(); ++issued; }
+        const char* cur = smem + c_stage * STAGE;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const uint4 wh = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * 128 + so0);
+          const uint4 wl = *reinterpret_cast<const uint4*>(cur + w_base + a * 16 * 128 + so1);
+#pragma unroll
+          for (int b = 0; b < TW; ++b) {
+            f32x4_t& d = acc2[h * 8 + a][b];
+            d = mma_sub<bf16_t>(wl, xh[b][j], d);
+            d = mma_sub<bf16_t>(wh, xl[b][j], d);
+            d = mma_sub<bf16_t>(wh, xh[b][j], d);
+          }
+        }
+        finish_step();
+      }
+    }
+    // the accumulator layout (channels a * 16 + 4 g .. of token li) is the row layout of the epilogue: + bo + x -> x1, stored in place (the
+    // epilogue re-reads it as its residual: same lane, same addresses), LayerNorm statistics two-pass over the row's four lanes, and the
+    // normalised row as the (hi, lo) fragments of layer 1 (fragments 2 ks, 2 ks + 1 = channels 32 ks + 4 g .. and 32 ks + 16 + 4 g ..)
+#pragma unroll
+    for (int b = 0; b < TW; ++b) {
+      float* xrow = p.x + (int64_t)m[b] * p.ld;
+      float s1 = 0.f;
+#pragma unroll
+      for (int a = 0; a < FN2; ++a) {
+        const float4 xv = xres[b][a];
+        const float4 bv = *reinterpret_cast<const float4*>(s_bo + a * 16 + g * 4);
+        f32x4_t& d = acc2[a][b];
+        d[0] += bv.x + xv.x; d[1] += bv.y + xv.y; d[2] += bv.z + xv.z; d[3] += bv.w + xv.w;
+        s1 += (d[0] + d[1]) + (d[2] + d[3]);
+        if (row_ok[b]) *reinterpret_cast<float4*>(xrow + a * 16 + g * 4) = make_float4(d[0], d[1], d[2], d[3]);
+      }
+      s1 += __shfl_xor(s1, 16);
+      s1 += __shfl_xor(s1, 32);
+      const float mean = s1 * (1.0f / C);
+      float s2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < FN2; ++a) {
+        f32x4_t& d = acc2[a][b];
+        d[0] -= mean; d[1] -= mean; d[2] -= mean; d[3] -= mean;
+        s2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+      s2 += __shfl_xor(s2, 16);
+      s2 += __shfl_xor(s2, 32);
+      const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        const f32x4_t d0 = acc2[2 * ks][b], d1 = acc2[2 * ks + 1][b];
+        const float v[8] = {d0[0] * rstd, d0[1] * rstd, d0[2] * rstd, d0[3] * rstd, d1[0] * rstd, d1[1] * rstd, d1[2] * rstd, d1[3] * rstd};
+        split_bf16x8(v, xh[b][ks], xl[b][ks]);
+      }
+#pragma unroll
+      for (int a = 0; a < FN2; ++a) acc2[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   for (int c = 0; c < nch; ++c) {
     // ---- layer 1 of this chunk: acc1[a] (hidden units c * 128 + a * 16 + 4 g ..) over the C channels --------------------------------
 #pragma unroll
@@ -288,11 +400,74 @@ __global__ __launch_bounds__(256, 2) void ff_split_kernel(const FFSplitParams p)
       s1 += (y.x + y.y) + (y.z + y.w);
       s2 += (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
       if (row_ok[b]) *reinterpret_cast<float4*>(xrow + a * 16 + g * 4) = y;
+      if constexpr (POST) acc2[a][b] = f32x4_t{y.x, y.y, y.z, y.w};
     }
     if (p.stat_out) {
       s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
       s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
       if (g == 0 && row_ok[b]) p.stat_out[m[b]] = make_float2(s1, s2);
+    }
+  }
+  if constexpr (POST) {
+    // ---- q|k|v of the next attention: LayerNorm of the output rows (two-pass over the row's four lanes; the rows are still in acc2) as the
+    //      (hi, lo) fragments of a layer-1-shaped GEMM against Wqkv' -- 3C / 128 chunks of 128 columns, + bq', 16-byte stores ------------------
+#pragma unroll
+    for (int b = 0; b < TW; ++b) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int a = 0; a < FN2; ++a) s1 += (acc2[a][b][0] + acc2[a][b][1]) + (acc2[a][b][2] + acc2[a][b][3]);
+      s1 += __shfl_xor(s1, 16);
+      s1 += __shfl_xor(s1, 32);
+      const float mean = s1 * (1.0f / C);
+      float s2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < FN2; ++a) {
+        f32x4_t& d = acc2[a][b];
+        d[0] -= mean; d[1] -= mean; d[2] -= mean; d[3] -= mean;
+        s2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+      s2 += __shfl_xor(s2, 16);
+      s2 += __shfl_xor(s2, 32);
+      const float rstd = 1.0f / sqrtf(s2 * (1.0f / C) + 1e-5f);
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        const f32x4_t d0 = acc2[2 * ks][b], d1 = acc2[2 * ks + 1][b];
+        const float v[8] = {d0[0] * rstd, d0[1] * rstd, d0[2] * rstd, d0[3] * rstd, d1[0] * rstd, d1[1] * rstd, d1[2] * rstd, d1[3] * rstd};
+        split_bf16x8(v, xh[b][ks], xl[b][ks]);
+      }
+    }
+    for (int c = 0; c < NQC; ++c) {
+#pragma unroll
+      for (int r = 0; r < S1; ++r) {
+        if (issued < total) { issue(); ++issued; }
+        const char* cur = smem + c_stage * STAGE;
+#pragma unroll
+        for (int kc = 0; kc < KPS; ++kc)
+#pragma unroll
+          for (int a = 0; a < FN1; ++a) {
+            const int ks = r * KPS + kc;
+            const uint4 wh = *reinterpret_cast<const uint4*>(cur + w_base + (kc * HC + a * 16) * 128 + so0);
+            const uint4 wl = *reinterpret_cast<const uint4*>(cur + w_base + (kc * HC + a * 16) * 128 + so1);
+#pragma unroll
+            for (int b = 0; b < TW; ++b) {
+              acc1[a][b] = mma_sub<bf16_t>(wl, xh[b][ks], acc1[a][b]);
+              acc1[a][b] = mma_sub<bf16_t>(wh, xl[b][ks], acc1[a][b]);
+              acc1[a][b] = mma_sub<bf16_t>(wh, xh[b][ks], acc1[a][b]);
+            }
+          }
+        finish_step();
+      }
+#pragma unroll
+      for (int a = 0; a < FN1; ++a) {
+        const float4 bv = *reinterpret_cast<const float4*>(s_bq + c * 128 + a * 16 + g * 4);
+#pragma unroll
+        for (int b = 0; b < TW; ++b) {
+          if (row_ok[b])
+            *reinterpret_cast<float4*>(p.qkv + (int64_t)m[b] * p.ld_qkv + c * 128 + a * 16 + g * 4) =
+                make_float4(acc1[a][b][0] + bv.x, acc1[a][b][1] + bv.y, acc1[a][b][2] + bv.z, acc1[a][b][3] + bv.w);
+          acc1[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+      }
     }
   }
 }
@@ -302,10 +477,10 @@ inline bool ff_split_supported(int c, int hidden) { return (c == 128 || c == 256
 #ifndef WX_FFS_HC
 #define WX_FFS_HC 128
 #endif
-template <int C, int TW>
+template <int C, int TW, bool PRE, bool POST = false>
 inline void launch_ff_split_tw(const FFSplitParams& p, hipStream_t stream) {
-  const int LDS = 3 * 128 * 128 + (p.hidden + C) * 4;
-  auto kern = ff_split_kernel<C, TW, WX_FFS_HC>;
+  const int LDS = 3 * 128 * 128 + (p.hidden + 5 * C) * 4;
+  auto kern = ff_split_kernel<C, TW, WX_FFS_HC, PRE, POST>;
   static uint64_t attr_done_mask = 0;
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -318,10 +493,20 @@ inline void launch_ff_split_tw(const FFSplitParams& p, hipStream_t stream) {
 // larger tile; C = 256 always runs 1)
 inline void launch_ff_split(int c, const FFSplitParams& p, hipStream_t stream, int tw = 2) {
   if (!ff_split_supported(c, p.hidden)) throw std::runtime_error("ff_split: unsupported width");
-  if (c == 256) launch_ff_split_tw<256, 1>(p, stream);
-  else if (tw == 2) launch_ff_split_tw<128, 2>(p, stream);
-  else if (tw == 1) launch_ff_split_tw<128, 1>(p, stream);
+  const bool pre = p.o != nullptr;
+  if (pre && (!p.wos || !p.bo)) throw std::runtime_error("ff_split: the out-projection form needs its weights and bias");
+  const bool post = p.qkv != nullptr;
+  if (post && (!pre || !p.wqs || !p.bq)) throw std::runtime_error("ff_split: the to_qkv tail rides on the out-projection form and needs its weights and bias");
+#if WX_FFS_HC == 128
+#define WX_FFS_GO(CC, TT) { if (post) launch_ff_split_tw<CC, TT, true, true>(p, stream); else if (pre) launch_ff_split_tw<CC, TT, true>(p, stream); else launch_ff_split_tw<CC, TT, false>(p, stream); }
+#else
+#define WX_FFS_GO(CC, TT) { if (post) throw std::runtime_error("ff_split: to_qkv tail needs 128-unit chunks"); if (pre) launch_ff_split_tw<CC, TT, true>(p, stream); else launch_ff_split_tw<CC, TT, false>(p, stream); }
+#endif
+  if (c == 256) WX_FFS_GO(256, 1)
+  else if (tw == 2) WX_FFS_GO(128, 2)
+  else if (tw == 1) WX_FFS_GO(128, 1)
   else throw std::runtime_error("ff_split: unknown tile form");
+#undef WX_FFS_GO
 }
 
 }  // namespace wx

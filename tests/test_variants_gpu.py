@@ -359,3 +359,55 @@ def test_split_feedforward_one_launch():
     assert 0.0 < dev <= 2e-5, f"one-launch FeedForward vs the GEMM pair: {dev:.3e} of max|y|"
     assert torch.equal(_forward(tw1, x), _forward(tw2, x))
     assert torch.equal(yf, _forward(fused, x))
+
+
+def test_split_feedforward_takes_out_projection():
+    """fp32s, C = 128 / 256 stages: the one-launch FeedForward also applies the attention's out-projection + residual in front of it
+    (wx_ff_split.h PRE instantiations: x1 = x + Wout . o + bo in the accumulators, LayerNorm statistics of x1 two-pass in registers) --
+    no to_out launch, x1 is not written by one kernel and read by the next.  Against the unfused order (WX_NO_FF_SPLIT_PRE=1: to_out as a
+    split GEMM with one-pass LayerNorm partials) the forward differs by rounding order only, the GEMM count is the same, the launch count
+    drops by one per sub-block, both tile forms agree bit for bit, and two runs are bit-identical."""
+    cfg = named_config("C1")
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    pre = _engine("C1", "fp32s", {})
+    nopre = _engine("C1", "fp32s", {"WX_NO_FF_SPLIT_PRE": "1"})
+    yp, yn = _forward(pre, x), _forward(nopre, x)
+    n_sub = sum(2 * d for d, c in zip(cfg.depth, cfg.dim) if c in (128, 256))
+    assert pre.query("ff_split_pre") == n_sub and nopre.query("ff_split_pre") == 0
+    assert pre.query("split_gemms") == nopre.query("split_gemms")
+    assert pre.query("launches") <= nopre.query("launches") - n_sub
+    assert torch.isfinite(yp).all()
+    dev = float((yp - yn).abs().max() / yn.abs().max())
+    assert 0.0 < dev <= 2e-5, f"out-projection inside the FeedForward launch vs in front of it: {dev:.3e} of max|y|"
+    tw1 = _engine("C1", "fp32s", {"WX_FF_SPLIT_TW": "1"})
+    tw2 = _engine("C1", "fp32s", {"WX_FF_SPLIT_TW": "2"})
+    assert torch.equal(_forward(tw1, x), _forward(tw2, x))
+    assert torch.equal(yp, _forward(pre, x))
+
+
+def test_split_feedforward_makes_next_qkv():
+    """fp32s, C = 128 / 256 stages: the one-launch FeedForward that took the out-projection in front also runs the NEXT attention's
+    LayerNorm + to_qkv behind it (wx_ff_split.h POST instantiations: the output rows are still in the accumulators -- statistics two-pass
+    in registers, q|k|v as 3C / 128 more layer-1-shaped chunks of the weight ring) -- no to_qkv launch, the rows are not read again.
+    Against the unfused order (WX_NO_FF_SPLIT_POST=1) the forward differs by rounding order only, the GEMM count is the same, one launch
+    per fused sub-block is gone, both tile forms agree bit for bit, and two runs are bit-identical."""
+    cfg = named_config("C1")
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    post = _engine("C1", "fp32s", {})
+    nopost = _engine("C1", "fp32s", {"WX_NO_FF_SPLIT_POST": "1"})
+    yp, yn = _forward(post, x), _forward(nopost, x)
+    # every sub-block of a C = 128 / 256 stage whose successor in the stage is an attention with windows of more than one token
+    n_post = 0
+    for d, c, gw in zip(cfg.depth, cfg.dim, cfg.global_window_size):
+        if c in (128, 256):
+            n_post += (d if gw > 1 else 0) + (d - 1)
+    assert n_post > 0 and post.query("ff_split_post") == n_post and nopost.query("ff_split_post") == 0
+    assert post.query("split_gemms") == nopost.query("split_gemms")
+    assert post.query("launches") <= nopost.query("launches") - n_post
+    assert torch.isfinite(yp).all()
+    dev = float((yp - yn).abs().max() / yn.abs().max())
+    assert 0.0 < dev <= 2e-5, f"to_qkv behind the FeedForward launch vs its own launch: {dev:.3e} of max|y|"
+    tw1 = _engine("C1", "fp32s", {"WX_FF_SPLIT_TW": "1"})
+    tw2 = _engine("C1", "fp32s", {"WX_FF_SPLIT_TW": "2"})
+    assert torch.equal(_forward(tw1, x), _forward(tw2, x))
+    assert torch.equal(yp, _forward(post, x))
