@@ -1009,6 +1009,7 @@ class Engine : public EngineBase {
   int skinny_min_nk = getenv("WX_SKINNY_MIN_NK") ? atoi(getenv("WX_SKINNY_MIN_NK")) : 16;
   int skinny_tiles = getenv("WX_SKINNY_TILES") ? atoi(getenv("WX_SKINNY_TILES")) : 32;
   int skinny_tiles_band = getenv("WX_SKINNY_TILES_BAND") ? atoi(getenv("WX_SKINNY_TILES_BAND")) : 128;
+  int skinny_max_band = getenv("WX_SKINNY_MAX_BAND") ? atoi(getenv("WX_SKINNY_MAX_BAND")) : 4;
   float* splitk_buf = nullptr;   // fp32 partial sums of every split-K form (plain, skinny, hidden-split FeedForward): ONE buffer, sized in
   size_t splitk_bytes = 0;       // alloc_activations from the split rules' own bounds -- the forward never allocates (hipMalloc inside a
                                  // forward would also be illegal under the opt-in graph capture)
@@ -1530,7 +1531,10 @@ class Engine : public EngineBase {
         w.n % 64 == 0 && (w.cin * (int)sizeof(T)) % 128 == 0 && conv_gemm_is_dma<T>(p, zero_page) && !dbg_flags) {
       const int64_t tiles = (int64_t)cdiv((int64_t)out_h * out_w, 128) * conv_gemm_n_tiles(w.n);
       const int nk = w.cin * (int)sizeof(T) / 128;
-      const int S = std::min(skinny_max, nk / skinny_steps);
+      // (the tiles the wider lat-band rule adds -- more than skinny_tiles of them -- take at most skinny_max_band K ranges: with 8 the fp32
+      // partial sums of a rank's stage-2 FeedForward 2, 8 x 2 600 x 512 floats written and read back, cost more than the shorter K walk
+      // saves: slowest of 8 ranks 4.51 -> 4.32 ms with 4, 4.42 with 2)
+      const int S = std::min((band_on && tiles > skinny_tiles) ? std::min(skinny_max, skinny_max_band) : skinny_max, nk / skinny_steps);
       // lat-band ranks: a rank's share of the 0.25-degree stage 2 is ~80 tiles walking K = 2048 alone (FeedForward layer 2: 40 us) -- the
       // rule tuned on the 1-degree model (<= 32 tiles) is widened there (slowest of 8 ranks 4.62 -> 4.53 ms)
       if (tiles <= (band_on ? std::max(skinny_tiles, skinny_tiles_band) : skinny_tiles) && nk >= skinny_min_nk && S >= 2) {
@@ -2244,6 +2248,8 @@ class Engine : public EngineBase {
   }
   size_t b_pc = 0;
   int b_pending = -1;
+  int b_unpack_slots = 0;   // > 0: the last band_unpack left that many LayerNorm partials per token of the layout it filled
+  bool band_stats_ship = !getenv("WX_NO_BAND_STATS");
   const float *bx_own = nullptr, *bfrc_own = nullptr;
   float *by = nullptr, *by_phys = nullptr, *bx_next = nullptr;
   int attn_kind_override = -1;
@@ -2466,11 +2472,19 @@ class Engine : public EngineBase {
       }
     }
   }
-  void band_rowcopy(const BRow& d, const BRow& s, const int2* map, int n) {
+  // stat_slots > 0: the copy also leaves the LayerNorm partials of the tokens it moves in statpart (band_rowcopy_stats_kernel); the
+  // destination buffer's row `stat_row_off` is the stream's first row
+  void band_rowcopy(const BRow& d, const BRow& s, const int2* map, int n, int stat_slots = 0, int stat_row_off = 0, int stat_rows = 0) {
     if (n <= 0) return;
     if (d.width != s.width || d.hpr != s.hpr || (d.width & 15)) throw StateError("band: row shape mismatch");
     const int64_t per_row = (int64_t)d.hpr * (d.width / 16);
     const dim3 grid((unsigned)std::min<int64_t>(64, cdiv(per_row, 256)), (unsigned)std::min(n, 16384));
+    if (stat_slots > 0) {
+      hipLaunchKernelGGL(band_rowcopy_stats_kernel<T>, grid, dim3(256), 0, cur_stream, d.base, d.row_stride, d.pitch, s.base, s.row_stride, s.pitch,
+                         (int)(d.width / 16), d.hpr, n, map, stat_dst((int64_t)stat_rows * d.hpr, stat_slots), stat_slots, stat_row_off, stat_rows);
+      WX_HIP(hipGetLastError());
+      return;
+    }
     hipLaunchKernelGGL(band_rowcopy_kernel, grid, dim3(256), 0, cur_stream, d.base,
                        d.row_stride, d.pitch, s.base, s.row_stride, s.pitch, (int)(d.width / 16), d.hpr, n, map);
     WX_HIP(hipGetLastError());
@@ -2488,8 +2502,20 @@ class Engine : public EngineBase {
     const BandXDev& d = bx_dev[xid];
     const BRow dv = band_row(x.dst_buf, x);
     if (dv.width * dv.hpr != x.row_bytes) throw StateError("band: row size mismatch in " + x.name);
-    band_rowcopy(dv, band_staging(b_recv, dv), d.unpack, d.n_unpack);
-    if (d.n_self > 0) band_rowcopy(dv, band_row(x.src_buf, x), d.self, d.n_self);
+    // the rows of a long-attention redistribution arrive with their LayerNorm partials: every row of the new layout passes through one of
+    // the two copies below (wx_band.h: to_long / to_short gather whole layouts, no zero fill), so the sub-block behind the exchange
+    // starts from statpart instead of an ln_stats launch
+    int slots = 0, row_off = 0, rows = 0;
+    if (band_stats_ship && fuse_ln && (x.name.compare(0, 8, "to_long.") == 0 || x.name.compare(0, 9, "to_short.") == 0) && d.n_zero == 0) {
+      const int64_t w16 = dv.width / 16;
+      const bool to_long = x.dst_buf == BB_STREAM_L;
+      rows = to_long ? bplan.g.rows_long(x.stage, b_rank) : bplan.g.rows_short(x.stage, b_rank);
+      row_off = (!to_long && x.stage < 3) ? -1 : 0;   // the short layout sits behind one halo row of the concat buffer
+      if (w16 >= 1 && (w16 & (w16 - 1)) == 0 && w16 <= 512 && d.n_unpack + d.n_self == rows) slots = (int)std::max<int64_t>(1, w16 / 64);
+    }
+    band_rowcopy(dv, band_staging(b_recv, dv), d.unpack, d.n_unpack, slots, row_off, rows);
+    if (d.n_self > 0) band_rowcopy(dv, band_row(x.src_buf, x), d.self, d.n_self, slots, row_off, rows);
+    b_unpack_slots = slots;
     if (d.n_zero > 0) {   // beyond the pole: the convolution's zero padding
       const int64_t per_row = (int64_t)dv.hpr * (dv.width / 16);
       const dim3 grid((unsigned)std::min<int64_t>(64, cdiv(per_row, 256)), (unsigned)std::min(d.n_zero, 16384));
@@ -2522,7 +2548,9 @@ class Engine : public EngineBase {
     b_long[s] = is_long;
     sh[s] = is_long ? bplan.g.rows_long(s, b_rank) : bplan.g.rows_short(s, b_rank);
     attn_kind_override = is_long ? 2 : -1;
-    stat_tiles_ready = 0;   // LayerNorm partials belong to the rows that just left
+    // LayerNorm partials belong to the rows that just left -- unless the unpack of the redistribution that brought the new rows took them
+    stat_tiles_ready = b_unpack_slots;
+    b_unpack_slots = 0;
   }
   // GroupNorm: local (sum, sum sq) -> gn_acc
   void band_gn_local(const T* x, int c, int64_t m, bool have_partials) {
