@@ -1002,6 +1002,7 @@ class Engine : public EngineBase {
   float* embed_tail = nullptr;
   size_t embed_tail_bytes = 0;
   bool embed_ride4 = !getenv("WX_NO_EMBED_RIDE4");
+  bool embed_side = !getenv("WX_NO_EMBED_SIDE");   // stage-0 CrossEmbed: the branch outside the patch kernel on the side stream, beside it
   bool pack_align = !getenv("WX_NO_PACK_ALIGN");   // pack_input: block origin shifted onto the source's 256-byte boundaries
   bool stat_share = !getenv("WX_NO_EMBED_STATS");
   int skinny_max = getenv("WX_SKINNY_MAX") ? atoi(getenv("WX_SKINNY_MAX")) : 8;          // K ranges per tile (0 / 1: off)
@@ -1963,10 +1964,22 @@ class Engine : public EngineBase {
           }
           launch_embed_patch<T>(ep, zero_page, cur_stream);
         });
-      } else if (s == 0)
+      } else if (s == 0) {
+        // the branch that does not ride in the patch kernel (k = 4 of the 0.25-degree model: 64 channels, its own implicit GEMM) writes a
+        // channel range of the rows nobody else writes and reads the packed input only: on the engine's side stream, beside the patch
+        // launch (whose 625 tiles leave a partly filled last round), joined at the end of this function
+        const bool side = embed_side && patch_on && !band_on && !prof_on && !dbg_on && !dbg_flags && rwn < 0 && !side_open;
+        hipStream_t main_s = cur_stream;
+        if (side) {
+          side_ensure();
+          WX_HIP(hipEventRecord(ev_fork, main_s)); WX_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+          cur_stream = side_stream;
+          side_open = true;
+        }
+        struct Back { Engine* e; hipStream_t s; ~Back() { e->cur_stream = s; } } back{this, main_s};
         gemm("gemm_embed", st.embed[b], in, in_h, Wp + 2 * halo, cpad0, stv, pd - halo, pd - halo, sh[0], sw[0],
              x + choff, ld, nullptr, 0, nullptr, 0);
-      else {
+      } else {
         if (share) { stat_share_stride = total_slots; stat_share_slot0 = slot_at; }
         const bool made = gemm("gemm_embed", st.embed[b], in, in_h, sw[s - 1], in_ld_s, stv, pd + in_row0, pd, sh[s], sw[s],
                                x + choff, ld, nullptr, 0, nullptr, 0, 0, 0, 0, 0, share);
@@ -1978,6 +1991,13 @@ class Engine : public EngineBase {
       choff += st.embed[b].n;
     }
     if (share) stat_tiles_ready = all_made ? total_slots : 0;
+    side_join();
+  }
+  bool side_open = false;   // a launch of this forward is in flight on side_stream and not joined yet
+  void side_join() {
+    if (!side_open) return;
+    WX_HIP(hipEventRecord(ev_join, side_stream)); WX_HIP(hipStreamWaitEvent(cur_stream, ev_join, 0));
+    side_open = false;
   }
   // a4-a7: the transformer blocks of stage s on the rows the stream currently holds
   // ---- two-stream half-map schedule (round 5) ------------------------------------------------------------------------------------------
@@ -2430,7 +2450,10 @@ class Engine : public EngineBase {
   }
   BRow band_staging(char* base, const BRow& like) { return BRow{base, like.width * like.hpr, like.width, like.width, like.hpr}; }
   // row lists of every exchange, resident on the device (built once in band_enable)
-  struct BandXDev { int2 *pack = nullptr, *unpack = nullptr, *self = nullptr; int* zero = nullptr; int n_pack = 0, n_unpack = 0, n_self = 0, n_zero = 0; };
+  struct BandXDev {
+    int2 *pack = nullptr, *merged = nullptr;   // merged: the receiving side's one row list (band_unpack_kernel: staging / own / zero rows)
+    int n_pack = 0, n_unpack = 0, n_self = 0, n_zero = 0, n_merged = 0;
+  };
   std::vector<BandXDev> bx_dev;
   void band_upload_maps() {
     bx_dev.assign(bplan.xs.size(), BandXDev());
@@ -2464,27 +2487,20 @@ class Engine : public EngineBase {
         *dst = (int2*)dalloc(v.size() * sizeof(int2));
         WX_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(int2), hipMemcpyHostToDevice));
       };
-      up2(pk, &d.pack, &d.n_pack); up2(up, &d.unpack, &d.n_unpack); up2(sf, &d.self, &d.n_self);
-      d.n_zero = (int)zr.size();
-      if (!zr.empty()) {
-        d.zero = (int*)dalloc(zr.size() * sizeof(int));
-        WX_HIP(hipMemcpy(d.zero, zr.data(), zr.size() * sizeof(int), hipMemcpyHostToDevice));
-      }
+      up2(pk, &d.pack, &d.n_pack);
+      d.n_unpack = (int)up.size(); d.n_self = (int)sf.size(); d.n_zero = (int)zr.size();
+      std::vector<int2> mg;
+      for (const int2& e : up) mg.push_back(e);
+      for (const int2& e : sf) mg.push_back(make_int2(-1 - e.x, e.y));
+      for (int zrow : zr) mg.push_back(make_int2((int)0x80000000, zrow));
+      up2(mg, &d.merged, &d.n_merged);
     }
   }
-  // stat_slots > 0: the copy also leaves the LayerNorm partials of the tokens it moves in statpart (band_rowcopy_stats_kernel); the
-  // destination buffer's row `stat_row_off` is the stream's first row
-  void band_rowcopy(const BRow& d, const BRow& s, const int2* map, int n, int stat_slots = 0, int stat_row_off = 0, int stat_rows = 0) {
+  void band_rowcopy(const BRow& d, const BRow& s, const int2* map, int n) {
     if (n <= 0) return;
     if (d.width != s.width || d.hpr != s.hpr || (d.width & 15)) throw StateError("band: row shape mismatch");
     const int64_t per_row = (int64_t)d.hpr * (d.width / 16);
     const dim3 grid((unsigned)std::min<int64_t>(64, cdiv(per_row, 256)), (unsigned)std::min(n, 16384));
-    if (stat_slots > 0) {
-      hipLaunchKernelGGL(band_rowcopy_stats_kernel<T>, grid, dim3(256), 0, cur_stream, d.base, d.row_stride, d.pitch, s.base, s.row_stride, s.pitch,
-                         (int)(d.width / 16), d.hpr, n, map, stat_dst((int64_t)stat_rows * d.hpr, stat_slots), stat_slots, stat_row_off, stat_rows);
-      WX_HIP(hipGetLastError());
-      return;
-    }
     hipLaunchKernelGGL(band_rowcopy_kernel, grid, dim3(256), 0, cur_stream, d.base,
                        d.row_stride, d.pitch, s.base, s.row_stride, s.pitch, (int)(d.width / 16), d.hpr, n, map);
     WX_HIP(hipGetLastError());
@@ -2513,16 +2529,18 @@ class Engine : public EngineBase {
       row_off = (!to_long && x.stage < 3) ? -1 : 0;   // the short layout sits behind one halo row of the concat buffer
       if (w16 >= 1 && (w16 & (w16 - 1)) == 0 && w16 <= 512 && d.n_unpack + d.n_self == rows) slots = (int)std::max<int64_t>(1, w16 / 64);
     }
-    band_rowcopy(dv, band_staging(b_recv, dv), d.unpack, d.n_unpack, slots, row_off, rows);
-    if (d.n_self > 0) band_rowcopy(dv, band_row(x.src_buf, x), d.self, d.n_self, slots, row_off, rows);
     b_unpack_slots = slots;
-    if (d.n_zero > 0) {   // beyond the pole: the convolution's zero padding
-      const int64_t per_row = (int64_t)dv.hpr * (dv.width / 16);
-      const dim3 grid((unsigned)std::min<int64_t>(64, cdiv(per_row, 256)), (unsigned)std::min(d.n_zero, 16384));
-      hipLaunchKernelGGL(band_rowzero_kernel, grid, dim3(256), 0, cur_stream, dv.base,
-                         dv.row_stride, dv.pitch, (int)(dv.width / 16), dv.hpr, d.n_zero, d.zero);
-      WX_HIP(hipGetLastError());
-    }
+    if (d.n_merged <= 0) return;
+    // one launch for the received rows, the rows that stay on this rank and the zero rows beyond the pole (band_unpack_kernel)
+    const BRow g = band_staging(b_recv, dv);
+    const BRow o = d.n_self > 0 ? band_row(x.src_buf, x) : g;
+    if (o.width != dv.width || o.hpr != dv.hpr || (dv.width & 15)) throw StateError("band: row shape mismatch");
+    const int64_t per_row = (int64_t)dv.hpr * (dv.width / 16);
+    const dim3 grid((unsigned)std::min<int64_t>(64, cdiv(per_row, 256)), (unsigned)std::min(d.n_merged, 16384));
+    hipLaunchKernelGGL(band_unpack_kernel<T>, grid, dim3(256), 0, cur_stream, dv.base, dv.row_stride, dv.pitch, g.base, g.row_stride, g.pitch, o.base,
+                       o.row_stride, o.pitch, (int)(dv.width / 16), dv.hpr, d.n_merged, d.merged,
+                       slots > 0 ? stat_dst((int64_t)rows * dv.hpr, slots) : nullptr, slots, row_off, rows);
+    WX_HIP(hipGetLastError());
   }
 
   // ---- the program
