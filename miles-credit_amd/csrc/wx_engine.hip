@@ -1002,7 +1002,9 @@ class Engine : public EngineBase {
   float* embed_tail = nullptr;
   size_t embed_tail_bytes = 0;
   bool embed_ride4 = !getenv("WX_NO_EMBED_RIDE4");
-  bool embed_side = !getenv("WX_NO_EMBED_SIDE");   // stage-0 CrossEmbed: the branch outside the patch kernel on the side stream, beside it
+  // stage-0 CrossEmbed: the branch outside the patch kernel on the side stream, beside it.  OFF: bit-identical and a tie on MI355X (C3 bf16, same
+  // box, four alternations: 8.084 - 8.185 ms/step with it, 8.066 - 8.100 without) -- the patch launch fills the chip, the 88 us GEMM only moves
+  bool embed_side = getenv("WX_EMBED_SIDE") && getenv("WX_EMBED_SIDE")[0] == '1';
   bool pack_align = !getenv("WX_NO_PACK_ALIGN");   // pack_input: block origin shifted onto the source's 256-byte boundaries
   bool stat_share = !getenv("WX_NO_EMBED_STATS");
   int skinny_max = getenv("WX_SKINNY_MAX") ? atoi(getenv("WX_SKINNY_MAX")) : 8;          // K ranges per tile (0 / 1: off)

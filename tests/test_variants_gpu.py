@@ -411,3 +411,22 @@ def test_split_feedforward_makes_next_qkv():
     tw2 = _engine("C1", "fp32s", {"WX_FF_SPLIT_TW": "2"})
     assert torch.equal(_forward(tw1, x), _forward(tw2, x))
     assert torch.equal(yp, _forward(post, x))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32s"])
+def test_embed_branch_on_side_stream_bit_identical(precision):
+    """Stage-0 CrossEmbed of the 0.25-degree widths: the k = 4 branch does not fit the patch kernel's accumulator rows and runs as its own
+    implicit GEMM -- with WX_EMBED_SIDE=1 on the engine's side stream, beside the patch launch (it reads the packed input only and writes a
+    channel range of its own; fork / join = one event pair inside cross_embed; measured a tie, so OFF by default).  Same kernels, same
+    launches: the forward must be BIT-identical to the one-stream order and bit-identical run to run (race screen: three forwards)."""
+    cfg = named_config("C3S")
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    side = _engine("C3S", precision, {"WX_EMBED_SIDE": "1"})
+    one = _engine("C3S", precision, {})
+    y1 = _forward(one, x)
+    y2 = _forward(side, x)
+    assert torch.isfinite(y2).all()
+    assert torch.equal(y1, y2), f"side-stream CrossEmbed branch differs (max {float((y1 - y2).abs().max()):.3e})"
+    for _ in range(3):
+        assert torch.equal(_forward(side, x), y2), "side-stream CrossEmbed branch is not deterministic (race between the streams)"
+    assert side.query("launches") == one.query("launches")
