@@ -389,6 +389,9 @@ typedef struct wx_kernel_stat {
  *   "launches"           kernel launches of the last forward
  *   "precision"          the wx_config precision the engine was created with
  *   "split_gemms"        GEMM launches of the last forward that ran split-bf16 arithmetic (WX_PREC_FP32_SPLIT)
+ *   "ff_split_fused"     ... of whose FeedForward sub-blocks ran as ONE launch (wx_ff_split.h; each counts two split GEMMs), and of those
+ *   "ff_split_pre"       how many also applied the attention's out-projection + residual in front (three GEMMs in the launch),
+ *   "ff_split_post"      how many also produced the next attention's q|k|v behind (four)
  * Unknown key -> WX_ERR_INVALID. */
 int wx_query(wx_handle h, const char* key, int64_t* value);
 int wx_profile(wx_handle h, int enable);
