@@ -2069,7 +2069,15 @@ class Engine : public EngineBase {
       stat_tiles_ready = save_ready; last_stat_slots = save_slots;
       return std::make_pair(end_ready, end_slots);
     };
+    // A fork is safe only while both halves keep ONE LayerNorm-partial layout: statpart is [token][slots], a half's region starts at
+    // (its first token) x slots, and the residual layers of a half leave dim / 64 slots per row (the persistent GEMM's N tiles).  When the
+    // partials a chain STARTS from have another slot count (stage entry: the CrossEmbed epilogues leave 4 / 8), the regions of the two
+    // layouts overlap between the halves -- half A's first residual layer would write where half B's first to_qkv still has to read (or
+    // the other way round).  Found as a one-in-~25 mismatch of a warm-up rollout on one lease; such a chain runs whole, on the caller's
+    // stream, and leaves the chain's layout for the forks that follow.
+    const int chain_slots = cfg.dim[s] / 64;
     auto both = [&](auto&& body) {
+      if (stat_tiles_ready != chain_slots) { body(); return; }
       fork();
       const auto ea = half(0, rows_a, main_s, body);
       const auto eb = half(rows_a, rows_b, side_stream, body);
@@ -2078,10 +2086,19 @@ class Engine : public EngineBase {
       stat_tiles_ready = ea.first; last_stat_slots = ea.second;
     };
     if (pointwise_long) {
+      size_t first = 0;
+      if (stat_tiles_ready != chain_slots && !st.blocks.empty()) {   // the stage's first sub-block brings the chain's layout (see `both`)
+        attention(st.blocks[0].sa, s, "");
+        feedforward(st.blocks[0].sf, s, "");
+        first = 1;
+      }
       both([&] {
-        for (const BlockL& bl : st.blocks) {
-          attention(bl.sa, s, "");
-          feedforward(bl.sf, s, "");
+        for (size_t d = 0; d < st.blocks.size(); ++d) {
+          const BlockL& bl = st.blocks[d];
+          if (d >= first) {
+            attention(bl.sa, s, "");
+            feedforward(bl.sf, s, "");
+          }
           attention(bl.la, s, "");
           feedforward(bl.lf, s, "");
         }
