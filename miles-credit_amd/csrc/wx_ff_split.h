@@ -19,6 +19,13 @@
 //   epilogue  + b2 + x (re-read: the rows are L2 / MALL-resident, the registers are not there to keep them), 16-byte stores, per-row
 //             (sum, sum of squares) of the outputs for the next LayerNorm (one slot per row).
 // No activation staging, no hidden tensor, one epilogue per token instead of five tile epilogues.
+// PRE / POST instantiations (the bf16 engine's ff_fused_kernel has the same pair): the attention's out-projection + residual in front
+// (x1 = x + Wout . o + bo accumulates in layer 2's still idle accumulators from o's fragments; the residual rows are requested in the
+// prologue into layer 1's still idle accumulator registers; x1 is stored in place, normalised two-pass in registers) and the NEXT attention's
+// LayerNorm + to_qkv behind (the output rows are still in the accumulators: 3C / 128 more layer-1-shaped chunks of the ring).  One launch
+// then replaces to_out + FeedForward 1 + FeedForward 2 + to_qkv: stage 0 of the 0.25-degree model 110 + 278 + 198 us -> 459 us per
+// sub-block, C3 forward 22.04 -> 21.86 (PRE) -> 21.50 ms (PRE + POST) on one box -- less than the bytes saved suggest, because this
+// launch is issue-bound, not HBM-bound (docs/history/r05_negative_results.md).
 // Measured (tools/ffs_probe, 320 000 tokens, 20 back-to-back launches; inside a forecast, between other kernels, the same launch
 // takes 256 us, the unfused pair 558): 325 us, of which -- taking one piece out at a time (WX_FFS_DBG) -- the MFMAs ~130 (their bare
 // rate), GELU + split VALU ~60, the LDS fragment reads ~75, LDS-DMA + the per-step barrier ~50.  The pieces ADD (a SIMD does not
