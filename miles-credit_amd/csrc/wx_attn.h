@@ -81,6 +81,7 @@ __device__ __forceinline__ uint2 lds_read_tr16(const void* lds_ptr) {
 // 16-byte accesses through a native vector type: a plain uint4 (struct) copy from a pointer becomes a memcpy that keeps the
 // destination array in scratch memory
 typedef unsigned attn_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned attn_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint4 attn_ld16(const void* p) {
   const attn_u32x4 v = *reinterpret_cast<const attn_u32x4*>(p);
   return make_uint4(v.x, v.y, v.z, v.w);
@@ -165,9 +166,14 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
 #else
   constexpr bool VTR = sizeof(T) == 2;
 #endif
+  // M3 (fp32 storage, split-bf16 products): V is split ONCE, on its way into LDS -- two bf16 images (hi, lo) in the bf16 kernel's row-major
+  // layout, 8 bytes per loaded 16-byte piece and image -- and the paired (hi, lo) P.V operands come out of the same transpose read the bf16
+  // kernel uses (the 32-key block of a read IS the M3 pairing: keys 32 b + 4 g .. | + 16).  Before: an fp32 V^T image built with four
+  // ds_write_b32 per piece (15 k of a task's 52 k cycles), 16-byte reads and a split of every fragment pair in registers.
+  constexpr bool VTS = M3;
   constexpr int VT_COLS = VTR ? NKB * 32 : sizeof(T) == 2 ? NKB * 32 + 8 : (NP + 4);
-  constexpr int VT_BYTES = D * VT_COLS * (int)sizeof(T);
   constexpr int VSUB = NKB * 32 * 32;                    // bytes of one 16-channel sub-image
+  constexpr int VT_BYTES = VTS ? 2 * NDF * VSUB : D * VT_COLS * (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
 
   // ---- V rows -> registers; K fragments requested before anything waits -------------------------------------------
   constexpr int PIECES = D / VEC;  // 16-byte pieces per token row
-  constexpr int COLS_FILL = (sizeof(T) == 2) ? NKB * 32 : NP;
+  constexpr int COLS_FILL = (sizeof(T) == 2 || VTS) ? NKB * 32 : NP;
   constexpr int STEP = SPLIT ? 256 : 64;
   constexpr int ITER = (COLS_FILL * PIECES + STEP - 1) / STEP;
   uint4 vv[ITER];
@@ -344,6 +350,15 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
       if (idx < COLS_FILL * PIECES) {
         if constexpr (VTR) {
           attn_st16(reinterpret_cast<char*>(vt) + (piece >> 1) * VSUB + t * 32 + (piece & 1) * 16, vv[it]);
+        } else if constexpr (VTS) {   // piece = channels 4 piece .. 4 piece + 3 of token t: sub-image piece / 4, 8 bytes at (piece % 4) * 8 of its 32-byte row
+          const float e0 = __builtin_bit_cast(float, vv[it].x), e1 = __builtin_bit_cast(float, vv[it].y);
+          const float e2 = __builtin_bit_cast(float, vv[it].z), e3 = __builtin_bit_cast(float, vv[it].w);
+          const uint32_t h0 = pack_bf16x2(e0, e1), h1 = pack_bf16x2(e2, e3);
+          const uint32_t l0 = pack_bf16x2(e0 - __builtin_bit_cast(float, h0 << 16), e1 - __builtin_bit_cast(float, h0 & 0xffff0000u));
+          const uint32_t l1 = pack_bf16x2(e2 - __builtin_bit_cast(float, h1 << 16), e3 - __builtin_bit_cast(float, h1 & 0xffff0000u));
+          char* at = reinterpret_cast<char*>(vt) + (piece >> 2) * VSUB + t * 32 + (piece & 3) * 8;
+          *reinterpret_cast<attn_u32x2*>(at) = attn_u32x2{h0, h1};
+          *reinterpret_cast<attn_u32x2*>(at + NDF * VSUB) = attn_u32x2{l0, l1};
         } else {
           const T* e = reinterpret_cast<const T*>(&vv[it]);
 #pragma unroll
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
   // per block against ~350 instructions, and 32 registers fewer
   constexpr bool VLDS = WX_ATTN_VLDS && sizeof(T) == 2 && NKF >= 7 && NKF <= 8 && DH == 32;
   auto read_vf = [&](int df, int b, int opaque = 0) -> uint4 {
-    if constexpr (VTR) {
+    if constexpr (VTR || VTS) {   // VTS: opaque = byte offset of the image (0 = hi, NDF * VSUB = lo)
       // lane l of a 16-lane group points at its own 8 bytes of the group's [4 keys][16 channels] block: keys b*32 + g*4 + {0..3}
       // (lo) and + 16 (hi) -- the key order the score accumulators hold -- so the block of group g starts lane*8 bytes in
       const char* base = reinterpret_cast<const char*>(vt) + opaque + lane * 8 + df * VSUB + b * 1024;
@@ -378,7 +393,16 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
   };
   constexpr int NVFA = M3 ? NVF + (NVF & 1) : NVF;   // M3 pairs key fragments: an even count (the odd one out is a zero fragment)
   uint4 vf[VLDS ? 1 : NDF][VLDS ? 1 : NVFA];
-  if constexpr (!VLDS) {
+  if constexpr (VTS) {   // (vf[df][2 b], vf[df][2 b + 1]) = (hi, lo) fragments of keys 32 b + 4 g .. | 32 b + 16 + 4 g ..
+    static_assert(NVFA == 2 * NKB, "one (hi, lo) pair per 32-key block");
+#pragma unroll
+    for (int df = 0; df < NDF; ++df)
+#pragma unroll
+      for (int b = 0; b < NKB; ++b) {
+        vf[df][2 * b] = read_vf(df, b);
+        vf[df][2 * b + 1] = read_vf(df, b, NDF * VSUB);
+      }
+  } else if constexpr (!VLDS) {
 #pragma unroll
     for (int df = 0; df < NDF; ++df) {
 #pragma unroll
@@ -391,10 +415,12 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
     for (int j = 0; j < NKF; ++j)
 #pragma unroll
       for (int s = 0; s < QK_SUBS; s += 2) attn_split_pair(kf[j][s], kf[j][s + 1]);
+    if constexpr (!VTS) {
 #pragma unroll
-    for (int df = 0; df < NDF; ++df)
+      for (int df = 0; df < NDF; ++df)
 #pragma unroll
-      for (int b = 0; b < NVFA; b += 2) attn_split_pair(vf[df][b], vf[df][b + 1]);
+        for (int b = 0; b < NVFA; b += 2) attn_split_pair(vf[df][b], vf[df][b + 1]);
+    }
   }
 
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
@@ -808,7 +834,8 @@ inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
   constexpr int VT_COLS = (sizeof(T) == 2) ? NKB * 32 : (NKF * 16 + 4);
 #endif
   constexpr int TB2 = B2W > 0 ? ((2 * B2W - 1) * (2 * B2W - 1) + 7) / 8 * 8 : 0;
-  constexpr int LDS = (SPLIT ? 1 : 4) * DH * VT_COLS * (int)sizeof(T) + (B2W > 0 ? TB2 * 16 + NKF * 16 * 4 : BT ? 1024 * 4 + NKF * 16 * 4 : 0) + NKF * 16 * 4;
+  constexpr int VIMG = M3 ? 2 * (DH / 16) * NKB * 32 * 32 : DH * VT_COLS * (int)sizeof(T);   // per wave: M3 keeps two bf16 images (hi, lo)
+  constexpr int LDS = (SPLIT ? 1 : 4) * VIMG + (B2W > 0 ? TB2 * 16 + NKF * 16 * 4 : BT ? 1024 * 4 + NKF * 16 * 4 : 0) + NKF * 16 * 4;
   auto kern = window_attn_kernel<T, NKF, SPLIT, BT, DH, SW, B2W, M3>;
   static uint64_t attr_done_mask = 0;   // hipFuncSetAttribute is per device: one bit per device id
   if (!attr_done_on_device(attr_done_mask)) {
