@@ -325,6 +325,11 @@ def named_config(name: str) -> WXConfig:
         mc = dict(base, frames=2, output_frames=1, image_height=37, image_width=72, levels=3, output_only_channels=3,
                   dim=[32, 64, 128, 256], depth=[1, 1, 2, 1], global_window_size=[4, 2, 2, 1], local_window_size=3,
                   padding_conf=dict(activate=True, mode="earth", pad_lat=[6, 6], pad_lon=[12, 12]))
+    elif name == "T0X":  # T0 geometry with a WIDE input (4 x 57 + 8 = 236 channels -> 256 padded: pack_input's channel-group loop, two groups)
+        # and longitude pads that are not multiples of 4 (its scalar-load path with a shifted block origin)
+        mc = dict(base, image_height=37, image_width=72, levels=57, output_only_channels=3,
+                  dim=[32, 64, 128, 256], depth=[1, 1, 2, 1], global_window_size=[4, 2, 2, 1], local_window_size=3,
+                  padding_conf=dict(activate=True, mode="earth", pad_lat=[6, 6], pad_lon=[13, 11]))
     elif name == "T5":  # T1 geometry with the WIDTHS of the 0.25-degree model (C = 128 / 256 / 512 / 1024): every launch shape of
         # C3's stages 2-3 (persistent GEMM, k-blocked hidden, 4-token packed windows, v-only long attention) on 200 / 50 rows
         mc = dict(base, image_height=61, image_width=120, levels=5, output_only_channels=2,

@@ -47,7 +47,7 @@ def check(y, ref, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])
-@pytest.mark.parametrize("name", ["T0", "T1", "T0W", "T0U", "T0M", "T0F", "T0H", "T1H"])
+@pytest.mark.parametrize("name", ["T0", "T1", "T0W", "T0U", "T0M", "T0F", "T0H", "T1H", "T0X"])
 def test_forward_and_every_block_vs_oracle(name, prec):
     cfg = named_config(name)
     sd = synth_state_dict(cfg)
@@ -88,7 +88,7 @@ def test_c1_vs_oracle_and_reference_golden(name, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])
-@pytest.mark.parametrize("name", ["T0H", "T1H"])
+@pytest.mark.parametrize("name", ["T0H", "T1H", "T0X"])
 def test_wide_heads_vs_reference_golden(name, prec):
     """dim_head = 64 / 128 (crossformer.py:372-401; the reference's YAMLs leave the default 32): the general-head-dimension attention
     kernel between the plain GEMMs, against the reference's own fp32 forward (tools/make_goldens.py --only T0H / T1H), same gates

@@ -82,7 +82,7 @@ def test_stress_families_differ_from_base_only_where_documented():
     assert hi[k1][3] == 7.0e4 and st[k1][3] == base[k1][3]
 
 
-@pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W", "T0U", "T0M", "T0F", "RT", "T0H", "T1H",
+@pytest.mark.parametrize("name", ["T0", "T1", "C1", "C3S", "T0W", "C1W", "T0U", "T0M", "T0F", "RT", "T0H", "T1H", "T0X",
                                   pytest.param("C3", marks=pytest.mark.skipif(
                                       not _SLOW, reason="~1.5 min of CPU; set WX_SLOW=1"))])
 def test_forward_matches_reference_golden(name):

@@ -821,7 +821,7 @@ def main():
             reconstruct_golden()
         elif item == "asm":
             assemble_golden()
-        elif item in ("T0", "T1", "T0W", "T0U", "T0M", "T0F", "T0H", "T1H"):
+        elif item in ("T0", "T1", "T0W", "T0U", "T0M", "T0F", "T0H", "T1H", "T0X"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "RT":   # the model of the reference's own tests/test_crossformer.py
             model_golden(item, 2, False)
