@@ -1764,6 +1764,13 @@ class Engine : public EngineBase {
         q.w2s = reinterpret_cast<const float*>(ws_dev + f.w2.wt); q.b2 = f_dev + f.w2.bias;
         q.rowstat = rs; q.stat_tiles = pre ? 0 : stat_tiles_ready; q.stat_inv_c = 1.0f / (float)c;
         q.stat_out = fuse_ln ? stat_dst(t0 + m, 1) + t0 : nullptr;
+        if (!pre && q.stat_out && stat_tiles_ready > 1) {
+          // the launch would read `statpart` as [M][stat_tiles_ready] in its prologue and write it as [M][1] in its epilogue: workgroup 2j's
+          // stores land on the entries workgroup j still has to read, and nothing orders the two (lat-band ranks, WX_NO_FF_SPLIT_PRE,
+          // debug captures: the producer was a stand-alone to_out with 2 - 4 slots).  Final statistics through `rowstat` instead.
+          ln_stats(x, ld, c, m);
+          q.rowstat = rowstat; q.stat_tiles = 0;
+        }
         if (pre) {
           q.o = reinterpret_cast<const float*>(attn_o + t0 * c); q.ld_o = c;
           q.wos = reinterpret_cast<const float*>(ws_dev + pre->out.wt); q.bo = f_dev + pre->out.bias;
