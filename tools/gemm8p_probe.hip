@@ -44,19 +44,19 @@ static double time_us(hipStream_t st, int reps, F&& fn) {
 template <int FM, int ABL>
 static void launch_abl(const Gemm8pParams& q, int variant, hipStream_t st) {
   switch (variant) {
-    case 0: launch_gemm8p_v<FM, false, false, false, false, ABL>(q, st); break;
-    case 1: launch_gemm8p_v<FM, true, false, false, false, ABL>(q, st); break;
-    case 2: launch_gemm8p_v<FM, true, true, false, false, ABL>(q, st); break;
-    default: launch_gemm8p_v<FM, false, false, true, true, ABL>(q, st); break;
+    case 0: launch_gemm8p_v<2, FM, false, false, false, false, false, false, ABL>(q, st); break;
+    case 1: launch_gemm8p_v<2, FM, false, true, false, false, false, false, ABL>(q, st); break;
+    case 2: launch_gemm8p_v<2, FM, false, true, true, false, false, false, ABL>(q, st); break;
+    default: launch_gemm8p_v<2, FM, false, false, false, true, true, false, ABL>(q, st); break;
   }
 }
 template <int FM>
 static void launch_trace(const Gemm8pParams& q, int variant, hipStream_t st) {
   switch (variant) {
-    case 0: launch_gemm8p_v<FM, false, false, false, false, 0, true>(q, st); break;
-    case 1: launch_gemm8p_v<FM, true, false, false, false, 0, true>(q, st); break;
-    case 2: launch_gemm8p_v<FM, true, true, false, false, 0, true>(q, st); break;
-    default: launch_gemm8p_v<FM, false, false, true, true, 0, true>(q, st); break;
+    case 0: launch_gemm8p_v<2, FM, false, false, false, false, false, false, 0, true>(q, st); break;
+    case 1: launch_gemm8p_v<2, FM, false, true, false, false, false, false, 0, true>(q, st); break;
+    case 2: launch_gemm8p_v<2, FM, false, true, true, false, false, false, 0, true>(q, st); break;
+    default: launch_gemm8p_v<2, FM, false, false, false, true, true, false, 0, true>(q, st); break;
   }
 }
 
@@ -83,6 +83,8 @@ int main(int argc, char** argv) {
     shapes.push_back({8192, 8192, 8192, 0, "8192^3  (bias)"});
     shapes.push_back({20480, 2048, 4096, 0, "deep K  (bias)"});
   }
+  if (getenv("WX_ONLY_CONV")) shapes.clear();
+  if (getenv("WX_CONV_AS_1X1")) shapes = {{20000, 2048, 512, 0, "s2 ff1' (bias only)"}, {20480, 2048, 4096, 0, "deep K  (bias)"}, {20000, 512, 4608, 0, "up1-like (bias)"}};
   hipStream_t st;
   WX_HIP(hipStreamCreate(&st));
   char* sink = (char*)dalloc(8192);
@@ -108,7 +110,8 @@ int main(int argc, char** argv) {
       const float mean = (float)sm / K, var = std::max((float)sq / K - mean * mean, 0.f);
       hs[i] = make_float2(mean, 1.0f / std::sqrt(var + 1e-5f));
     }
-    uint16_t* x = (uint16_t*)dalloc(hx.size() * 2);
+    uint16_t* x = (uint16_t*)dalloc(hx.size() * 2 + 256);
+    WX_HIP(hipMemset((char*)x + hx.size() * 2, 0, 256));
     uint16_t* w = (uint16_t*)dalloc(hw.size() * 2);
     uint16_t* wblk = (uint16_t*)dalloc(hw.size() * 2);   // [K/32][N][32] (production kernel)
     {
@@ -154,8 +157,15 @@ int main(int argc, char** argv) {
     Gemm8pParams gf = g;
     gf.xcd_part = 0;
 
-    auto run_prod = [&] { launch_gemm_stream<5, 3>(q, s.variant, st); };
-    auto run_prod128 = [&] { launch_gemm_stream_n128<5, 3, 2>(q4, st); };
+    // the engine's own choice per epilogue (Engine::gemm): to_qkv 128 x 256 / 3 stages, GELU 160 x 256 / 2 stages, residual layers 160 x 128
+    // (loader / consumer form when there is at most one tile per CU and K >= 1024)
+    const bool lc = res && stream_gemm_lc_pays(M, N, K, 5);
+    auto run_prod = [&] {
+      if (s.variant == 1) launch_gemm_stream<4, 3>(q, 1, st);
+      else if (s.variant == 2) launch_gemm_stream<5, 2>(q, 2, st);
+      else launch_gemm_stream<5, 3>(q, s.variant, st);
+    };
+    auto run_prod128 = [&] { if (lc) launch_gemm_stream_n128_lc<5, 8>(q4, st); else launch_gemm_stream_n128<5, 3, 2>(q4, st); };
     auto run_5x = [&] { launch_gemm8p<5>(g, s.variant, st); };
     auto run_5f = [&] { launch_gemm8p<5>(gf, s.variant, st); };
     auto run_8x = [&] { launch_gemm8p<8>(g, s.variant, st); };
@@ -224,9 +234,34 @@ int main(int argc, char** argv) {
       t8x = std::min(t8x, time_us(st, 20, run_8x));
       t8f = std::min(t8f, time_us(st, 20, run_8f));
     }
+    if (s.variant == 0 && getenv("WX_CONV_AS_1X1")) {   // the conv form's DMA path (buffer descriptor, tap masks) on a 1x1 layer: what does the path itself cost?
+      Gemm8pParams gc = g;
+      gc.in_h = 1; gc.in_w = M; gc.cin = K; gc.kh = gc.kw = 1; gc.pad_y = gc.pad_x = 0;
+
+      auto run_c = [&] { launch_gemm8p_v<2, 5, true, false, false, false, false, false>(gc, st); };
+      WX_HIP(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, st));
+      run_c();
+      WX_HIP(hipStreamSynchronize(st));
+      WX_HIP(hipMemcpy(h2.data(), y1, h2.size() * 2, hipMemcpyDeviceToHost));
+      const bool same = std::memcmp(h1.data(), h2.data(), h1.size() * 2) == 0;
+      double tc = 1e30, tg = 1e30;
+      for (int round = 0; round < 3; ++round) { tc = std::min(tc, time_us(st, 20, run_c)); tg = std::min(tg, time_us(st, 20, run_5x)); }
+      printf("    1x1 through the conv form: %7.1f us against %7.1f us (global-pointer form), outputs %s\n", tc, tg, same ? "bitwise equal" : "DIFFER");
+      {
+        auto a1 = [&] { launch_gemm8p_v<2, 5, true, false, false, false, false, false, 5>(gc, st); };
+        auto a0 = [&] { launch_gemm8p_v<2, 5, false, false, false, false, false, false, 5>(g, st); };
+        auto b1 = [&] { launch_gemm8p_v<2, 5, true, false, false, false, false, false, 1>(gc, st); };
+        auto b0 = [&] { launch_gemm8p_v<2, 5, false, false, false, false, false, false, 1>(g, st); };
+        auto c1 = [&] { launch_gemm8p_v<2, 5, true, false, false, false, false, false, 3>(gc, st); };
+        auto c0 = [&] { launch_gemm8p_v<2, 5, false, false, false, false, false, false, 3>(g, st); };
+        printf("      no epilogue: conv %7.1f plain %7.1f | no epilogue, no DMA: conv %7.1f plain %7.1f | no epilogue, no MFMA: conv %7.1f plain %7.1f\n",
+               time_us(st, 10, b1), time_us(st, 10, b0), time_us(st, 10, a1), time_us(st, 10, a0), time_us(st, 10, c1), time_us(st, 10, c0));
+      }
+      if (!same) ++bad;
+    }
     const double fl = 2.0 * M * N * K * 1e-6;
     printf("%-20s M=%6d N=%5d K=%5d | production %7.1f us %5.0f TF", s.name, M, N, K, t_prod, fl / t_prod);
-    if (res) printf(" (128-col %7.1f us %5.0f TF)", t_p128, fl / t_p128);
+    if (res) printf(" (128-col%s %7.1f us %5.0f TF)", lc ? " LC" : "", t_p128, fl / t_p128);
     printf(" | 8p 160x256 xcd %7.1f us %5.0f TF  flat %7.1f us %5.0f TF | 8p 256x256 xcd %7.1f us %5.0f TF  flat %7.1f us %5.0f TF\n",
            t5x, fl / t5x, t5f, fl / t5f, t8x, fl / t8x, t8f, fl / t8f);
     printf("    parity: max|ref| %.3f  err production %.4f  err 8p %.4f | production-vs-8p differing %.4f%% (max %.4f) | stat rel %.2e | races %d  %s\n",
@@ -247,7 +282,7 @@ int main(int argc, char** argv) {
       }
       for (int fm : {5, 8}) {   // one traced launch: where does a workgroup's life go (shader clocks, wave 0 and wave 4)
         Gemm8pParams gt = g;
-        gemm8p_geometry(gt, fm);
+        gemm8p_geometry(gt, 2, fm);
         const size_t grid = gemm8p_grid(gt);
         unsigned long long* tr = (unsigned long long*)dalloc(grid * 2 * 64);
         WX_HIP(hipMemset(tr, 0, grid * 2 * 64));
@@ -262,12 +297,12 @@ int main(int argc, char** argv) {
           t0 = std::min(t0, h[b * 8]); t1 = std::max(t1, h[b * 8 + 1]);
           const double n = (double)h[b * 8 + 4];
           life.push_back((double)(h[b * 8 + 1] - h[b * 8]));
-          kl.push_back((double)h[b * 8 + 2] / n);
+          kl.push_back(((double)(h[b * 8 + 1] - h[b * 8]) - (double)h[b * 8 + 3]) / n);
           ep.push_back((double)h[b * 8 + 3] / n);
         }
         auto pct = [](std::vector<double> v, double qq) { std::sort(v.begin(), v.end()); return v[(size_t)(qq * (v.size() - 1))]; };
         if (!life.empty())
-          printf("    trace %s: %.1f us | grid %zu | span %llu clk | life p50 %.0f p90 %.0f | per tile: K loop p50 %.0f p90 %.0f (%d K tiles -> %.0f clk per K tile) epilogue p50 %.0f p90 %.0f\n",
+          printf("    trace %s: %.1f us | grid %zu | span %llu clk | life p50 %.0f p90 %.0f | per tile: rest of life p50 %.0f p90 %.0f (%d K tiles -> %.0f clk per K tile) epilogue p50 %.0f p90 %.0f\n",
                  fm == 5 ? "160x256" : "256x256", t_tr, grid, t1 - t0, pct(life, .5), pct(life, .9), pct(kl, .5), pct(kl, .9), K / 64, pct(kl, .5) / (K / 64),
                  pct(ep, .5), pct(ep, .9));
         WX_HIP(hipFree(tr));
@@ -276,6 +311,114 @@ int main(int argc, char** argv) {
     fflush(stdout);
     for (void* ptr : {(void*)x, (void*)w, (void*)y0, (void*)y1, (void*)rs, (void*)bias, (void*)colsum, (void*)rowstat, (void*)so0, (void*)so1, (void*)wblk})
       WX_HIP(hipFree(ptr));
+  }
+
+  // ---- stride-1 3x3 convolutions of the decoder (GroupNorm partials in the epilogue): 8p conv form against conv_gemm_dma_kernel --------
+  if (set >= 0 && !getenv("WX_NO_CONV")) {
+    struct CShape { int H, W, C, N; const char* name; };
+    std::vector<CShape> cs = {{100, 200, 512, 512, "up1 conv3 100x200 512->512"}, {200, 400, 256, 256, "up2 conv3 200x400 256->256"},
+                              {400, 800, 128, 128, "up3 conv3 400x800 128->128"}, {37, 53, 128, 256, "ragged   37x53   128->256"},
+                              {41, 29, 128, 128, "ragged   41x29   128->128"}};
+    char* zero = (char*)dalloc(256);
+    WX_HIP(hipMemset(zero, 0, 256));
+    for (const CShape& c : cs) {
+      const int M = c.H * c.W, K = 9 * c.C, N = c.N;
+      std::mt19937 rng(11);
+      std::uniform_real_distribution<float> u(-1.f, 1.f);
+      std::vector<uint16_t> hx((size_t)M * c.C), hw((size_t)N * K);
+      for (auto& v : hx) v = f2bf(u(rng));
+      for (auto& v : hw) v = f2bf(u(rng) * 0.03f);
+      std::vector<float> hb(N);
+      for (auto& v : hb) v = u(rng) * 0.3f;
+      uint16_t* x = (uint16_t*)dalloc(hx.size() * 2 + 256);
+    WX_HIP(hipMemset((char*)x + hx.size() * 2, 0, 256));
+      uint16_t* w = (uint16_t*)dalloc(hw.size() * 2);
+      uint16_t* y0 = (uint16_t*)dalloc((size_t)M * N * 2);
+      uint16_t* y1 = (uint16_t*)dalloc((size_t)M * N * 2);
+      float* bias = (float*)dalloc(N * 4);
+      const int t0 = (int)cdiv((int64_t)M, (int64_t)128), t1 = gemm8p_conv_gn_tiles(M, N);
+      float2* g0 = (float2*)dalloc((size_t)t0 * N * 8);
+      float2* g1 = (float2*)dalloc((size_t)t1 * N * 8);
+      WX_HIP(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+      WX_HIP(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+      WX_HIP(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice));
+      ConvGemmParams p;
+      std::memset(&p, 0, sizeof(p));
+      p.in = x; p.in_h = c.H; p.in_w = c.W; p.in_ld = c.C; p.cin = c.C; p.kh = p.kw = 3; p.stride = 1; p.pad_y = p.pad_x = 1;
+      p.out_h = c.H; p.out_w = c.W; p.wt = w; p.n = N; p.n_alloc = N; p.bias = bias; p.out = y0; p.out_ld = N; p.gn_out = g0;
+      Gemm8pParams g;
+      std::memset(&g, 0, sizeof(g));
+      g.a = x; g.lda = c.C; g.w = w; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = y1; g.out_ld = N; g.sink = sink; g.xcd_part = 1;
+      g.gn_out = g1; g.in_h = c.H; g.in_w = c.W; g.cin = c.C; g.kh = g.kw = 3; g.pad_y = g.pad_x = 1;
+      auto run_prod = [&] { launch_conv_gemm<uint16_t>(p, zero, st, 0); };
+      g.xcd_part = getenv("WX_XCD_PART") ? atoi(getenv("WX_XCD_PART")) : 1;
+
+      auto run_8p = [&] { launch_gemm8p_conv(g, st); };
+      WX_HIP(hipMemset(y0, 0, (size_t)M * N * 2));
+      WX_HIP(hipMemset(y1, 0xff, (size_t)M * N * 2));
+      run_prod();
+      run_8p();
+      WX_HIP(hipStreamSynchronize(st));
+      std::vector<uint16_t> h0((size_t)M * N), h1((size_t)M * N), h2((size_t)M * N);
+      WX_HIP(hipMemcpy(h0.data(), y0, h0.size() * 2, hipMemcpyDeviceToHost));
+      WX_HIP(hipMemcpy(h1.data(), y1, h1.size() * 2, hipMemcpyDeviceToHost));
+      size_t ndiff = 0;
+      double maxd = 0;
+      for (size_t i = 0; i < h0.size(); ++i)
+        if (h0[i] != h1[i]) { ++ndiff; maxd = std::max(maxd, (double)std::fabs(bf2f(h0[i]) - bf2f(h1[i]))); }
+      // fp64 reference on sampled pixels (borders included)
+      double err = 0, max_ref = 0;
+      for (int sidx = 0; sidx < 24; ++sidx) {
+        const int m = sidx == 0 ? 0 : sidx == 1 ? M - 1 : sidx == 2 ? c.W - 1 : sidx == 3 ? (c.H - 1) * c.W : (int)(((int64_t)sidx * 7919 * 131) % M);
+        const int oy = m / c.W, ox = m % c.W;
+        for (int n = 0; n < N; n += 7) {
+          double a = hb[n];
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+              const int iy = oy + ky - 1, ix = ox + kx - 1;
+              if (iy < 0 || iy >= c.H || ix < 0 || ix >= c.W) continue;
+              for (int ch = 0; ch < c.C; ++ch)
+                a += (double)bf2f(hx[((size_t)iy * c.W + ix) * c.C + ch]) * bf2f(hw[(size_t)n * K + (ky * 3 + kx) * c.C + ch]);
+            }
+          max_ref = std::max(max_ref, std::fabs(a));
+          err = std::max(err, std::fabs(a - bf2f(h1[(size_t)m * N + n])));
+        }
+      }
+      // GroupNorm partials: folded per channel in fp64, both kernels against the sums of the rounded outputs
+      std::vector<float2> a0((size_t)t0 * N), a1((size_t)t1 * N);
+      WX_HIP(hipMemcpy(a0.data(), g0, a0.size() * 8, hipMemcpyDeviceToHost));
+      WX_HIP(hipMemcpy(a1.data(), g1, a1.size() * 8, hipMemcpyDeviceToHost));
+      double gn_err = 0;
+      for (int n = 0; n < N; ++n) {
+        double s0 = 0, q0 = 0, s1 = 0, q1 = 0, sr = 0, qr = 0;
+        for (int t = 0; t < t0; ++t) { s0 += a0[(size_t)t * N + n].x; q0 += a0[(size_t)t * N + n].y; }
+        for (int t = 0; t < t1; ++t) { s1 += a1[(size_t)t * N + n].x; q1 += a1[(size_t)t * N + n].y; }
+        for (int m = 0; m < M; ++m) { const double f = bf2f(h1[(size_t)m * N + n]); sr += f; qr += f * f; }
+        gn_err = std::max(gn_err, std::fabs(s1 - sr) / (1.0 + std::fabs(sr)));
+        gn_err = std::max(gn_err, std::fabs(q1 - qr) / (1.0 + std::fabs(qr)));
+        if (ndiff == 0) gn_err = std::max(gn_err, std::fabs(s1 - s0) / (1.0 + std::fabs(s0)));   // (wide inputs: the production kernel walks taps inside channel chunks -- another k order)
+      }
+      int races = 0;
+      for (int rep = 0; rep < 4; ++rep) {
+        WX_HIP(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, st));
+        run_8p();
+        WX_HIP(hipStreamSynchronize(st));
+        WX_HIP(hipMemcpy(h2.data(), y1, h2.size() * 2, hipMemcpyDeviceToHost));
+        if (std::memcmp(h1.data(), h2.data(), h1.size() * 2) != 0) ++races;
+      }
+      double tp = 1e30, t8 = 1e30;
+      for (int round = 0; round < 3; ++round) {
+        tp = std::min(tp, time_us(st, 10, run_prod));
+        t8 = std::min(t8, time_us(st, 10, run_8p));
+      }
+      const double fl = 2.0 * M * N * K * 1e-6;
+      const bool ok = (ndiff == 0 || (c.C >= 512 && maxd <= max_ref * 8e-3)) && err <= max_ref * 8e-3 && gn_err < 1e-4 && races == 0;
+      if (!ok) ++bad;
+      printf("%-28s M=%6d N=%4d K=%5d | conv_gemm_dma %7.1f us %5.0f TF | 8p conv %7.1f us %5.0f TF | differing %.4f%% (max %.4f) err vs fp64 %.4f (max|ref| %.2f) gn rel %.2e races %d  %s\n",
+             c.name, M, N, K, tp, fl / tp, t8, fl / t8, 100.0 * ndiff / h0.size(), maxd, err, max_ref, gn_err, races, ok ? "OK" : "FAIL");
+      fflush(stdout);
+      for (void* ptr : {(void*)x, (void*)w, (void*)y0, (void*)y1, (void*)bias, (void*)g0, (void*)g1}) WX_HIP(hipFree(ptr));
+    }
   }
   printf(bad ? "PROBE FAILED (%d shapes)\n" : "PROBE OK\n", bad);
   return bad ? 1 : 0;
