@@ -27,6 +27,7 @@
 #include "wx_gemm.h"
 #include "wx_gemm_stream.h"
 #include "wx_gemm_wreg.h"
+#include "wx_gemm8p.h"
 #include "wx_ff_split.h"
 #include "wx_attn_block.h"
 #include "wx_swin.h"
@@ -1034,6 +1035,9 @@ class Engine : public EngineBase {
   bool use_stream = !(getenv("WX_NO_STREAM") && getenv("WX_NO_STREAM")[0] == '1');   // persistent large-tile GEMM (wx_gemm_stream.h) for the LN-folded 1x1 layers of the deep stages
   int stream_min_rows = 4096;
   bool use_stream_lc = !(getenv("WX_NO_STREAM_LC") && getenv("WX_NO_STREAM_LC")[0] == '1');   // loader / consumer form of the persistent GEMM (one-tile-per-CU residual layers)
+  bool use_gemm8p = !(getenv("WX_NO_GEMM8P") && getenv("WX_NO_GEMM8P")[0] == '1');   // eight-phase 160 x 256 kernel (wx_gemm8p.h) for the deep-K stride-1 k x k convs of the decoder
+  int64_t gemm8p_min_rows = getenv("WX_GEMM8P_MIN_ROWS") ? atoll(getenv("WX_GEMM8P_MIN_ROWS")) : 16384;
+  int64_t n_gemm8p = 0;              // launches of the last forward that took it
   bool use_wreg = !(getenv("WX_NO_WREG") && getenv("WX_NO_WREG")[0] == '1');   // weight-stationary GEMM (wx_gemm_wreg.h) for K = 512 layers on mid-sized maps
   int wreg_min_rows = getenv("WX_WREG_MIN_ROWS") ? atoi(getenv("WX_WREG_MIN_ROWS")) : 1024;
   int wreg_max_rows = getenv("WX_WREG_MAX_ROWS") ? atoi(getenv("WX_WREG_MAX_ROWS")) : 4096;
@@ -1058,6 +1062,7 @@ class Engine : public EngineBase {
     return statpart;
   }
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
+  int64_t gnpart_elems = 0;
   bool blk_hidden = false;      // set around a FeedForward's two gemm() calls: the hidden tensor is k-blocked [4C/32][M][32] (layer 1 writes
                                 // it, layer 2 reads it: full cache lines per LDS-DMA piece; ff2 47.9 -> 45.0 us, ff1 56.6 -> 53.8 us)
   // Row window (round 5): attention() / feedforward() / gemm() work on map rows [rw0, rw0 + rwn) of the current stage instead of the whole
@@ -1118,11 +1123,12 @@ class Engine : public EngineBase {
     statpart_elems = max_hw * 8;
     for (int s = 0; s < 4; ++s) statpart_elems = std::max(statpart_elems, (int64_t)sh[s] * sw[s] * std::max(8, cfg.dim[s] / 32));
     statpart = (float2*)dalloc(statpart_elems * sizeof(float2));
-    gnpart = (float2*)dalloc((int64_t)cdiv(max_hw, 128) * cfg.dim[3] * sizeof(float2));
+    gnpart_elems = (int64_t)cdiv(max_hw, 128) * cfg.dim[3];
+    gnpart = (float2*)dalloc(gnpart_elems * sizeof(float2));
     zero_page = (char*)dalloc(256);
     WX_HIP(hipMemset(zero_page, 0, 256));
     if (const char* e = getenv("WX_NO_DMA")) use_dma = !(e[0] == '1');
-    stream_sink = (char*)dalloc(4096);
+    stream_sink = (char*)dalloc(8192);   // 16 bytes per thread of the widest workgroup (512: wx_gemm8p.h)
     splitk_bytes = splitk_bound();
     splitk_buf = (float*)dalloc(splitk_bytes);
     if (const char* e = getenv("WX_DBG")) dbg_flags = atoi(e);
@@ -1273,6 +1279,7 @@ class Engine : public EngineBase {
     if (key == "launches") { *v = n_launches; return true; }
     if (key == "precision") { *v = sizeof(T) == 2 ? WX_PREC_BF16 : (split_mma ? WX_PREC_FP32_SPLIT : WX_PREC_FP32); return true; }
     if (key == "split_gemms") { *v = n_split_gemms; return true; }
+    if (key == "gemm8p_launches") { *v = n_gemm8p; return true; }
     if (key == "ff_split_fused") { *v = n_ff_split_fused; return true; }
     if (key == "ff_split_pre") { *v = n_ff_split_pre; return true; }
     if (key == "ff_split_post") { *v = n_ff_split_post; return true; }
@@ -1443,6 +1450,33 @@ class Engine : public EngineBase {
       if (gn_accum) gn_tile_off += cdiv((int64_t)out_h * out_w, 128);
     }
     if constexpr (sizeof(T) == 2) {
+      // stride-1 k x k convolutions with a deep K and >= 256 output channels on large maps (the two 3x3 convs of the decoder's first two
+      // UpBlocks at 0.25 degrees: K = 4608 / 2304): the eight-phase kernel's conv form (wx_gemm8p.h) -- 127.7 -> 90.1 us and 112.6 -> 102.0 us
+      // against the 128 x 128 kernel (tools/gemm8p_probe, profiles/r06_gemm8p_probe_b_conv_form.txt); bitwise the same outputs where the two
+      // walk K in the same order.  GroupNorm partials: one per (160-row tile, wave row) = 80 output rows, folded like the 128-row ones.
+      {
+        const int64_t rows = (int64_t)out_h * out_w;
+        const int kk = w.kh * w.kw * w.cin;
+        if (use_gemm8p && use_dma && !dbg_flags && !p.stat_out && w.kh == w.kw && w.kh > 1 && w.kh * w.kw <= 32 && stride == 1 &&
+            pad_y == (w.kh - 1) / 2 && pad_x == (w.kw - 1) / 2 && in_h == out_h && in_w == out_w && !rs && act == 0 && out_mode == 0 && !want_stats &&
+            w.n % 256 == 0 && w.cin % 64 == 0 && kk % 128 == 0 && (!want_gn || (fuse_ln && !gn_accum)) && rwn < 0 && !band_on && rows >= gemm8p_min_rows &&
+            rows * in_ld * 2 < (int64_t)0x7fffff00 && gemm8p_fits(rows, w.n, 2, 5, true)) {
+          Gemm8pParams q;
+          std::memset(&q, 0, sizeof(q));
+          q.a = reinterpret_cast<const bf16_t*>(in); q.lda = in_ld; q.w = reinterpret_cast<const bf16_t*>(wt_dev + w.wt);
+          q.M = (int)rows; q.N = w.n; q.K = kk; q.bias = p.bias;
+          q.res = reinterpret_cast<const bf16_t*>(res); q.res_ld = res_ld;
+          q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink; q.xcd_part = 1;
+          q.in_h = in_h; q.in_w = in_w; q.cin = w.cin; q.kh = w.kh; q.kw = w.kw; q.pad_y = pad_y; q.pad_x = pad_x;
+          q.gn_out = want_gn ? gnpart : nullptr;
+          if (want_gn && (int64_t)gemm8p_conv_gn_tiles(rows, w.n) * w.n > gnpart_elems) throw StateError("GroupNorm partials of the eight-phase conv exceed the reserved buffer");
+          cur_family = "gemm8p";
+          timed(cls, flops, bytes, [&] { launch_gemm8p_conv(q, cur_stream); });
+          ++n_gemm8p;
+          if (want_gn) gn_tile_off = gemm8p_conv_gn_tiles(rows, w.n);
+          return want_gn;
+        }
+      }
       // LayerNorm-folded 1x1 layers with many rows and K >= 512 (to_qkv, FeedForward layer 1 of stages 2-3): the persistent
       // 128 x 256-tile kernel; measured per shape against the 128 x 128 kernel in tools/gemm_stream_probe
       const bool one = w.kh == 1 && w.kw == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && in_h == out_h && in_w == out_w;
@@ -2149,6 +2183,7 @@ class Engine : public EngineBase {
   }
   void core(const float* x_item) {
     n_two_stream_stages = 0;
+    n_gemm8p = 0;
     n_split_gemms = 0;
     n_ff_split_fused = 0;
     n_ff_split_pre = 0;

@@ -60,7 +60,10 @@ struct Gemm8pParams {
 // one LDS-DMA piece through a buffer descriptor: 64 lanes x 16 B from rsrc.base + voff to lds_dst + lane * 16; lanes whose offset lies
 // beyond rsrc.num_records write ZEROS (tools/bufdma_probe.hip) -- the out-of-map taps of a convolution without a second pointer
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-// (M0 is declared clobbered instead of saved and restored around every piece: nothing else in these kernels reads it)
+// (M0 is declared clobbered instead of saved and restored around every piece -- 2 SALU and an SGPR less per piece; nothing else in these
+// kernels reads M0: gfx9 LDS instructions do not, and there is no indirect register indexing, interpolation or message traffic)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void lds_dma16_buf(const u32x4_t& rsrc, unsigned voff, unsigned lds_dst_sgpr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst_sgpr) : "memory", "m0");
 }
@@ -68,6 +71,8 @@ __device__ __forceinline__ void lds_dma16_buf(const u32x4_t& rsrc, unsigned voff
 __device__ __forceinline__ void lds_dma16_sv8(const void* sbase, unsigned voff, unsigned lds_dst_sgpr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst_sgpr) : "memory", "m0");
 }
+
+#pragma clang diagnostic pop
 
 constexpr int GEMM8P_MAX_TILES = 8;   // tiles per workgroup (LDS parameter slots); the host picks the grid accordingly
 

@@ -154,6 +154,56 @@ def test_persistent_gemm_forced_on_small_maps(name):
 
 
 @pytest.mark.parametrize("name", ["T5", "C1"])
+def test_eight_phase_conv_forced_on_small_maps(name):
+    """`gemm8p_kernel` (wx_gemm8p.h, conv form: eight waves / eight phases, 160 x 256 tiles, tap masks + buffer-descriptor LDS-DMA) takes the
+    decoder's 3x3 convs with >= 256 output channels on maps of >= 16384 pixels by itself -- the first two UpBlocks of the 0.25-degree model.
+    WX_GEMM8P_MIN_ROWS=1 forces it onto T5 (512 -> 512 on 10 x 20 pixels: two ragged 160-row tiles x two N-tiles, K = 4608; 256 -> 256 on
+    20 x 40) and C1 (256 -> 256 on 30 x 48): map borders on every side of a tile, rows beyond M in the last tile, GroupNorm partials per
+    80-row half tile.  Checked (a) against the same engine on the 128 x 128 kernel (`WX_NO_GEMM8P=1`), (b) per UpBlock against the CPU oracle
+    with the suite's bf16 gate, (c) run-to-run bit-identical (race screen), (d) that the kernel is what ran."""
+    from oracle import wxformer_oracle as O
+    cfg = named_config(name)
+    sd = synth_state_dict(cfg)
+    xin = synth_input(cfg)
+    x = torch.from_numpy(xin).cuda()
+    e8 = _engine(name, "bf16", {"WX_GEMM8P_MIN_ROWS": "1"})
+    plain = _engine(name, "bf16", {"WX_NO_GEMM8P": "1"})
+    cap = {}
+    y_ref = O.forward(cfg, sd, xin, capture=cap)
+    got = {}
+    for eng, key in ((e8, "8p"), (plain, "plain")):
+        eng.set_debug(True)
+        y = eng.forward(x).clone()
+        got[key] = (y, {k: eng.debug_read(k) for k in cap if k.startswith("up_block")})
+        eng.set_debug(False)
+    assert torch.equal(e8.forward(x), e8.forward(x)), "eight-phase conv: two runs differ (race)"
+    n8 = e8.query("gemm8p_launches")
+    assert n8 >= 2 and plain.forward(x) is not None and plain.query("gemm8p_launches") == 0, (n8, plain.query("gemm8p_launches"))
+    e8.profile(3)
+    e8.profile_reset()
+    e8.forward(x)
+    torch.cuda.synchronize()
+    tagged = [r["name"] for r in e8.profile_read() if r["name"].endswith("@gemm8p")]
+    e8.profile(0)
+    assert tagged and all(t.startswith("gemm_conv3") for t in tagged), tagged
+    ups = sorted(got["8p"][1])
+    assert len(ups) >= 3, ups
+    for k in ups:
+        ref = cap[k][0].numpy().astype(np.float64)
+        a, b = got["8p"][1][k].astype(np.float64), got["plain"][1][k].astype(np.float64)
+        l2_ref = np.linalg.norm(a - ref) / np.linalg.norm(ref)
+        l2_pl = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+        assert l2_ref <= 2e-2, f"{name} {k}: eight-phase conv vs oracle rel-L2 {l2_ref:.3e}"
+        assert l2_pl <= 8e-3, f"{name} {k}: eight-phase conv vs 128x128 kernel rel-L2 {l2_pl:.3e}"
+    y8, yp = got["8p"][0], got["plain"][0]
+    l2 = float(torch.linalg.norm((y8 - yp).double()) / torch.linalg.norm(yp.double()))
+    yr = y_ref.numpy().astype(np.float64)
+    l2o = np.linalg.norm(y8.cpu().numpy().astype(np.float64) - yr) / np.linalg.norm(yr)
+    assert l2 <= 1e-2 and l2o <= 2e-2, (l2, l2o)
+    print(f"[gemm8p conv parity] {name}: {n8} launches; y vs 128x128 path {l2:.2e}, vs oracle {l2o:.2e}")
+
+
+@pytest.mark.parametrize("name", ["T5", "C1"])
 def test_weight_stationary_gemm_forced_on_small_maps(name):
     """`gemm_wreg_kernel` (wx_gemm_wreg.h: weights in registers, activations streamed in 32-row tiles) takes the K = 512 layers on maps
     of 1024 .. 4095 rows by itself -- a lat-band rank's share of the 0.25-degree stage 2.  WX_WREG_MIN_ROWS=0 forces it onto T5's
