@@ -337,8 +337,9 @@ def main():
         y32 = y_phys.clone()
         del eng32
         torch.cuda.empty_cache()
-        # round 5: the FAST mode that still meets that tolerance -- fp32 storage, LayerNorm / softmax / GroupNorm / attention in fp32, every
-        # implicit GEMM as split-bf16 arithmetic (x_hi.W_hi + x_hi.W_lo + x_lo.W_hi on the bf16 MFMA pipe, fp32 accumulate): what a
+        # round 5: the FAST mode that still meets that tolerance -- fp32 storage, LayerNorm / GroupNorm / softmax statistics in fp32, every
+        # implicit GEMM AND the window attention's Q.K^T / P.V as split-bf16 arithmetic (x_hi.W_hi + x_hi.W_lo + x_lo.W_hi on the bf16
+        # MFMA pipe, fp32 accumulate; include/wxengine.h lists the window sizes that take it): what a
         # maintainer who needs the reference's fp32 numerics (credit/seed.py:24-25: TF32 off) would run.  Same loop, same workload.
         engs = WXEngine(cfg, "fp32s", local_rank)
         engs.load_state_dict(sd)

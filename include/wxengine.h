@@ -48,11 +48,16 @@ enum wx_arch {
 enum wx_precision {
   WX_PREC_FP32 = 0,        /* f32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32) */
   WX_PREC_BF16 = 1,        /* bf16 storage + bf16 MFMA, fp32 accumulate / LN / softmax / GN */
-  WX_PREC_FP32_SPLIT = 2   /* f32 storage, LN / softmax / GN / attention as WX_PREC_FP32; every implicit GEMM as split-bf16 arithmetic:
-                            * x = x_hi + x_lo, W = W_hi + W_lo, three v_mfma_f32_16x16x32_bf16 per product (hi.hi + hi.lo + lo.hi),
-                            * fp32 accumulate -- the fast mode that still meets the fp32 tolerance against the reference (whose
-                            * inference is fp32 with TF32 off, credit/seed.py:24-25).  wx_create (incl. lat-band mode), wx_swin_create and wx_fuxi_create take it
-                            * (their attention kernels stay exact fp32 outside the CrossFormer windows); wx_winattn_create takes FP32 / BF16. */
+  WX_PREC_FP32_SPLIT = 2   /* f32 storage; LayerNorm / GroupNorm / softmax statistics (max, sum, exp on v_exp_f32) in fp32 as in WX_PREC_FP32;
+                            * every implicit GEMM as split-bf16 arithmetic: x = x_hi + x_lo, W = W_hi + W_lo, three
+                            * v_mfma_f32_16x16x32_bf16 per product (hi.hi + hi.lo + lo.hi), fp32 accumulate -- the fast mode that still
+                            * meets the fp32 tolerance against the reference (whose inference is fp32 with TF32 off, credit/seed.py:24-25).
+                            * The CrossFormer window attention's two products (Q.K^T and P.V) run in the same three-MFMA form, with the
+                            * position bias and the softmax statistics exact, for windows of 17 - 32, 33 - 64, 97 - 112 and 113 - 128
+                            * tokens with dim_head 32 on the LDS bias-table path (key-fragment counts 2 / 4 / 7 / 8: every multi-token
+                            * window of BASELINE configs 1 - 4); any other window size or head width falls back to the exact-f32 MFMA
+                            * products of WX_PREC_FP32.  wx_create (incl. lat-band mode), wx_swin_create and wx_fuxi_create take the mode
+                            * (the Swin / FuXi attention kernels stay exact fp32); wx_winattn_create takes FP32 / BF16. */
 };
 
 /* The YAML `model:` mapping of the reference constructor

@@ -951,6 +951,7 @@ class Engine : public EngineBase {
         ws_dev = (T*)dalloc(sp.size() * sizeof(uint16_t) + 256);
         WX_HIP(hipMemcpy(ws_dev, sp.data(), sp.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         if (!sp16_host.empty()) {
+          if (sp16_dev) { (void)hipFree(sp16_dev); allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)sp16_dev)); sp16_dev = nullptr; }   // a second wx_finalize_weights: no leak
           sp16_dev = (uint16_t*)dalloc(sp16_host.size() * sizeof(uint16_t) + 256);
           WX_HIP(hipMemcpy(sp16_dev, sp16_host.data(), sp16_host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
           std::vector<uint16_t>().swap(sp16_host);
@@ -1417,7 +1418,7 @@ class Engine : public EngineBase {
       if (split_mma && w.cin % 32 == 0 && !dbg_flags && conv_gemm_is_dma<T>(p, use_dma ? zero_page : nullptr)) {
         p.split = 1;
         p.wt = ws_dev + w.wt;
-        ++n_split_gemms;
+        if (!gemm_par) ++n_split_gemms;   // a ConvTranspose's outer call only dispatches: its launches are counted where they happen
       }
     }
     if (gemm_par) {   // the four parity convs of a ConvTranspose k4 s2 p1 (out_mode 2): one launch when the fast path takes it
@@ -1428,6 +1429,7 @@ class Engine : public EngineBase {
         for (int q = 0; q < 4; ++q) p.wt_par[q] = (p.split ? ws_dev : wt_dev) + gp[q].wt;
         const double fl4 = 4.0 * 2.0 * m * w.n * w.kh * w.kw * w.cin_true;
         const double by4 = (4.0 * m * w.n + (double)in_h * in_w * w.cin_true + 4.0 * w.n * w.kh * w.kw * w.cin) * sizeof(T);
+        if (p.split) ++n_split_gemms;   // the merged launch
         timed(cls, fl4, by4, [&] { launch_conv_gemm<T>(p, zero_page, cur_stream, gemm_cfg); });
         return false;
       }
@@ -2380,6 +2382,7 @@ class Engine : public EngineBase {
     WX_HIP(hipSetDevice(device));
     if (splitk_bound(true) > splitk_bytes) {   // the band ranks' split-K rule reaches more tiles than the whole-map engine's
       splitk_bytes = splitk_bound(true);
+      if (splitk_buf) { (void)hipFree(splitk_buf); allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)splitk_buf)); splitk_buf = nullptr; }
       splitk_buf = (float*)dalloc(splitk_bytes);
     }
     for (int s = 0; s < 4; ++s) gsh[s] = sh[s];

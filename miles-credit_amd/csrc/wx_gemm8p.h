@@ -9,7 +9,7 @@
 // /opt/skills/guides/cdna_hip_programming.md section 5 ("256^2 8-phase template"):
 //   * ONE 512-thread workgroup per CU, waves WR (pixels) x WC (channels), WR * WC = 8; wave tile 16*FM pixels x 64 channels; tile
 //     (16*FM*WR) x (64*WC): WR = 2: 160 x 256 (FM = 5; 160 divides the 20 000 tokens of the 0.25-degree model's stage 2) or 256 x 256
-//     (FM = 8); WR = 4: 256 x 128 (FM = 4) for layers of 128 output channels;
+//     (FM = 8); WR = 4: 320 x 128 (FM = 5) for layers of 128 output channels;
 //   * K tile = 64 (128-byte LDS rows = one cache line per row and K tile: no k-blocked operand copies are needed), TWO LDS buffers, each
 //     split into four units  X0 | X1 (pixel fragments [0, FM0) / [FM0, FM) of every wave row)  W0 | W1 (channel fragment pairs 0 / 1 of
 //     every wave column);
@@ -665,17 +665,16 @@ inline void launch_gemm8p(const Gemm8pParams& p, int variant, hipStream_t stream
     default: throw std::runtime_error("gemm8p: unknown epilogue variant");
   }
 }
-// stride-1 k x k convolutions (bias; optional residual; optional GroupNorm partials): 160 x 256 tiles, or 256 x 128 for N % 256 != 0
+// stride-1 k x k convolutions (bias; optional residual; optional GroupNorm partials), N % 256 == 0: 160 x 256 tiles.
+// (WR = 4 tiles for 128-channel layers -- 256 x 128 and 320 x 128 -- were measured and LOSE to the 128 x 128 kernel on the 0.25-degree
+// model's last UpBlock, 133.7 - 146 us against 120: K = 1152 is 18 K tiles per output tile, and the epilogue's share is what the
+// 128 x 128 kernel's four workgroups per CU hide; profiles/r06_gemm8p_probe_b_conv_form.txt.  The instantiations are not built.)
 inline void launch_gemm8p_conv(const Gemm8pParams& p, hipStream_t stream) {
   const bool res = p.res != nullptr, gn = p.gn_out != nullptr;
-  if (p.N % 256 == 0) {
-    if (res) { if (gn) launch_gemm8p_v<2, 5, true, false, false, true, false, true>(p, stream); else launch_gemm8p_v<2, 5, true, false, false, true, false, false>(p, stream); }
-    else { if (gn) launch_gemm8p_v<2, 5, true, false, false, false, false, true>(p, stream); else launch_gemm8p_v<2, 5, true, false, false, false, false, false>(p, stream); }
-  } else {
-    if (res) { if (gn) launch_gemm8p_v<4, 4, true, false, false, true, false, true>(p, stream); else launch_gemm8p_v<4, 4, true, false, false, true, false, false>(p, stream); }
-    else { if (gn) launch_gemm8p_v<4, 4, true, false, false, false, false, true>(p, stream); else launch_gemm8p_v<4, 4, true, false, false, false, false, false>(p, stream); }
-  }
+  if (p.N % 256 != 0) throw std::runtime_error("gemm8p conv: N % 256 != 0");
+  if (res) { if (gn) launch_gemm8p_v<2, 5, true, false, false, true, false, true>(p, stream); else launch_gemm8p_v<2, 5, true, false, false, true, false, false>(p, stream); }
+  else { if (gn) launch_gemm8p_v<2, 5, true, false, false, false, false, true>(p, stream); else launch_gemm8p_v<2, 5, true, false, false, false, false, false>(p, stream); }
 }
-inline int gemm8p_conv_gn_tiles(int64_t M, int N) { return N % 256 == 0 ? (int)cdiv(M, (int64_t)160) * 2 : (int)cdiv(M, (int64_t)256) * 4; }
+inline int gemm8p_conv_gn_tiles(int64_t M, int N) { return (int)cdiv(M, (int64_t)160) * 2; }
 
 }  // namespace wx

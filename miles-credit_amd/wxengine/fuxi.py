@@ -73,6 +73,13 @@ class FuxiConfig:
     # (fuxi.py:4-5, 250-260) and what its checkpoints contain; "cr" = credit/models/swin.py's V2-Cr block (the variant whose goldens
     # come from reference code -- timm is not installable here, so the timm variant follows timm's published block: parity unpinned)
     stage: str = "timm"
+    # timm stage only: does attn.qkv read `weight_orig` UN-normalised?  True reproduces what the reference module computes when it is built
+    # on the CPU, loaded with load_state_dict and called without being moved or cast in between (see TIMM_UNNORMALISED below: timm's
+    # WindowAttention reads `self.qkv.weight` without calling the module, so spectral_norm's pre-hook never runs and `weight` is still the
+    # alias of `weight_orig`).  After `.to(device)` / `.half()` / any `module._apply`, torch rebuilds `weight` as a separate tensor holding
+    # the LAST value the hook computed -- a maintainer who runs the reference that way (or who trains: the hook fires in train mode's
+    # power iteration through other paths) sets this to False and gets `weight_orig / sigma` like every other layer.
+    timm_qkv_unnormalised: bool = True
 
     @classmethod
     def from_model_conf(cls, conf: Dict) -> "FuxiConfig":
@@ -270,6 +277,9 @@ def _sn_matrix(prefix: str, w: np.ndarray) -> np.ndarray:
 # torch.nn.utils.spectral_norm installs (fuxi.py:16-22) never fires for it, and the plain `weight` attribute it reads is the alias of
 # `weight_orig` the hook-based implementation leaves behind (checked here with torch alone: after load_state_dict,
 # `m.weight.data_ptr() == m.weight_orig.data_ptr()` until the module itself is called).  The effective qkv weight is weight_orig.
+# PRECONDITION: that aliasing holds only for a module that has not been moved or cast since apply_spectral_norm (CPU, fp32, no
+# `_apply`); FuxiConfig.timm_qkv_unnormalised = False selects the normalised weight for the other case.  No reference golden pins
+# either choice (timm is not installable here): `tools/make_goldens.py --only fuxi_timm` generates one wherever `import timm` works.
 TIMM_UNNORMALISED = (".attn.qkv",)
 
 
@@ -340,7 +350,8 @@ class FuxiHIP:
             got = tuple(sd[k].shape)
             if got != tuple(shape):
                 raise ValueError(f"FuxiHIP.load_state_dict: {k} has shape {got}, expected {tuple(shape)}")
-        eff = fold_spectral_norm(OrderedDict((k, sd[k]) for k in spec), raw=TIMM_UNNORMALISED if cfg.stage == "timm" else ())
+        eff = fold_spectral_norm(OrderedDict((k, sd[k]) for k in spec),
+                                 raw=TIMM_UNNORMALISED if (cfg.stage == "timm" and cfg.timm_qkv_unnormalised) else ())
         ws = (cfg.window_size, cfg.window_size)
         if cfg.stage == "timm":
             for k, v in eff.items():

@@ -84,3 +84,30 @@ def two_source_conf():
                 "aux": {"levels": None, "variables": {
                     "prognostic": grp(v2=("sst", "ice")), "static": grp(v2=("depth",)),
                     "dynamic_forcing": grp(v2=("tide", "wind")), "diagnostic": grp(v2=("flux",))}}}}}
+
+
+def gen2loop_schema(cfg):
+    """Variable keys of a gen-2 forecast on a CrossFormer config: (input keys with level counts, output keys with level counts)."""
+    L = cfg.levels
+    inp = [(f"era5/prognostic/3d/{v}", L) for v in "UVTQ"[:cfg.channels]] + [(f"era5/prognostic/2d/s{i}", 1) for i in range(cfg.surface_channels)]
+    inp += [("era5/static/2d/LSM", 1), ("era5/static/2d/Z", 1), ("era5/dynamic_forcing/2d/tsi", 1), ("era5/dynamic_forcing/2d/sza", 1)]
+    out = inp[:cfg.channels + cfg.surface_channels] + [(f"era5/diagnostic/2d/d{i}", 1) for i in range(cfg.output_only_channels)]
+    return inp, out
+
+
+def gen2loop_batches(cfg, n_steps=3, seed=77):
+    """Initial condition, n_steps - 1 forcing batches (physical units, [1, n_levels, 1, H, W]) and per-variable statistics for the
+    composed gen-2 loop (tools/make_goldens.py --only gen2loop drives the reference's run_forecast with exactly these)."""
+    inp, out = gen2loop_schema(cfg)
+    gen = np.random.Generator(np.random.Philox(key=[seed, 1]))
+    H, W = cfg.image_height, cfg.image_width
+
+    def field(nl, scale=1.0, shift=0.0):
+        return torch.from_numpy((gen.standard_normal((1, nl, 1, H, W)) * scale + shift).astype(np.float32))
+    mean = {k.split("/")[-1]: (np.arange(nl, dtype=np.float32) * 0.1 + 0.3) for k, nl in inp[:-2]}
+    std = {k.split("/")[-1]: (np.arange(nl, dtype=np.float32) * 0.2 + 1.5) for k, nl in inp[:-2]}
+    mean.update({f"d{i}": np.float32(0.1 * i) for i in range(cfg.output_only_channels)})
+    std.update({f"d{i}": np.float32(2.0 + i) for i in range(cfg.output_only_channels)})
+    ic = {"input": {"era5": {k: field(nl, 1.5, 0.3) for k, nl in inp}}}
+    frcs = [{"input": {"era5": {k: field(1) for k, _ in inp[-2:]}}} for _ in range(n_steps - 1)]
+    return ic, frcs, mean, std

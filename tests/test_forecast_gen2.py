@@ -1,6 +1,7 @@
 """Gen-2 named-tensor forecast loop (wxengine/forecast.py): the routing function against a golden of
-the reference's `assemble_rollout_batch`, and -- on the GPU -- three autoregressive steps of the device loop against an
-independent CPU oracle loop (oracle model + oracle preblock, restated routing)."""
+the reference's `assemble_rollout_batch`, and -- on the GPU -- three autoregressive steps of the device loop against (a) a golden written
+by the reference's OWN `run_forecast` (tests/golden/gen2_loop_T0.npz, tools/make_goldens.py --only gen2loop: reference preblocks, model,
+Reconstruct, assemble_rollout_batch, composed by the reference's loop) in every precision and (b) an independent CPU oracle loop."""
 import os
 
 import numpy as np
@@ -100,3 +101,48 @@ def test_three_step_device_loop_vs_oracle_loop():
             a, b = got[step][k].numpy(), want[step][k].numpy()
             assert a.shape == b.shape
             assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1.0), (step, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])
+def test_three_step_device_loop_vs_reference_run_forecast(prec):
+    """The composed loop against the reference's own: same IC, forcings and statistics (tests/synth_batches.gen2loop_batches), three steps
+    of `credit.trainers.rollout_utils.run_forecast` on the reference CrossFormer stored by tools/make_goldens.py --only gen2loop."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from synth_batches import gen2loop_batches, gen2loop_schema
+    from wxengine.model import WXFormerHIP
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gen2_loop_T0.npz"))
+    cfg = named_config("T0")
+    sd = synth_state_dict(cfg)
+    ic, frcs, mean, std = gen2loop_batches(cfg, 3)
+    _, out = gen2loop_schema(cfg)
+    cmap, cur = {}, 0
+    for k, nl in out:
+        cmap[k] = {"slice": slice(cur, cur + nl), "orig_shape": (nl, 1)}
+        cur += nl
+    mc = dict(image_height=37, image_width=72, frames=1, channels=4, surface_channels=4, input_only_channels=4,
+              output_only_channels=3, levels=3, dim=[32, 64, 128, 256], depth=[1, 1, 2, 1],
+              global_window_size=[4, 2, 2, 1], local_window_size=3,
+              cross_embed_kernel_sizes=[[4, 8, 16, 32], [2, 4], [2, 4], [2, 4]], cross_embed_strides=[2, 2, 2, 2],
+              padding_conf=dict(activate=True, mode="earth", pad_lat=[6, 6], pad_lon=[12, 12]), post_conf=dict(activate=False))
+    model = WXFormerHIP(precision=prec, **mc).to("cuda").eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    cu = lambda b: {"input": {s: {k: v.cuda() for k, v in d.items()} for s, d in b["input"].items()}}  # noqa: E731
+    got = []
+    run_forecast(model, cu(ic), [cu(f) for f in frcs], 3, cmap, mean, std, [InverseScale(mean, std)],
+                 lambda yp, step: got.append({k: v.cpu() for k, v in yp["era5"].items()}))
+    assert len(got) == 3 and list(got[0].keys()) == [str(k) for k in g["keys"]]
+    worst = 0.0
+    for step in range(3):
+        for k in got[step]:
+            a, b = got[step][k].numpy()[..., ::2, ::2], g[f"step{step}:{k}"]
+            assert a.shape == b.shape, (step, k, a.shape, b.shape)
+            if prec in ("fp32", "fp32s"):
+                err = np.abs(a - b).max() / max(np.abs(b).max(), 1.0)
+                assert err <= 2e-4, (prec, step, k, err)
+            else:
+                err = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+                assert err <= 3e-2, (prec, step, k, err)
+            worst = max(worst, float(err))
+    print(f"[gen-2 loop vs reference run_forecast] {prec}: worst {'rel max' if prec != 'bf16' else 'rel-L2'} error over 3 steps x {len(got[0])} variables {worst:.2e}")

@@ -180,9 +180,16 @@ def test_full_length_rollout_vs_reference_trajectory(name, prec):
     x0 = torch.from_numpy(synth_input(cfg)).cuda()
     frcs = [torch.from_numpy(synth_forcing(cfg, 2, t + 1)).cuda() for t in range(n)]
     ys, x = [], x0
+    dense_steps = [int(v) for v in g["dense_steps"]] if "dense_steps" in g.files else []
+    ds = int(g["dense_stride"]) if dense_steps else 1
+    dense, sums = {}, []
     for t in range(n):                 # wx_step keeps the normalised output (the golden's quantity); wx_rollout is checked above
         y, _, xn = eng.step(x, frcs[t], want_phys=False)
         ys.append(y[0, :, 0, ::s, ::s].cpu().numpy().astype(np.float64))
+        yd = y[0, :, 0].double()       # every pixel of every channel: per-channel (sum, sum of squares) against the golden's ch_sums
+        sums.append(torch.stack([yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))]).cpu().numpy())
+        if t + 1 in dense_steps:
+            dense[t + 1] = y[0, :, 0, ::ds, ::ds].cpu().numpy().astype(np.float64)
         x = xn
     ref, floor = g["y"].astype(np.float64), g["ref_vs_fp64_rel_l2"]
     o64 = g["y64"].astype(np.float64) if g["y64"].size else ref      # no fp64 trajectory at this size: the reference alone
@@ -192,12 +199,34 @@ def test_full_length_rollout_vs_reference_trajectory(name, prec):
     for t in range(n):
         print(f"  t={t + 1:2d}  {rel[t]:.3e}  {rel64[t]:.3e}  {floor[t]:.3e}")
     assert all(np.isfinite(v) for v in rel)
+    n_pix = float(cfg.image_height * cfg.image_width)
+    ch = g["ch_sums"].astype(np.float64)          # [n_steps, 2, C_out] of the reference's full maps
+    worst_s = worst_q = 0.0
     for t in range(n):
         if prec in ("fp32", "fp32s"):
             bound = 1e-4 * (t + 1) if np.isnan(floor[t]) else max(1e-4 * (t + 1), 4.0 * floor[t])
             assert rel[t] <= bound, f"{prec} step {t + 1}: {rel[t]:.3e} (bound {bound:.3e})"
         else:
+            bound = BF16_BOUND
             assert rel[t] <= BF16_BOUND, f"bf16 step {t + 1}: rel-L2 {rel[t]:.3e}"
+        # the strided sample sees one pixel in stride^2; the channel sums see every pixel.  A map whose error has rel-L2 e moves a channel's
+        # sum by at most sqrt(N * sum sq) * e (Cauchy-Schwarz) and its sum of squares by about 2 e: both held to the step's own bound,
+        # channel by channel (a channel-local defect -- a wrong tap at a map border, a bad tile -- shows here and not in the global norm)
+        ds1 = np.abs(sums[t][0] - ch[t, 0]) / np.sqrt(n_pix * ch[t, 1])
+        ds2 = np.abs(sums[t][1] - ch[t, 1]) / ch[t, 1]
+        worst_s, worst_q = max(worst_s, float(ds1.max())), max(worst_q, float(ds2.max()))
+        assert ds1.max() <= bound, f"{prec} step {t + 1}: channel {int(ds1.argmax())} sum off by {ds1.max():.3e} of sqrt(N sum sq) (bound {bound:.3e})"
+        assert ds2.max() <= 2.5 * bound, f"{prec} step {t + 1}: channel {int(ds2.argmax())} sum of squares off by {ds2.max():.3e} (bound {2.5 * bound:.3e})"
+    print(f"  channel sums over full maps: worst |d sum| / sqrt(N sum sq) {worst_s:.3e}, worst |d sum sq| / sum sq {worst_q:.3e}")
+    for i, st in enumerate(dense_steps):   # round 6: stride-16 samples of a few steps (6x the points of the stride-40 sample each)
+        want = g["y_dense"][i].astype(np.float64)
+        r = float(np.linalg.norm(dense[st] - want) / np.linalg.norm(want))
+        if prec in ("fp32", "fp32s"):
+            bound = 1e-4 * st if np.isnan(floor[st - 1]) else max(1e-4 * st, 4.0 * floor[st - 1])
+        else:
+            bound = BF16_BOUND
+        print(f"  dense sample (stride {ds}) t={st}: rel-L2 {r:.3e}")
+        assert r <= bound, f"{prec} dense sample step {st}: {r:.3e} (bound {bound:.3e})"
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp32s", "bf16"])

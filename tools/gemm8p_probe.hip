@@ -317,8 +317,8 @@ int main(int argc, char** argv) {
   if (set >= 0 && !getenv("WX_NO_CONV")) {
     struct CShape { int H, W, C, N; const char* name; };
     std::vector<CShape> cs = {{100, 200, 512, 512, "up1 conv3 100x200 512->512"}, {200, 400, 256, 256, "up2 conv3 200x400 256->256"},
-                              {400, 800, 128, 128, "up3 conv3 400x800 128->128"}, {37, 53, 128, 256, "ragged   37x53   128->256"},
-                              {41, 29, 128, 128, "ragged   41x29   128->128"}};
+                              {37, 53, 128, 256, "ragged   37x53   128->256"},
+                              {41, 29, 128, 512, "ragged   41x29   128->512"}};
     char* zero = (char*)dalloc(256);
     WX_HIP(hipMemset(zero, 0, 256));
     for (const CShape& c : cs) {

@@ -202,7 +202,7 @@ def glue_golden():
     np.savez_compressed(os.path.join(GOLD, "rollout_T0.npz"), **out)
 
 
-def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base"):
+def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base", dense_steps=(), dense_stride=16):
     """Row R of SURVEY.md 8(a): the predict() loop (rollout_to_netcdf.py:262-316) for n_steps steps on a full-size grid, through the
     reference's own pieces -- CrossFormer forward (fp32, CPU), TracerFixer, y*std+mean, update_x -- and, beside it, the same
     trajectory from the fp64 oracle (oracle/wxformer_oracle.py::rollout).  Stored per step: strided samples of the
@@ -224,7 +224,7 @@ def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base"):
     ac = []
     out = {"tracer_inds": np.array(q_inds), "tracer_thres": np.array(thres, dtype=np.float32), "n_static": np.int64(2),
            "n_dyn": np.int64(2), "stride": np.int64(stride), "n_steps": np.int64(n_steps)}
-    ys, y64s, sums, rel = [], [], [], []
+    ys, y64s, sums, rel, dense = [], [], [], [], []
     t0 = time.time()
     with torch.no_grad():
         for step in range(1, n_steps + 1):
@@ -244,6 +244,8 @@ def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base"):
                 ac.append(float((y16 - y).norm() / y.norm()))
             ys.append(y[0, :, 0, ::stride, ::stride].numpy().astype(np.float32))
             y64s.append(y64[0, :, 0, ::stride, ::stride].numpy().astype(np.float32))
+            if step in dense_steps:   # a denser sample of a few steps (the strided one is one pixel in 1 600)
+                dense.append(y[0, :, 0, ::dense_stride, ::dense_stride].numpy().astype(np.float32))
             s1, s2, _ = channel_stats(y)
             sums.append(np.stack([s1, s2]))
             d = (y.double() - y64)[0, :, 0]
@@ -254,6 +256,8 @@ def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base"):
     # the fp64 oracle's trajectory at the same points (without it: an empty array -- tests then gate against the reference alone)
     out["y64"] = np.stack(y64s) if with_fp64 else np.zeros((0,), np.float32)
     out["ch_sums"] = np.stack(sums)    # [n_steps, 2, C_out] float64
+    if dense:
+        out["y_dense"], out["dense_steps"], out["dense_stride"] = np.stack(dense), np.array(list(dense_steps)), np.int64(dense_stride)
     out["ref_vs_fp64_rel_l2"] = np.array(rel) if with_fp64 else np.full(n_steps, np.nan)
     if ac:
         out["bf16_autocast_l2"] = np.array(ac)
@@ -715,6 +719,101 @@ def assemble_golden():
     print("[golden] assemble_rollout_batch:", dict(zip(res["keys"], res["vals"])))
 
 
+
+def gen2loop_golden():
+    """The COMPOSED gen-2 loop: the reference's own `run_forecast` (credit/trainers/rollout_utils.py:204-319) driven for three steps on T0
+    -- its `apply_preblocks` over the reference's ERA5Normalizer (statistics injected: xarray is absent) + ConcatToTensor (with a
+    ChannelSchema, so the diagnostics reach the target channel map as at inference), the reference CrossFormer, its `apply_postblocks`
+    over the reference's Reconstruct and an inverse scaler, its `assemble_rollout_batch` between steps.  The inverse scaler is the one
+    block that is not reference code (the reference's is a bridgescaler wrapper; bridgescaler is not installable here): y * std + mean
+    per variable, written here as a BasePostblock.  Stored: every y_processed variable of every step (stride 2 in both map axes)."""
+    import credit.trainers.rollout_utils as RU
+    from credit.datasets.gen_2.channel_utils import ChannelSchema
+    from credit.postblock.base import BasePostblock
+    from credit.postblock.reconstruct import Reconstruct
+    from credit.preblock.concat import ConcatToTensor
+    from credit.preblock.norm import ERA5Normalizer
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth_batches import gen2loop_batches, gen2loop_schema
+    cfg = named_config("T0")
+    n_steps = 3
+    ic, frcs, mean, std = gen2loop_batches(cfg, n_steps)
+    inp, out = gen2loop_schema(cfg)
+
+    norm = ERA5Normalizer.__new__(ERA5Normalizer)
+    torch.nn.Module.__init__(norm)
+    norm._mean = {k: torch.tensor(np.array(v), dtype=torch.float32) for k, v in mean.items()}
+    norm._std = {k: torch.tensor(np.array(v), dtype=torch.float32) for k, v in std.items()}
+    concat = ConcatToTensor()
+    concat.set_schema(ChannelSchema([{"var_key": k, "n_levels": nl, "n_time": 1} for k, nl in inp],
+                                    [{"var_key": k, "n_levels": nl, "n_time": 1} for k, nl in out]))
+
+    class InverseScale(BasePostblock):
+        def forward(self, batch_dict):
+            for src, variables in batch_dict["y_processed"].items():
+                for key in list(variables):
+                    name = key.split("/")[-1]
+                    if name in mean:
+                        variables[key] = variables[key] * torch.as_tensor(std[name]).reshape(1, -1, 1, 1, 1) + torch.as_tensor(mean[name]).reshape(1, -1, 1, 1, 1)
+            return batch_dict
+    step_pre = torch.nn.ModuleDict({"norm": norm, "concat": concat})
+    step_post = torch.nn.ModuleDict({"reconstruct": Reconstruct(), "inverse_scaler": InverseScale()})
+    model = reference_model(cfg)
+    t0 = np.datetime64("2020-01-01T00").astype("datetime64[ns]").astype(np.int64)
+    ic_batch = {"input": ic["input"], "metadata": {"era5": {"input_datetime": torch.tensor([int(t0)])}}}
+    RU.decode_time = lambda ns, calendar="standard": __import__("pandas").Timestamp(int(ns))   # cftime is absent; the standard calendar is plain pandas
+    got = []
+
+    def save(y_processed, init_time, step, fhr_per_step, save_dir, pool):
+        got.append({k: v.clone() for k, v in y_processed["era5"].items()})
+    conf = {"data": {"timestep": "6h", "history_len": 1}}
+    RU.run_forecast(conf, n_steps, "unused", torch.nn.ModuleDict(), step_pre, step_post, torch.nn.ModuleDict(), model,
+                    iter([ic_batch] + frcs), torch.device("cpu"), None, save, verbose=False)
+    assert len(got) == n_steps
+    res = {"keys": np.array(list(got[0].keys()))}
+    for s, d in enumerate(got):
+        for k, v in d.items():
+            res[f"step{s}:{k}"] = v.numpy()[..., ::2, ::2]
+    np.savez_compressed(os.path.join(GOLD, "gen2_loop_T0.npz"), **res)
+    print(f"[golden] gen-2 composed loop (reference run_forecast, T0, {n_steps} steps): {len(got[0])} variables per step, "
+          f"max |y| {max(float(v.abs().max()) for v in got[-1].values()):.3f}")
+
+
+def fuxi_timm_golden():
+    """BASELINE config 5's default stage variant is timm's SwinTransformerV2Stage, and timm is not installable in the build container:
+    the engine's timm block follows timm's published source and is unpinned.  This entry pins it wherever `import timm` works: it builds
+    the reference Fuxi (credit/models/fuxi.py) at the FT0 geometry with the real timm stage, loads the build's synthetic weights and
+    writes tests/golden/fuxi_timm_FT{0,1,2}T.npz, which tests/test_fuxi.py picks up (and skips, loudly, while the files are absent)."""
+    try:
+        import timm  # noqa: F401
+        if "MagicMock" in type(timm).__name__ or not hasattr(timm, "__version__") or not isinstance(timm.__version__, str):
+            raise ImportError("timm is the oracle stub")
+    except Exception as e:   # noqa: BLE001
+        print(f"[golden] fuxi_timm: SKIPPED -- `import timm` does not give the real package here ({e}); run "
+              "`python tools/make_goldens.py --only fuxi_timm` in an environment that has timm to pin BASELINE config 5's default stage")
+        return
+    from credit.models.fuxi import Fuxi
+    from wxengine.fuxi import named_fuxi_config, synth_fuxi_state_dict
+    from wxengine.synth import keyed_normal
+    for name in ("FT0T", "FT1T", "FT2T"):   # tests/test_fuxi.py's three geometries with the reference's own stage
+        cfg = named_fuxi_config(name)
+        m = Fuxi(image_height=cfg.image_height, patch_height=cfg.patch_height, image_width=cfg.image_width, patch_width=cfg.patch_width,
+                 levels=cfg.levels, frames=cfg.frames, frame_patch_size=cfg.frame_patch_size, dim=cfg.dim, num_groups=cfg.num_groups,
+                 channels=cfg.channels, surface_channels=cfg.surface_channels, input_only_channels=cfg.input_only_channels,
+                 output_only_channels=cfg.output_only_channels, num_heads=cfg.num_heads, depth=cfg.depth, window_size=cfg.window_size,
+                 use_spectral_norm=cfg.use_spectral_norm, interp=cfg.interp)
+        sd = synth_fuxi_state_dict(cfg)
+        res = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        bad = [k for k in list(res.missing_keys) + list(res.unexpected_keys) if not k.endswith(("relative_position_index", "relative_coords_table", "attn_mask"))]
+        assert not bad, f"{name}: the synthetic state dict and the reference module disagree on keys: {bad[:6]}"
+        m.eval()   # built and loaded on the CPU, never moved or cast: the case FuxiConfig.timm_qkv_unnormalised = True describes
+        x = torch.from_numpy(keyed_normal("fuxi/x0", (1, cfg.in_chans, cfg.frames, cfg.image_height, cfg.image_width), 1000))
+        with torch.no_grad():
+            y = m(x)
+        np.savez_compressed(os.path.join(GOLD, f"fuxi_timm_{name}.npz"), y=y[0, :, 0].numpy().astype(np.float32), timm_version=np.array(timm.__version__))
+        print(f"[golden] fuxi_timm {name}: y {tuple(y.shape)} mean|y| {float(y.abs().mean()):.4f} (timm {timm.__version__})")
+
+
 SIGMA_A = np.array([200.0, 5000.0, 12000.0, 14000.0, 9000.0, 3000.0, 0.0], dtype=np.float32)       # Pa
 SIGMA_B = np.array([0.0, 0.0, 0.08, 0.3, 0.6, 0.88, 1.0], dtype=np.float32)
 
@@ -780,7 +879,7 @@ def fixers_sigma_golden():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,fuxi,attend,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,C1,C3S,C3,T0W,C1W,T0U,T0F,RT,stress")
+    ap.add_argument("--only", default="pad,T0,T1,glue,swin,swinblock,fuxi,attend,rollC1,rollC3S,rollC3,T0M,layout,fixers,sigma,updown,pre,gen2,rec,asm,gen2loop,fuxi_timm,C1,C3S,C3,T0W,C1W,T0U,T0F,RT,stress")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -804,7 +903,7 @@ def main():
         elif item == "rollC1stress":   # 8 steps of the 1-degree model on the "stress" weight family (logits +-40, pre-GELU 1e2)
             long_rollout_golden("C1", 8, 20, family="stress")
         elif item == "rollC3":      # BASELINE config 3 itself: its 40 steps of the FULL-width 124 M-parameter model on the 0.25-degree grid
-            long_rollout_golden("C3", 40, 40, with_fp64=False)   # (rounds 2-4 stored 6 steps; ~30 min of CPU for 40)
+            long_rollout_golden("C3", 40, 40, with_fp64=False, dense_steps=(1, 10, 20, 40), dense_stride=16)   # (rounds 2-4 stored 6 steps; ~30 min of CPU for 40; round 6: + stride-16 samples of four steps)
         elif item == "layout":
             layout_golden()
         elif item == "fixers":
@@ -821,6 +920,10 @@ def main():
             reconstruct_golden()
         elif item == "asm":
             assemble_golden()
+        elif item == "gen2loop":    # the composed gen-2 loop through the reference's own run_forecast
+            gen2loop_golden()
+        elif item == "fuxi_timm":   # BASELINE config 5's default stage: only where `import timm` works (skips loudly otherwise)
+            fuxi_timm_golden()
         elif item in ("T0", "T1", "T0W", "T0U", "T0M", "T0F", "T0H", "T1H", "T0X"):
             model_golden(item, 1, capture_layers=(item in ("T0", "T0W", "T0U")))
         elif item == "RT":   # the model of the reference's own tests/test_crossformer.py
