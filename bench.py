@@ -239,23 +239,38 @@ def main():
         peak = PEAK_TFLOPS[args.precision]
         # HBM traffic of the same kernel from the PMC passes of tools/collect_profiles.sh (rocprofv3 cannot run inside
         # this process; the summary is committed next to the kernel-stats it was collected with)
-        traffic, traffic_note = None, None
-        tname = next((n for n in ("pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r01.json") if os.path.isfile(os.path.join(ROOT, "profiles", n))), None)
+        traffic, traffic_note, traffic_step = None, None, None
+        tname = next((n for n in ("pmc_traffic_r06.json", "pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r01.json") if os.path.isfile(os.path.join(ROOT, "profiles", n))), None)
         if args.config == "C3" and args.precision == "bf16" and tname:
             pj = json.load(open(os.path.join(ROOT, "profiles", tname)))
             kern = pj["kernels"]
             lib_hash = eng.lib.wx_version().decode().rsplit("wxsrc:", 1)[-1]
-            fam = [kern[k] for k in ("wx::conv_gemm_dma_kernel", "wx::gemm_stream_kernel") if k in kern]
+            fam = [kern[k] for k in ("wx::conv_gemm_dma_kernel", "wx::gemm_stream_kernel", "wx::gemm8p_kernel") if k in kern]
             if pj.get("wxsrc") != lib_hash:
                 # the counters were collected on ANOTHER build of the library (or before round 5 stamped them): not this run's traffic
                 traffic_note = (f"stale: profiles/{tname} was collected on library wxsrc:{pj.get('wxsrc')}, this run loaded wxsrc:{lib_hash} "
                                 "(re-collect with tools/collect_profiles.sh)")
-            elif fam:   # launch-weighted mean over the two GEMM kernel families
+            elif fam:   # launch-weighted mean over the GEMM kernel families
                 nl = sum(k.get("launches", 1) for k in fam)
                 traffic = round(sum((k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) * k.get("launches", 1) for k in fam) / nl)
+                traffic_step = pj.get("engine_bytes_per_step")
+        # the same family's kernel time by rocprofv3 (tools/collect_profiles.sh -> profiles/kernel_time_<tag>.json, hash-stamped like the
+        # traffic): HIP events around every launch inflate the in-process sum by 5-8 %, so `frac` (events) UNDER-states the kernel
+        frac_rocprof, rocprof_note, rocprof_us = None, None, None
+        kname = next((n for n in ("kernel_time_r06.json",) if os.path.isfile(os.path.join(ROOT, "profiles", n))), None)
+        if args.config == "C3" and args.precision == "bf16" and kname:
+            kj = json.load(open(os.path.join(ROOT, "profiles", kname)))
+            lib_hash = eng.lib.wx_version().decode().rsplit("wxsrc:", 1)[-1]
+            if kj.get("wxsrc") != lib_hash:
+                rocprof_note = f"stale: profiles/{kname} is of library wxsrc:{kj.get('wxsrc')}, this run loaded wxsrc:{lib_hash}"
+            elif kj.get("gemm_family_us_per_step"):
+                rocprof_us = kj["gemm_family_us_per_step"]
+                frac_rocprof = round((g_fl / nprof) / (rocprof_us * 1e-6) / 1e12 / peak, 4)
         roofline = {
             "bound": "mfma", "kernel": "wx::conv_gemm_dma_kernel + wx::gemm_stream_kernel (implicit-GEMM MFMA convs; all gemm_* launches)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "frac_events": round(achieved / peak, 4), "frac_rocprof": frac_rocprof, "rocprof_kernel_us_per_step": rocprof_us, "rocprof_note": rocprof_note,
+            "traffic_per_step": traffic_step, "algorithmic_bytes_per_step": 5.9e9 if args.config == "C3" and args.precision == "bf16" else None,
             "traffic": traffic, "traffic_unit": f"HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE; profiles/{tname})", "traffic_note": traffic_note,
             "algorithmic_bytes_per_launch": round(sum(r["bytes"] for r in gemm) / max(g_n, 1)),
             "launches_per_step": g_n // nprof, "avg_launch_us": round(1e3 * g_ms / max(g_n, 1), 2),
@@ -292,14 +307,24 @@ def main():
             physical = psutil.cpu_count(logical=False) or logical
         except Exception:
             physical = logical
-        cores = min(physical, 32)
-        torch.set_num_threads(cores)
         xs = synth_input(cfg, seed=1000)
         n_cpu = max(1, args.cpu_steps)
-        times = []
+        # round 6: one timed step at 32 / 64 / 128 threads (capped at the physical cores), the best count then runs the remaining timed steps;
+        # every count's time is reported (256 threads = every logical CPU: 281 s/step, not repeated)
+        sweep_counts = sorted({min(c, physical) for c in (32, 64, 128)})
+        sweep = {}
         with torch.no_grad():
+            torch.set_num_threads(sweep_counts[0])
             O.forward(cfg, sd, xs)   # warm-up (thread pool, allocator, first-touch of the activation buffers): not timed
-            for _ in range(n_cpu):
+            for c in sweep_counts:
+                torch.set_num_threads(c)
+                t1 = time.perf_counter()
+                O.forward(cfg, sd, xs)
+                sweep[c] = time.perf_counter() - t1
+            cores = min(sweep, key=sweep.get)
+            torch.set_num_threads(cores)
+            times = [sweep[cores]]
+            for _ in range(n_cpu - 1):
                 t1 = time.perf_counter()
                 O.forward(cfg, sd, xs)
                 times.append(time.perf_counter() - t1)
@@ -307,9 +332,10 @@ def main():
         cpu_baseline = {"value": round(1.0 / cpu_s, 5), "unit": "forecast-steps/sec", "cores": cores, "kind": "port",
                         "physical_cores": physical, "logical_cpus": logical,
                         "seconds_per_step": [round(t, 2) for t in times],
-                        "sample": f"1 warm-up + {n_cpu} timed forecast steps (forward only; median reported) of the same {args.config} "
-                                  f"workload, torch CPU fp32 oracle, {cores} threads on {physical} physical cores "
-                                  f"({logical} logical CPUs), {cpu_s:.1f} s per step"}
+                        "seconds_per_step_by_threads": {str(c): round(t, 2) for c, t in sweep.items()},
+                        "sample": f"1 warm-up + one timed forecast step at each of {sweep_counts} threads + {n_cpu - 1} more at the best count "
+                                  f"({cores}; median of its {len(times)} steps reported) of the same {args.config} workload (forward only), torch CPU "
+                                  f"fp32 oracle on {physical} physical cores ({logical} logical CPUs), {cpu_s:.1f} s per step"}
 
     fp32 = fp32_split = None
     if rank == 0 and world == 1 and args.precision == "bf16" and not args.no_fp32:

@@ -1479,6 +1479,25 @@ class Engine : public EngineBase {
           return want_gn;
         }
       }
+      // ConvTranspose k2 s2 (a 1x1 GEMM with N = 4 cout whose epilogue scatters 2 x 2 pixels; the decoder's three UpBlocks): the same
+      // kernel's 1x1 form with the scatter in its epilogue -- 33.4 -> 24.6, 59.3 -> 41.9, 63.1 -> 47.3 us at 0.25 degrees, bitwise equal
+      {
+        const int64_t rows = (int64_t)out_h * out_w;
+        if (use_gemm8p && use_dma && !dbg_flags && !p.stat_out && !p.gn_out && w.kh == 1 && w.kw == 1 && stride == 1 && pad_y == 0 && pad_x == 0 &&
+            in_h == out_h && in_w == out_w && !rs && !res && act == 0 && out_mode == 1 && !want_stats && !want_gn && cout > 0 && w.n == 4 * cout &&
+            cout % 64 == 0 && w.cin % 128 == 0 && rwn < 0 && !band_on && rows >= gemm8p_min_rows / 4 && gemm8p_fits(rows, w.n, 2, 5, true)) {
+          Gemm8pParams q;
+          std::memset(&q, 0, sizeof(q));
+          q.a = reinterpret_cast<const bf16_t*>(in); q.lda = in_ld; q.w = reinterpret_cast<const bf16_t*>(wt_dev + w.wt);
+          q.M = (int)rows; q.N = w.n; q.K = w.cin; q.bias = p.bias;
+          q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink; q.xcd_part = 1;
+          q.scat_w = out_w; q.cout = cout;
+          cur_family = "gemm8p";
+          timed(cls, flops, bytes, [&] { launch_gemm8p_convt2<5>(q, cur_stream); });
+          ++n_gemm8p;
+          return false;
+        }
+      }
       // LayerNorm-folded 1x1 layers with many rows and K >= 512 (to_qkv, FeedForward layer 1 of stages 2-3): the persistent
       // 128 x 256-tile kernel; measured per shape against the 128 x 128 kernel in tools/gemm_stream_probe
       const bool one = w.kh == 1 && w.kw == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && in_h == out_h && in_w == out_w;

@@ -54,6 +54,9 @@ struct Gemm8pParams {
   char* sink;            // >= 8 KB of scratch: rows beyond M store here (keeps the epilogue branch-free)
   // conv form
   int in_h, in_w, cin, kh, kw, pad_y, pad_x;
+  // SCAT (ConvTranspose k2 s2 as a GEMM, wx_gemm.h out_mode 1): n = q * cout + co, q = dy * 2 + dx -> output pixel (2 oy + dy, 2 ox + dx) of a
+  // map twice as wide, channel co; the M rows are the scat_w-wide input map's pixels; cout % 64 == 0
+  int scat_w, cout;
   unsigned long long* trace;  // TRACE instantiations: [grid][2][8] s_memtime stamps
 };
 
@@ -77,7 +80,7 @@ __device__ __forceinline__ void lds_dma16_sv8(const void* sbase, unsigned voff, 
 constexpr int GEMM8P_MAX_TILES = 8;   // tiles per workgroup (LDS parameter slots); the host picks the grid accordingly
 
 // ABL (probe only; results wrong): 1 no epilogue, 2 no MFMAs, 4 no LDS-DMA, 8 no fragment reads
-template <int WR, int FM, bool CONV, bool LN, bool ACT, bool RES, bool STAT, bool GN, int ABL = 0, bool TRACE = false>
+template <int WR, int FM, bool CONV, bool LN, bool ACT, bool RES, bool STAT, bool GN, int ABL = 0, bool TRACE = false, bool SCAT = false>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
   constexpr int WC = 8 / WR;
   constexpr int FM0 = (FM + 1) / 2, FM1 = FM - FM0;
@@ -355,9 +358,26 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
     float s1[FM], s2[FM];
 #pragma unroll
     for (int b = 0; b < FM; ++b) s1[b] = s2[b] = 0.f;
+    int spix[FM];   // SCAT: output pixel of sub-pixel (0, 0) of this lane's rows
+    if constexpr (SCAT) {
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        int m = m0 + 16 * b;
+        m = m < p.M ? m : p.M - 1;
+        const int oy = m / p.scat_w;
+        spix[b] = 4 * oy * p.scat_w + 2 * (m - oy * p.scat_w);
+      }
+    }
 #pragma unroll
     for (int ap = 0; ap < 2; ++ap) {
       const int cl = wn * 64 + ap * 32 + g * 8;   // channel inside the N-tile
+      int sq_off = 0, sch = 0;
+      if constexpr (SCAT) {   // a 32-channel run lies inside one sub-pixel (cout % 64 == 0): q is wave-uniform
+        const int nq = n_blk + wn * 64 + ap * 32;
+        const int q = nq / p.cout;
+        sq_off = (q >> 1) * 2 * p.scat_w + (q & 1);
+        sch = n_blk + cl - q * p.cout;
+      }
       float bs[8], cs[8];
       {
         const float4 t0 = *reinterpret_cast<const float4*>(par + cl), t1 = *reinterpret_cast<const float4*>(par + cl + 4);
@@ -423,7 +443,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
           }
         }
         {
-          char* dst = reinterpret_cast<char*>(p.out + (int64_t)m * p.out_ld + n_blk + cl);
+          char* dst;
+          if constexpr (SCAT) dst = reinterpret_cast<char*>(p.out + ((int64_t)spix[b] + sq_off) * p.out_ld + sch);
+          else dst = reinterpret_cast<char*>(p.out + (int64_t)m * p.out_ld + n_blk + cl);
           dst = m < p.M ? dst : p.sink + tid * 16;
           *reinterpret_cast<uint4*>(dst) = o;
         }
@@ -625,12 +647,12 @@ inline int gemm8p_tiles_per_wg(const Gemm8pParams& p, unsigned grid) {
   return p.xcd_part ? cdiv(cdiv(p.mt, 8) * p.nt, (int)(grid / 8)) : cdiv(p.mt * p.nt, (int)grid);
 }
 
-template <int WR, int FM, bool CONV, bool LN, bool ACT, bool RES, bool STAT, bool GN, int ABL = 0, bool TRACE = false>
+template <int WR, int FM, bool CONV, bool LN, bool ACT, bool RES, bool STAT, bool GN, int ABL = 0, bool TRACE = false, bool SCAT = false>
 inline void launch_gemm8p_v(Gemm8pParams p, hipStream_t stream) {
   constexpr int BM = 16 * FM * WR, BN = 64 * (8 / WR);
   constexpr int LDS = 2 * (BM + BN) * 128 + GEMM8P_MAX_TILES * (2 * BN * 4 + BM * 8);
   static_assert(LDS <= 160 * 1024, "two K-tile buffers beyond the CU's LDS");
-  auto kern = gemm8p_kernel<WR, FM, CONV, LN, ACT, RES, STAT, GN, ABL, TRACE>;
+  auto kern = gemm8p_kernel<WR, FM, CONV, LN, ACT, RES, STAT, GN, ABL, TRACE, SCAT>;
   static uint64_t attr_done_mask = 0;
   if (!attr_done_on_device(attr_done_mask)) {
     WX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -640,6 +662,7 @@ inline void launch_gemm8p_v(Gemm8pParams p, hipStream_t stream) {
   const unsigned grid = gemm8p_grid(p);
   if (gemm8p_tiles_per_wg(p, grid) > GEMM8P_MAX_TILES) throw std::runtime_error("gemm8p: more tiles per workgroup than LDS parameter slots");
   if (p.K % 128 != 0 || p.N % BN != 0) throw std::runtime_error("gemm8p: N / K outside the kernel's rules");
+  if (SCAT && (p.cout % 64 != 0 || p.N != 4 * p.cout || p.scat_w < 1 || p.M % p.scat_w != 0)) throw std::runtime_error("gemm8p: ConvTranspose scatter geometry outside the kernel's rules");
   if (CONV && (p.cin % 64 != 0 || p.K != p.kh * p.kw * p.cin || (int64_t)p.in_h * p.in_w != p.M || p.kh * p.kw > 32 ||
                (int64_t)p.M * p.lda * 2 >= (int64_t)0x7fffff00))
     throw std::runtime_error("gemm8p: convolution geometry outside the kernel's rules");
@@ -664,6 +687,11 @@ inline void launch_gemm8p(const Gemm8pParams& p, int variant, hipStream_t stream
     case 3: launch_gemm8p_v<2, FM, false, false, false, true, true, false>(p, stream); break;
     default: throw std::runtime_error("gemm8p: unknown epilogue variant");
   }
+}
+// ConvTranspose k2 s2 as a GEMM with the 2 x 2 pixel scatter in the epilogue (bias only)
+template <int FM>
+inline void launch_gemm8p_convt2(const Gemm8pParams& p, hipStream_t stream) {
+  launch_gemm8p_v<2, FM, false, false, false, false, false, false, 0, false, true>(p, stream);
 }
 // stride-1 k x k convolutions (bias; optional residual; optional GroupNorm partials), N % 256 == 0: 160 x 256 tiles.
 // (WR = 4 tiles for 128-channel layers -- 256 x 128 and 320 x 128 -- were measured and LOSE to the 128 x 128 kernel on the 0.25-degree

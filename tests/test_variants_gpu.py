@@ -159,7 +159,8 @@ def test_eight_phase_conv_forced_on_small_maps(name):
     decoder's 3x3 convs with >= 256 output channels on maps of >= 16384 pixels by itself -- the first two UpBlocks of the 0.25-degree model.
     WX_GEMM8P_MIN_ROWS=1 forces it onto T5 (512 -> 512 on 10 x 20 pixels: two ragged 160-row tiles x two N-tiles, K = 4608; 256 -> 256 on
     20 x 40) and C1 (256 -> 256 on 30 x 48): map borders on every side of a tile, rows beyond M in the last tile, GroupNorm partials per
-    80-row half tile.  Checked (a) against the same engine on the 128 x 128 kernel (`WX_NO_GEMM8P=1`), (b) per UpBlock against the CPU oracle
+    80-row half tile.  The same switch also routes the decoder's ConvTranspose k2 s2 layers (1x1 form, 2 x 2 pixel scatter in the
+    epilogue) through the kernel.  Checked (a) against the same engine on the 128 x 128 kernel (`WX_NO_GEMM8P=1`), (b) per UpBlock against the CPU oracle
     with the suite's bf16 gate, (c) run-to-run bit-identical (race screen), (d) that the kernel is what ran."""
     from oracle import wxformer_oracle as O
     cfg = named_config(name)
@@ -185,7 +186,8 @@ def test_eight_phase_conv_forced_on_small_maps(name):
     torch.cuda.synchronize()
     tagged = [r["name"] for r in e8.profile_read() if r["name"].endswith("@gemm8p")]
     e8.profile(0)
-    assert tagged and all(t.startswith("gemm_conv3") for t in tagged), tagged
+    assert tagged and all(t.startswith(("gemm_conv3", "gemm_convT2")) for t in tagged), tagged
+    assert any(t.startswith("gemm_conv3") for t in tagged) and any(t.startswith("gemm_convT2") for t in tagged), tagged
     ups = sorted(got["8p"][1])
     assert len(ups) >= 3, ups
     for k in ups:

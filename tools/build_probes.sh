@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_build
-for p in gemm_probe gemm256_probe attn_probe ff_probe l1_probe ffs_probe; do
+for p in gemm_probe gemm256_probe gemm8p_probe bufdma_probe attn_probe ff_probe l1_probe ffs_probe; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I miles-credit_amd/csrc tools/$p.hip -o tools/_build/$p
   echo "built tools/_build/$p"
 done

@@ -420,6 +420,76 @@ int main(int argc, char** argv) {
       for (void* ptr : {(void*)x, (void*)w, (void*)y0, (void*)y1, (void*)bias, (void*)g0, (void*)g1}) WX_HIP(hipFree(ptr));
     }
   }
+
+  // ---- ConvTranspose k2 s2 as a GEMM with the pixel scatter in the epilogue (decoder UpBlocks): 8p against conv_gemm_dma_kernel ------------
+  if (!getenv("WX_NO_CONVT")) {
+    struct TShape { int H, W, C, cout; const char* name; };
+    std::vector<TShape> ts = {{50, 100, 1024, 512, "up1 convT2 50x100 1024->512"}, {100, 200, 1024, 256, "up2 convT2 100x200 1024->256"},
+                              {200, 400, 512, 128, "up3 convT2 200x400 512->128"}, {13, 21, 256, 64, "ragged     13x21   256->64"}};
+    char* zero = (char*)dalloc(256);
+    WX_HIP(hipMemset(zero, 0, 256));
+    for (const TShape& c : ts) {
+      const int M = c.H * c.W, K = c.C, N = 4 * c.cout;
+      std::mt19937 rng(13);
+      std::uniform_real_distribution<float> u(-1.f, 1.f);
+      std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K);
+      for (auto& v : hx) v = f2bf(u(rng));
+      for (auto& v : hw) v = f2bf(u(rng) * 0.05f);
+      std::vector<float> hb(N);
+      for (auto& v : hb) v = u(rng) * 0.3f;
+      uint16_t* x = (uint16_t*)dalloc(hx.size() * 2);
+      uint16_t* w = (uint16_t*)dalloc(hw.size() * 2);
+      const size_t on = (size_t)4 * M * c.cout;
+      uint16_t* y0 = (uint16_t*)dalloc(on * 2);
+      uint16_t* y1 = (uint16_t*)dalloc(on * 2);
+      float* bias = (float*)dalloc(N * 4);
+      WX_HIP(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+      WX_HIP(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+      WX_HIP(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice));
+      ConvGemmParams p;
+      std::memset(&p, 0, sizeof(p));
+      p.in = x; p.in_h = c.H; p.in_w = c.W; p.in_ld = K; p.cin = K; p.kh = p.kw = 1; p.stride = 1;
+      p.out_h = c.H; p.out_w = c.W; p.wt = w; p.n = N; p.n_alloc = N; p.bias = bias; p.out = y0; p.out_ld = c.cout; p.out_mode = 1; p.cout = c.cout;
+      Gemm8pParams g;
+      std::memset(&g, 0, sizeof(g));
+      g.a = x; g.lda = K; g.w = w; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = y1; g.out_ld = c.cout; g.sink = sink; g.xcd_part = 1;
+      g.scat_w = c.W; g.cout = c.cout;
+      Gemm8pParams gf = g;
+      gf.xcd_part = 0;
+      auto run_prod = [&] { launch_conv_gemm<uint16_t>(p, zero, st, 0); };
+      auto run_5x = [&] { launch_gemm8p_convt2<5>(g, st); };
+      auto run_8f = [&] { launch_gemm8p_convt2<8>(gf, st); };
+      WX_HIP(hipMemset(y0, 0, on * 2));
+      WX_HIP(hipMemset(y1, 0xff, on * 2));
+      run_prod();
+      run_5x();
+      WX_HIP(hipStreamSynchronize(st));
+      std::vector<uint16_t> h0(on), h1(on), h2(on);
+      WX_HIP(hipMemcpy(h0.data(), y0, on * 2, hipMemcpyDeviceToHost));
+      WX_HIP(hipMemcpy(h1.data(), y1, on * 2, hipMemcpyDeviceToHost));
+      size_t ndiff = 0;
+      for (size_t i = 0; i < on; ++i) ndiff += h0[i] != h1[i];
+      WX_HIP(hipMemsetAsync(y1, 0xff, on * 2, st));
+      run_8f();
+      WX_HIP(hipStreamSynchronize(st));
+      WX_HIP(hipMemcpy(h2.data(), y1, on * 2, hipMemcpyDeviceToHost));
+      size_t ndiff8 = 0;
+      for (size_t i = 0; i < on; ++i) ndiff8 += h0[i] != h2[i];
+      double tp = 1e30, t5 = 1e30, t8 = 1e30;
+      for (int round = 0; round < 3; ++round) {
+        tp = std::min(tp, time_us(st, 10, run_prod));
+        t5 = std::min(t5, time_us(st, 10, run_5x));
+        t8 = std::min(t8, time_us(st, 10, run_8f));
+      }
+      const double fl = 2.0 * M * N * K * 1e-6;
+      const bool ok = ndiff == 0 && ndiff8 == 0;
+      if (!ok) ++bad;
+      printf("%-28s M=%6d N=%4d K=%5d | conv_gemm_dma %7.1f us %5.0f TF | 8p 160x256 xcd %7.1f us %5.0f TF | 8p 256x256 flat %7.1f us %5.0f TF | differing %zu / %zu  %s\n",
+             c.name, M, N, K, tp, fl / tp, t5, fl / t5, t8, fl / t8, ndiff, ndiff8, ok ? "OK" : "FAIL");
+      fflush(stdout);
+      for (void* ptr : {(void*)x, (void*)w, (void*)y0, (void*)y1, (void*)bias}) WX_HIP(hipFree(ptr));
+    }
+  }
   printf(bad ? "PROBE FAILED (%d shapes)\n" : "PROBE OK\n", bad);
   return bad ? 1 : 0;
 }

@@ -14,7 +14,7 @@ from collections import defaultdict
 
 def family(name):
     name = name.replace("void ", "")
-    for key in ("gemm_stream_kernel", "conv_gemm_dma_kernel", "conv_gemm_kernel", "ff_fused_kernel", "window_attn_kernel", "embed_patch_kernel"):
+    for key in ("gemm_stream_kernel", "gemm8p_kernel", "conv_gemm_dma_kernel", "conv_gemm_kernel", "ff_fused_kernel", "window_attn_kernel", "embed_patch_kernel"):
         if key in name:
             return "wx::" + key
     return name.split("(")[0][:60]
@@ -51,7 +51,14 @@ def main():
         wxsrc = wx_build.built_hash()
     except Exception:
         wxsrc = None
-    out = {"wxsrc": wxsrc,
+    steps = int(os.environ.get("WX_PMC_STEPS", "4"))   # forecast steps the profiled command ran (bench.py --steps 3 --warmup 1)
+    tot_f = sum(v["fetch_kb"] for v in fam.values() if True) * 2 * 1024
+    tot_w = sum(v["write_kb"] for v in fam.values()) * 1024
+    wx_f = sum(v["fetch_kb"] for k, v in fam.items() if k.startswith("wx::")) * 2 * 1024
+    wx_w = sum(v["write_kb"] for k, v in fam.items() if k.startswith("wx::")) * 1024
+    out = {"wxsrc": wxsrc, "steps_profiled": steps,
+           "engine_bytes_per_step": round((wx_f + wx_w) / steps), "engine_fetch_bytes_per_step": round(wx_f / steps),
+           "engine_write_bytes_per_step": round(wx_w / steps), "all_kernels_bytes_per_step": round((tot_f + tot_w) / steps),
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 "
                      "--warmup 1 --no-cpu-baseline --no-roofline",
            "corrections": "FETCH_SIZE x2 on gfx950 (128-byte requests tallied as 64 B); WRITE_SIZE uncalibrated; KB -> bytes x1024",

@@ -49,8 +49,40 @@ def counter_stats(path):
             print(f"{n:92s} {c:14s} dispatches={k:6d} sum={v:.6g} avg={v / k:.6g}")
 
 
+def kernel_time_json(root, out_path, steps):
+    """Per kernel family: launches and microseconds per forecast step, stamped with the library hash (bench.py reads it for
+    roofline.frac_rocprof: HIP events around every launch inflate the in-process kernel time by 5-8 %)."""
+    import json
+    fam = defaultdict(lambda: [0, 0.0])
+    for p in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
+        with open(p) as f:
+            for r in csv.DictReader(f):
+                n = (r.get("Kernel_Name") or "?").replace("void ", "")
+                key = n.split("<")[0].split("(")[0]
+                fam[key][0] += 1
+                fam[key][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miles-credit_amd"))
+    try:
+        import build as wx_build
+        wxsrc = wx_build.built_hash()
+    except Exception:
+        wxsrc = None
+    gemm = ("wx::gemm_stream_kernel", "wx::conv_gemm_dma_kernel", "wx::gemm8p_kernel", "wx::gemm_wreg_kernel", "wx::conv_gemm_kernel")
+    out = {"wxsrc": wxsrc, "steps_profiled": steps, "source": "rocprofv3 --kernel-trace -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline ...",
+           "engine_kernel_us_per_step": round(sum(v[1] for k, v in fam.items() if k.startswith("wx::")) / steps, 1),
+           "gemm_family_us_per_step": round(sum(v[1] for k, v in fam.items() if k in gemm) / steps, 1),
+           "gemm_family_launches_per_step": round(sum(v[0] for k, v in fam.items() if k in gemm) / steps, 2),
+           "window_attn_us_per_step": round(sum(v[1] for k, v in fam.items() if k == "wx::window_attn_kernel") / steps, 1),
+           "families": {k: {"launches_per_step": round(v[0] / steps, 2), "us_per_step": round(v[1] / steps, 1)} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]) if k.startswith("wx::")}}
+    json.dump(out, open(out_path, "w"), indent=1)
+
+
 if __name__ == "__main__":
     root = sys.argv[1]
+    if "--json" in sys.argv:
+        i = sys.argv.index("--json")
+        kernel_time_json(root, sys.argv[i + 1], int(sys.argv[i + 2]))
+        sys.exit(0)
     for p in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
         kernel_stats(p, by_grid="--by-grid" in sys.argv)
     for p in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
