@@ -340,6 +340,33 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
     }
   };
 
+  // RES: the tile's residual rows, requested by inline-asm loads in phase 1 of the tile's LAST K tile -- hipcc does not see them, so it
+  // plants no wait that would drain the LDS-DMA stream, and the HBM latency (two dependent round trips of ~2 k clocks per tile when the
+  // epilogue loads them itself: 14 k clocks of a 160 x 256 x 2048 tile's 79 k) hides behind three phases of MFMAs.  They are older than
+  // the three units the phase-4 wait leaves in flight, so that wait retires them; `res_landed` then makes the registers opaque to the
+  // compiler at that point (cdna_hip_programming.md 5.7 item 1, form (ii): no copy of them may be scheduled above it -- audited in the .s).
+  constexpr bool RESP = RES && FM <= 5;   // FM = 8 has no registers to hold them across four phases (it would spill them: fatal for an asm load's destination)
+  u32x4_t rres[2][FM];
+  auto res_prefetch = [&](int r) __attribute__((always_inline)) {
+    int m_blk, n_blk;
+    tile_of(r, m_blk, n_blk);
+#pragma unroll
+    for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+      for (int b = 0; b < FM; ++b) {
+        int m = m_blk + wm * 16 * FM + li + 16 * b;
+        m = m < p.M ? m : p.M - 1;
+        const bf16_t* src = p.res + (int64_t)m * p.res_ld + n_blk + wn * 64 + ap * 32 + g * 8;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rres[ap][b]) : "v"(src) : "memory");
+      }
+  };
+  auto res_landed = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+      for (int b = 0; b < FM; ++b) asm volatile("" : "+v"(rres[ap][b]));
+  };
+
   auto epilogue = [&](int r) __attribute__((always_inline)) {
     int m_blk, n_blk;
     tile_of(r, m_blk, n_blk);
@@ -388,7 +415,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
         cs[0] = t0.x; cs[1] = t0.y; cs[2] = t0.z; cs[3] = t0.w; cs[4] = t1.x; cs[5] = t1.y; cs[6] = t1.z; cs[7] = t1.w;
       }
       uint4 rv[FM];
-      if constexpr (RES) {
+      if constexpr (RESP) {
+#pragma unroll
+        for (int b = 0; b < FM; ++b) rv[b] = __builtin_bit_cast(uint4, rres[ap][b]);   // requested in phase 1 of the tile's last K tile (res_prefetch), landed by its phase-4 wait
+      } else if constexpr (RES) {
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
           int m = m0 + 16 * b;
@@ -563,12 +593,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
     }
   };
   int c_r = 0;
-  auto ktile = [&](auto buf_tag, auto first_tag) __attribute__((always_inline)) {
+  auto ktile = [&](auto buf_tag, auto first_tag, bool last) __attribute__((always_inline)) {
     constexpr int BI = decltype(buf_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;
     const char* buf = smem + BI * BUF;
     constexpr unsigned mine = BI * BUF, other = (1 - BI) * BUF;
     // phase 1: (X0, W0)
+    if constexpr (RESP && BI == 1) {
+      if (last) res_prefetch(c_r);
+    }
     read_w(buf + W0_OFF, wf0);
     read_x(buf + x0_row, FM0);
     stage_x1(ca, other);
@@ -593,6 +626,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
     // phase 4: (X1, W0); the K tile after this one must have landed before the partner group's and our next phase 1
     stage_w(cb, mine, 1);
     wait_tile();
+    if constexpr (RESP && BI == 1) {
+      if (last) res_landed();
+    }
     phase_sync();
     // the cursors move inside the MFMA section: the group's multiply sections are the short ones (the partner group's read / stage section
     // sets the interval), so the scalar bookkeeping -- and a tile change's divisions -- cost nothing here and ~6 % at the top of phase 1
@@ -604,11 +640,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
   for (c_r = 0; c_r < n_my; ++c_r) {
-    ktile(B0{}, std::true_type{});
-    ktile(B1{}, std::false_type{});
+    ktile(B0{}, std::true_type{}, false);
+    ktile(B1{}, std::false_type{}, nk == 2);
     for (int kt = 2; kt < nk; kt += 2) {
-      ktile(B0{}, std::false_type{});
-      ktile(B1{}, std::false_type{});
+      ktile(B0{}, std::false_type{}, false);
+      ktile(B1{}, std::false_type{}, kt + 2 == nk);
     }
     if (grp == 1) run_epilogue(c_r);
   }
