@@ -226,8 +226,15 @@ def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base", de
            "n_dyn": np.int64(2), "stride": np.int64(stride), "n_steps": np.int64(n_steps)}
     ys, y64s, sums, rel, dense = [], [], [], [], []
     t0 = time.time()
+    # a 40-step 0.25-degree trajectory is ~35 min of CPU: checkpointed after every step, so an interrupted run resumes where it stopped
+    ckpt = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"wx_rollout_golden_{name}_{family}_{n_steps}_{stride}.pt")
+    first = 1
+    if os.path.isfile(ckpt):
+        st = torch.load(ckpt)
+        first, x, x64, x16, ys, y64s, sums, rel, dense, ac = st["step"] + 1, st["x"], st["x64"], st["x16"], st["ys"], st["y64s"], st["sums"], st["rel"], st["dense"], st["ac"]
+        print(f"[golden] {name} ({family}) rollout: resuming at step {first} from {ckpt}", flush=True)
     with torch.no_grad():
-        for step in range(1, n_steps + 1):
+        for step in range(first, n_steps + 1):
             frc = torch.from_numpy(synth_forcing(cfg, 2, step))
             y = fixer({"y_pred": m(x), "x": x})["y_pred"]
             x = update_x(x, frc, y.detach(), groups)
@@ -250,6 +257,8 @@ def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base", de
             sums.append(np.stack([s1, s2]))
             d = (y.double() - y64)[0, :, 0]
             rel.append(float(d.norm() / y64[0, :, 0].norm()))
+            torch.save({"step": step, "x": x, "x64": x64, "x16": x16, "ys": ys, "y64s": y64s, "sums": sums, "rel": rel, "dense": dense, "ac": ac}, ckpt + ".tmp")
+            os.replace(ckpt + ".tmp", ckpt)
             print(f"[golden] {name} ({family}) rollout step {step}/{n_steps}: mean|y|={y.abs().mean():.4f}  reference-fp32 vs fp64 oracle "
                   f"rel-L2 {rel[-1]:.3e}" + (f"  reference under bf16 autocast {ac[-1]:.3e}" if ac else "") + f"  ({time.time() - t0:.0f}s)", flush=True)
     out["y"] = np.stack(ys)            # [n_steps, C_out, H/stride, W/stride]  reference, fp32
@@ -262,6 +271,8 @@ def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base", de
     if ac:
         out["bf16_autocast_l2"] = np.array(ac)
     np.savez_compressed(os.path.join(GOLD, f"rollout_{name}.npz" if family == "base" else f"rollout_{name}_{family}.npz"), **out)
+    if os.path.isfile(ckpt):
+        os.remove(ckpt)
 
 
 def swin_golden():
