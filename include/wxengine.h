@@ -392,6 +392,8 @@ typedef struct wx_kernel_stat {
  * parity test needs to prove it exercised the path it names; the reference has no counterpart: its "schedule" is ATen's).  Keys:
  *   "two_stream_stages"  stages of the last forward whose sub-block chains ran as two half-maps on two streams (round 5)
  *   "launches"           kernel launches of the last forward
+ *   "gemm8p_launches"    ... of which ran on the eight-phase kernel (wx_gemm8p.h: the decoder's deep-K convolutions, round 6)
+ *   "attn_blk"           attention sub-blocks of the last forward whose q|k|v and attention output travelled k-blocked (round 6)
  *   "precision"          the wx_config precision the engine was created with
  *   "split_gemms"        GEMM launches of the last forward that ran split-bf16 arithmetic (WX_PREC_FP32_SPLIT)
  *   "ff_split_fused"     ... of whose FeedForward sub-blocks ran as ONE launch (wx_ff_split.h; each counts two split GEMMs), and of those

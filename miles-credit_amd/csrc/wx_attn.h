@@ -41,6 +41,9 @@ struct AttnParams {
   float scale;                    // bf16 engine: scale * log2(e), and the bias table is pre-multiplied by log2(e)
   unsigned long long* trace;      // tools/attn_probe only (WX_ATTN_TRACE builds): [tasks][8] phase ticks
   int mma3 = 0;                   // T = float, != 0 (round 5, WX_PREC_FP32_SPLIT): the M3 instantiations -- Q.K^T and P.V as split-bf16 arithmetic
+  int blk = 0;                    // != 0 (bf16, dim_head 32): q|k|v and the output are k-blocked [C / 32][H * W][32] -- the persistent GEMM's
+                                  // o_blk / a_blk layouts (wx_gemm_stream.h): a head's 32 channels of consecutive pixels are contiguous, so a
+                                  // window row is one run of full cache lines instead of 64-byte halves of lines 2 * ld_qkv bytes apart
   int pack;                       // windows per 16-token tile (1, or 16 / wsz^2 for the 2x2 windows of the long
                                   // attention at stage 2: four windows share one MFMA tile, the bias table is
                                   // block-diagonal with -1e30 between windows)
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
     return true;
   };
   // byte offset of a pixel's q|k|v row: 24-bit multiplies (pixels < 2^24, row bytes < 2^24, tensor < 4 GB: checked at launch)
-  const unsigned row_bytes = (unsigned)p.ld_qkv * (unsigned)sizeof(T);
+  const unsigned row_bytes = p.blk ? 64u : (unsigned)p.ld_qkv * (unsigned)sizeof(T);
   auto row_off = [&](int pixel) -> unsigned { return __umul24((unsigned)pixel, row_bytes); };
 
 #ifdef WX_ATTN_TRACE
@@ -254,8 +257,11 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
 #define AT_ACC(a, x, y)
 #endif
   AT_TICK(at0);
-  const char* __restrict__ qkv_b = reinterpret_cast<const char*>(p.qkv) + (size_t)head * D * sizeof(T);   // this head's q columns
-  const size_t k_col = (size_t)p.C * sizeof(T), v_col = 2 * k_col;
+  const size_t map_blk = (size_t)p.H * p.W * 64;   // bytes of one 32-channel block of the k-blocked layouts
+  const char* __restrict__ qkv_b = reinterpret_cast<const char*>(p.qkv) + (p.blk ? (size_t)head * map_blk : (size_t)head * D * sizeof(T));   // this head's q columns
+  const size_t k_col = p.blk ? (size_t)(p.C / 32) * map_blk : (size_t)p.C * sizeof(T), v_col = 2 * k_col;
+  const unsigned o_ld = p.blk ? 32u : (unsigned)p.ld_out;                                   // output: elements between pixels ...
+  const size_t o_head = p.blk ? (size_t)head * (map_blk / sizeof(T)) : (size_t)head * D;     // ... and this head's first element
   T* vt = reinterpret_cast<T*>(smem + (SPLIT ? 0 : wave) * VT_BYTES);
   float* s_tb = reinterpret_cast<float*>(smem + (SPLIT ? 1 : 4) * VT_BYTES);
   constexpr int TB2 = B2W > 0 ? ((2 * B2W - 1) * (2 * B2W - 1) + 7) / 8 * 8 : 0;   // B2W: float4 entries of the block table
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
     };
     auto store_o = [&](QS& q) __attribute__((always_inline)) {
       const float inv = __builtin_amdgcn_rcpf(q.osum[0]);
-      T* orow = out + (size_t)__umul24((unsigned)q.qpix, (unsigned)p.ld_out) + head * D + pair_rows16_channel(g);
+      T* orow = out + (size_t)__umul24((unsigned)q.qpix, o_ld) + o_head + pair_rows16_channel(g);
       const uint2 lo = make_uint2(pack_bf16x2(q.o0[0] * inv, q.o0[1] * inv), pack_bf16x2(q.o0[2] * inv, q.o0[3] * inv));
       const uint2 hi = make_uint2(pack_bf16x2(q.o1[0] * inv, q.o1[1] * inv), pack_bf16x2(q.o1[2] * inv, q.o1[3] * inv));
       const uint4 w = pair_rows16(lo, hi);
@@ -793,7 +799,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
     if constexpr (sizeof(T) == 2 && NDF % 2 == 0) {
       // the two 8-byte pieces a lane holds per fragment pair become one 16-byte store (pair_rows16: every lane takes part, the
       // predicate only guards the store; lanes l and l ^ 16 belong to the same query, so they agree on it)
-      T* orow = out + (size_t)__umul24((unsigned)qpix, (unsigned)p.ld_out) + head * D + pair_rows16_channel(g);
+      T* orow = out + (size_t)__umul24((unsigned)qpix, o_ld) + o_head + pair_rows16_channel(g);
 #pragma unroll
       for (int df = 0; df < NDF; df += 2) {
         const uint2 lo = make_uint2(pack_bf16x2(oacc[df][0] * inv, oacc[df][1] * inv), pack_bf16x2(oacc[df][2] * inv, oacc[df][3] * inv));
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(256, attn_min_waves(NKF, DH, int(sizeof(T)), SW)) v
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = oacc[df][r] * inv;
-        store4<T>(out + (size_t)__umul24((unsigned)qpix, (unsigned)p.ld_out) + head * D + df * 16 + g * 4, v);
+        store4<T>(out + (size_t)__umul24((unsigned)qpix, o_ld) + o_head + df * 16 + g * 4, v);
       }
     }
     AT_TICK(q4);
@@ -827,6 +833,7 @@ inline void launch_window_attn_n(const AttnParams& p, hipStream_t stream) {
       (int64_t)p.H * p.W * p.ld_qkv * (int64_t)sizeof(T) >= (int64_t(1) << 32))
     throw std::runtime_error("window attention: map too large for 24-bit pixel / 32-bit byte addressing");
   if (!SW && (p.kind == 3 || p.logit_scale || p.q_scale != 0.f)) throw std::runtime_error("window attention: Swin-mode parameters on the WXFormer kernel");
+  if (p.blk && (sizeof(T) != 2 || DH != 32 || p.C % 32 != 0)) throw std::runtime_error("window attention: the k-blocked layouts are bf16 / dim_head 32 only");
   constexpr int NKB = (NKF + 1) / 2;
 #ifdef WX_ATTN_NOTR
   constexpr int VT_COLS = (sizeof(T) == 2) ? NKB * 32 + 8 : (NKF * 16 + 4);

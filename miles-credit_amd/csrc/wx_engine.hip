@@ -1064,6 +1064,11 @@ class Engine : public EngineBase {
   }
   float2* gnpart = nullptr;     // [m_tiles][C] GroupNorm partials written by the 3x3 conv epilogue
   int64_t gnpart_elems = 0;
+  bool blk_attn = false;        // set around an attention sub-block's to_qkv / window attention / to_out (round 6): q|k|v and the attention output
+                                // are k-blocked [C/32][M][32] = [head][token][32] at dim_head 32 -- to_qkv stores, the attention's loads and
+                                // stores and to_out's operand DMA all move full cache lines (row-major: 64-byte halves of lines 3C x 2 bytes apart)
+  bool attn_blk_on = !(getenv("WX_NO_ATTN_BLK") && getenv("WX_NO_ATTN_BLK")[0] == '1');
+  int64_t n_attn_blk = 0;       // attention sub-blocks of the last forward that ran on the k-blocked layouts
   bool blk_hidden = false;      // set around a FeedForward's two gemm() calls: the hidden tensor is k-blocked [4C/32][M][32] (layer 1 writes
                                 // it, layer 2 reads it: full cache lines per LDS-DMA piece; ff2 47.9 -> 45.0 us, ff1 56.6 -> 53.8 us)
   // Row window (round 5): attention() / feedforward() / gemm() work on map rows [rw0, rw0 + rwn) of the current stage instead of the whole
@@ -1281,6 +1286,7 @@ class Engine : public EngineBase {
     if (key == "precision") { *v = sizeof(T) == 2 ? WX_PREC_BF16 : (split_mma ? WX_PREC_FP32_SPLIT : WX_PREC_FP32); return true; }
     if (key == "split_gemms") { *v = n_split_gemms; return true; }
     if (key == "gemm8p_launches") { *v = n_gemm8p; return true; }
+    if (key == "attn_blk") { *v = n_attn_blk; return true; }
     if (key == "ff_split_fused") { *v = n_ff_split_fused; return true; }
     if (key == "ff_split_pre") { *v = n_ff_split_pre; return true; }
     if (key == "ff_split_post") { *v = n_ff_split_post; return true; }
@@ -1511,7 +1517,7 @@ class Engine : public EngineBase {
         const int64_t rows = (int64_t)out_h * out_w;
         const bool ln_v = rs && !res && !want_stats && w.colsum >= 0, res_v = !rs && res && want_stats && fuse_ln && act == 0;
         if (use_wreg && use_dma && w.wt_kb >= 0 && one && w.cin == 512 && w.n % WREG_BN == 0 && w.bias >= 0 && out_mode == 0 && !want_gn && !dbg_flags &&
-            !blk_hidden && rwn < 0 && rows >= wreg_min_rows && rows < wreg_max_rows && (ln_v || (res_v && w.n / 32 <= WREG_MAXT)) &&
+            !blk_hidden && !blk_attn && rwn < 0 && rows >= wreg_min_rows && rows < wreg_max_rows && (ln_v || (res_v && w.n / 32 <= WREG_MAXT)) &&
             wreg_gemm_ok(rows, w.n, w.cin, p.stat_tiles, ln_v)) {
           StreamGemmParams q;
           std::memset(&q, 0, sizeof(q));
@@ -1539,7 +1545,7 @@ class Engine : public EngineBase {
         q.res = reinterpret_cast<const bf16_t*>(res); q.res_ld = res_ld;
         q.stat_out = stat_dst(st_tok0 + q.M, w.n / 64) + st_tok0 * (w.n / 64); q.stat_slots = w.n / 64;
         q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
-        q.a_blk = blk_hidden ? 1 : 0; q.a_rows = q.M;
+        q.a_blk = (blk_hidden || blk_attn) ? 1 : 0; q.a_rows = q.M;
         // at most one 160 x 128 tile per CU and a deep K (stage 3 of the 0.25-degree model): the loader / consumer form of the kernel
         const bool lc = use_stream_lc && stream_gemm_lc_pays(sel_rows, q.N, q.K, 5);
         cur_family = lc ? "stream_lc" : "stream";
@@ -1558,7 +1564,7 @@ class Engine : public EngineBase {
         q.M = out_h * out_w; q.N = w.n; q.K = w.cin;
         q.bias = p.bias; q.colsum = p.colsum; q.rowstat = rs; q.stat_tiles = p.stat_tiles; q.stat_inv_c = p.stat_inv_c;
         q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
-        q.o_blk = (blk_hidden && act == 1) ? 1 : 0; q.o_rows = q.M;
+        q.o_blk = ((blk_hidden && act == 1) || (blk_attn && act == 0)) ? 1 : 0; q.o_rows = q.M;
         // tile per epilogue (tools/gemm_stream_probe, MI355X): with GELU the 160-row tile on a 2-stage ring (256 VGPRs, 2 x 54 KB of
         // LDS) wins -- 54.6 / 46.8 us on the stage-2 / stage-3 FeedForward shapes against 56.4 / 58.5 -- without it the 128-row tile
         // on 3 stages does (39.8 vs 46.4 us on to_qkv)
@@ -1571,6 +1577,7 @@ class Engine : public EngineBase {
       }
     }
     if (blk_hidden) throw StateError("k-blocked hidden tensor requested but the GEMM fell back to the row-major kernel");
+    if (blk_attn) throw StateError("k-blocked q|k|v / attention output requested but the GEMM fell back to the row-major kernel");
     if (rwn >= 0) throw StateError("row-window launch fell to the generic kernel (the two-stream schedule runs on the persistent GEMMs only)");
     // split-K for plain deep-K launches that cannot fill the chip (stage-3 CrossEmbed k = 4: 160 tiles walking K = 8192; every
     // CrossEmbed GEMM of the 1-degree grid): 128 x 128 tiles x S K-ranges, fp32 partial sums, fixed-order finish kernel
@@ -1687,9 +1694,16 @@ class Engine : public EngineBase {
       }
     }
     const float2* rs = qkv_ready ? nullptr : stream_stats(x, ld, c, m);
+    struct Unblk { bool* f; ~Unblk() { *f = false; } } unblk{&blk_attn};   // set below for to_qkv / attention / to_out of this sub-block only
     if (a.wsz == 1) {
       gemm("gemm_qkv", a.vonly, x, h, w, ld, 1, 0, 0, h, w, attn_o, c, rs, 0, nullptr, 0);
     } else {
+      // C >= 512 on large maps (stages 2 - 3 of the 0.25-degree model): the three launches exchange q|k|v and the attention output
+      // k-blocked (see blk_attn); outputs bitwise the row-major chain's
+      blk_attn = sizeof(T) == 2 && attn_blk_on && use_stream && use_dma && fuse_ln && !dbg_flags && !dbg_on && !band_on && rwn < 0 && cfg.dim_head == 32 &&
+                 !qkv_ready && !defer_out && attn_kind_override < 0 && a.qkv.wt_kb >= 0 && a.out.wt_kb >= 0 && (c == 512 || c == 1024) && rs &&
+                 (rule_rows > 0 ? rule_rows : (int64_t)m) >= stream_min_rows && a.out.bias >= 0 && a.qkv.colsum >= 0 && a.qkv.n % 256 == 0;
+      if (blk_attn) ++n_attn_blk;
       if (!qkv_ready) gemm("gemm_qkv", a.qkv, x, h, w, ld, 1, 0, 0, h, w, scratch, 3 * c, rs, 0, nullptr, 0);
       AttnParams p;
       p.trace = nullptr;
@@ -1698,6 +1712,7 @@ class Engine : public EngineBase {
       p.scale = (float)(1.0 / std::sqrt((double)cfg.dim_head));   // fp32 engine only: the bf16 engine's q already carries scale * log2(e)
       p.pack = attn_pack(a.wsz);
       p.mma3 = split_mma ? 1 : 0;
+      p.blk = blk_attn ? 1 : 0;
       const double n = (double)a.wsz * a.wsz;
       timed("window_attn", 4.0 * m * n * c, 4.0 * m * c * sizeof(T), [&] {
         if (cfg.dim_head == 32) launch_window_attn<T>(p, cur_stream, attn_split);
@@ -2205,6 +2220,7 @@ class Engine : public EngineBase {
   void core(const float* x_item) {
     n_two_stream_stages = 0;
     n_gemm8p = 0;
+    n_attn_blk = 0;
     n_split_gemms = 0;
     n_ff_split_fused = 0;
     n_ff_split_pre = 0;

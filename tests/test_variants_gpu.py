@@ -205,6 +205,25 @@ def test_eight_phase_conv_forced_on_small_maps(name):
     print(f"[gemm8p conv parity] {name}: {n8} launches; y vs 128x128 path {l2:.2e}, vs oracle {l2o:.2e}")
 
 
+@pytest.mark.parametrize("name,env", [("T5", {"WX_STREAM_MIN_ROWS": "0"}), ("C3", {})])
+def test_attention_sub_block_on_k_blocked_layouts_bit_identical(name, env):
+    """Round 6: at C >= 512 on the persistent GEMMs, to_qkv writes q|k|v k-blocked ([C/32][tokens][32] = [head][token][32] at dim_head 32),
+    the window attention reads it and writes its output the same way, to_out reads that as its k-blocked operand -- only addresses change,
+    so the forward must be BITWISE the row-major chain's (`WX_NO_ATTN_BLK=1`).  T5 forces the persistent GEMMs onto 200- and 50-token maps
+    (short 5 x 5 and long 2 x 2 / 1 x 1 windows, ragged GEMM tiles); C3 is the headline model (stage 2: 10 x 10 short and packed 2 x 2 long
+    windows on 20 000 tokens; stage 3: 5 000)."""
+    cfg = named_config(name)
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    blk = _engine(name, "bf16", dict(env))
+    row = _engine(name, "bf16", dict(env, WX_NO_ATTN_BLK="1"))
+    y_b, y_r = _forward(blk, x), _forward(row, x)
+    nb, nr = blk.query("attn_blk"), row.query("attn_blk")
+    assert nb >= 2 and nr == 0, (nb, nr)
+    assert torch.equal(y_b, y_r), f"{name}: k-blocked attention chain differs from the row-major one (max {float((y_b - y_r).abs().max()):.3e})"
+    assert torch.equal(y_b, _forward(blk, x))
+    print(f"[attention k-blocked] {name}: {nb} sub-blocks on the blocked layouts, forward bit-identical to the row-major chain")
+
+
 @pytest.mark.parametrize("name", ["T5", "C1"])
 def test_weight_stationary_gemm_forced_on_small_maps(name):
     """`gemm_wreg_kernel` (wx_gemm_wreg.h: weights in registers, activations streamed in 32-row tiles) takes the K = 512 layers on maps
