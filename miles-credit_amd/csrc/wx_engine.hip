@@ -1037,6 +1037,8 @@ class Engine : public EngineBase {
   int stream_min_rows = 4096;
   bool use_stream_lc = !(getenv("WX_NO_STREAM_LC") && getenv("WX_NO_STREAM_LC")[0] == '1');   // loader / consumer form of the persistent GEMM (one-tile-per-CU residual layers)
   bool use_gemm8p = !(getenv("WX_NO_GEMM8P") && getenv("WX_NO_GEMM8P")[0] == '1');   // eight-phase 160 x 256 kernel (wx_gemm8p.h) for the deep-K stride-1 k x k convs of the decoder
+  bool gemm8p_ff2 = getenv("WX_GEMM8P_FF2") && getenv("WX_GEMM8P_FF2")[0] == '1';   // OFF: a tie inside the step (7.809 vs 7.802 ms/step same box) although
+                                                                                     // the stand-alone launch is 5 % faster (43.7 vs 45.9 us); bit-identical
   int64_t gemm8p_min_rows = getenv("WX_GEMM8P_MIN_ROWS") ? atoll(getenv("WX_GEMM8P_MIN_ROWS")) : 16384;
   int64_t n_gemm8p = 0;              // launches of the last forward that took it
   bool use_wreg = !(getenv("WX_NO_WREG") && getenv("WX_NO_WREG")[0] == '1');   // weight-stationary GEMM (wx_gemm_wreg.h) for K = 512 layers on mid-sized maps
@@ -1546,6 +1548,22 @@ class Engine : public EngineBase {
         q.stat_out = stat_dst(st_tok0 + q.M, w.n / 64) + st_tok0 * (w.n / 64); q.stat_slots = w.n / 64;
         q.out = reinterpret_cast<bf16_t*>(out); q.out_ld = out_ld; q.sink = stream_sink;
         q.a_blk = (blk_hidden || blk_attn) ? 1 : 0; q.a_rows = q.M;
+        // experiment switch WX_GEMM8P_FF2=1: FeedForward layer 2 of stage 2 (20 000 x 512 x 2048 from the k-blocked hidden tensor) as one 160 x 256 tile
+        // of 32 K tiles per CU on the eight-phase kernel -- 43.7 against 45.9 us stand-alone (tools/gemm8p_probe), 46.8 against 47.3 inside the step
+        // (operands from HBM instead of a warm L2): a tie, so off.  Bitwise the same output and row partials (64-channel slots either way).
+        if (use_gemm8p && gemm8p_ff2 && blk_hidden && q.N == 512 && q.K >= 2048 && q.K % 128 == 0 && sel_rows >= gemm8p_min_rows && rwn < 0 && !band_on &&
+            gemm8p_fits(q.M, q.N, 2, 5, true)) {
+          Gemm8pParams g;
+          std::memset(&g, 0, sizeof(g));
+          g.a = q.a; g.a_blk = 1; g.a_rows = q.M; g.lda = q.K; g.w = reinterpret_cast<const bf16_t*>(wt_dev + w.wt); g.M = q.M; g.N = q.N; g.K = q.K;
+          g.bias = q.bias; g.res = q.res; g.res_ld = q.res_ld; g.stat_out = q.stat_out; g.stat_slots = q.stat_slots;
+          g.out = q.out; g.out_ld = q.out_ld; g.sink = stream_sink; g.xcd_part = 1;
+          cur_family = "gemm8p";
+          timed(cls, flops, bytes, [&] { launch_gemm8p<5>(g, 3, cur_stream); });
+          ++n_gemm8p;
+          last_stat_slots = q.stat_slots;
+          return true;
+        }
         // at most one 160 x 128 tile per CU and a deep K (stage 3 of the 0.25-degree model): the loader / consumer form of the kernel
         const bool lc = use_stream_lc && stream_gemm_lc_pays(sel_rows, q.N, q.K, 5);
         cur_family = lc ? "stream_lc" : "stream";

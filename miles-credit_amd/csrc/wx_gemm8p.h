@@ -35,6 +35,8 @@ namespace wx {
 struct Gemm8pParams {
   const bf16_t* a;       // [M][lda]  (conv form: the input map, pixel-major, lda elements between pixels)
   int64_t lda;
+  int a_blk;             // 1x1 form, 1: `a` is k-blocked [K/32][a_rows][32] (wx_gemm_stream.h's o_blk output: the FeedForward hidden tensor)
+  int64_t a_rows;
   const bf16_t* w;       // [N][K]
   int M, N, K;           // N % (64 WC) == 0, K % 128 == 0 (conv form: K = kh * kw * cin, cin % 64 == 0)
   const float* bias;     // [N] or nullptr
@@ -133,7 +135,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
   // ---- DMA coordinates ---------------------------------------------------------------------------------
   // X unit h, instruction q = i * 8 + wave: LDS rows R = q * 8 + (lane >> 3); row R = wave row R / (16 FMh), pixel fragment row R % (16 FMh)
   const int l8 = lane >> 3;
-  const unsigned x_piece = (unsigned)(((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) << 4);
+  // source piece (16 bytes of the row's 128) behind this lane's LDS slot; k-blocked `a`: pieces 0-3 / 4-7 lie in two 32-channel blocks
+  const unsigned x_q = (unsigned)((lane & 7) ^ (4 * (wave & 1) + (lane >> 4)));
+  const unsigned x_piece = (!CONV && p.a_blk) ? (x_q >> 2) * (unsigned)(p.a_rows * 64) + (x_q & 3) * 16 : x_q << 4;
   int x0_pix[X0_I], x1_pix[X1_I];
 #pragma unroll
   for (int i = 0; i < X0_I; ++i) {
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
   // W unit h, instruction q = i * 8 + wave: LDS rows R = q * 8 + (lane >> 3) <-> channel (R >> 5) * 64 + h * 32 + (R & 31)
   const unsigned w_voff = (unsigned)(((wave >> 2) * 64 + (wave & 3) * 8 + l8) * p.K * 2) +
                           (unsigned)(((lane & 7) ^ (((lane >> 4) & 1) | ((wave & 3) << 1))) << 4);
-  const unsigned ldab = (unsigned)p.lda * 2u;
+  const unsigned ldab = (!CONV && p.a_blk) ? 64u : (unsigned)p.lda * 2u;
   const unsigned dst0 = lds_addr_sgpr(smem) + (unsigned)wave * 1024u;
 
   // conv form: per X instruction the byte offset of this lane's (clamped) output pixel + its 16-byte piece, and a bit per tap that is
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
 #pragma unroll
       for (int i = 0; i < X1_I; ++i) conv_lane(m_blk + (x1_pix[i] < c.last ? x1_pix[i] : c.last), c.x1_off[i], c.x1_out[i]);
     } else {
-      c.a = reinterpret_cast<const char*>(p.a) + ((int64_t)m_blk * p.lda + (int64_t)c.kt * 64) * 2;
+      c.a = reinterpret_cast<const char*>(p.a) + (p.a_blk ? ((int64_t)c.kt * 2 * p.a_rows + m_blk) * 64 : ((int64_t)m_blk * p.lda + (int64_t)c.kt * 64) * 2);
     }
   };
   auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {   // K tiles beyond the end restage the last one (never read; keeps the vmcnt arithmetic uniform)
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Gemm8pParams p) {
       c.w = c.w_tile + (c.tap * p.cin + c.c0) * 2;
     } else {
       c.w += 128;
-      c.a += 128;
+      c.a += p.a_blk ? p.a_rows * 128 : 128;
     }
   };
   auto conv_voff = [&](const Cursor& c, unsigned off, unsigned out_mask) __attribute__((always_inline)) -> unsigned {
@@ -698,6 +702,7 @@ inline void launch_gemm8p_v(Gemm8pParams p, hipStream_t stream) {
   const unsigned grid = gemm8p_grid(p);
   if (gemm8p_tiles_per_wg(p, grid) > GEMM8P_MAX_TILES) throw std::runtime_error("gemm8p: more tiles per workgroup than LDS parameter slots");
   if (p.K % 128 != 0 || p.N % BN != 0) throw std::runtime_error("gemm8p: N / K outside the kernel's rules");
+  if (p.a_blk && (CONV || p.a_rows < p.M || p.a_rows * 64 >= (int64_t(1) << 31))) throw std::runtime_error("gemm8p: k-blocked operand outside the kernel's rules");
   if (SCAT && (p.cout % 64 != 0 || p.N != 4 * p.cout || p.scat_w < 1 || p.M % p.scat_w != 0)) throw std::runtime_error("gemm8p: ConvTranspose scatter geometry outside the kernel's rules");
   if (CONV && (p.cin % 64 != 0 || p.K != p.kh * p.kw * p.cin || (int64_t)p.in_h * p.in_w != p.M || p.kh * p.kw > 32 ||
                (int64_t)p.M * p.lda * 2 >= (int64_t)0x7fffff00))

@@ -120,6 +120,13 @@ int main(int argc, char** argv) {
         for (int k = 0; k < K; ++k) t[((size_t)(k / 32) * N + n) * 32 + k % 32] = hw[(size_t)n * K + k];
       WX_HIP(hipMemcpy(wblk, t.data(), t.size() * 2, hipMemcpyHostToDevice));
     }
+    uint16_t* xblk = (uint16_t*)dalloc(hx.size() * 2);   // [K/32][M][32]: the k-blocked hidden tensor FeedForward 1 leaves for layer 2
+    {
+      std::vector<uint16_t> tx(hx.size());
+      for (int m = 0; m < M; ++m)
+        for (int k = 0; k < K; ++k) tx[((size_t)(k / 32) * M + m) * 32 + k % 32] = hx[(size_t)m * K + k];
+      WX_HIP(hipMemcpy(xblk, tx.data(), tx.size() * 2, hipMemcpyHostToDevice));
+    }
     uint16_t* y0 = (uint16_t*)dalloc((size_t)M * N * 2);
     uint16_t* y1 = (uint16_t*)dalloc((size_t)M * N * 2);
     uint16_t* rs = (uint16_t*)dalloc((size_t)M * N * 2);
@@ -259,6 +266,23 @@ int main(int argc, char** argv) {
       }
       if (!same) ++bad;
     }
+    if (res) {   // the k-blocked operand (both kernels): bitwise the row-major result
+      Gemm8pParams gb = g;
+      gb.a = xblk; gb.a_blk = 1; gb.a_rows = M;
+      StreamGemmParams qb = q4;
+      qb.a = xblk; qb.a_blk = 1; qb.a_rows = M;
+      auto run_b8 = [&] { launch_gemm8p<5>(gb, 3, st); };
+      auto run_bp = [&] { if (lc) launch_gemm_stream_n128_lc<5, 8>(qb, st); else launch_gemm_stream_n128<5, 3, 2>(qb, st); };
+      WX_HIP(hipMemsetAsync(y1, 0xff, (size_t)M * N * 2, st));
+      run_b8();
+      WX_HIP(hipStreamSynchronize(st));
+      WX_HIP(hipMemcpy(h2.data(), y1, h2.size() * 2, hipMemcpyDeviceToHost));
+      const bool same = std::memcmp(h1.data(), h2.data(), h1.size() * 2) == 0;
+      double tb8 = 1e30, tbp = 1e30;
+      for (int round = 0; round < 3; ++round) { tb8 = std::min(tb8, time_us(st, 20, run_b8)); tbp = std::min(tbp, time_us(st, 20, run_bp)); }
+      printf("    k-blocked operand: 8p 160x256 %7.1f us, production 128-col%s %7.1f us, 8p output %s\n", tb8, lc ? " LC" : "", tbp, same ? "bitwise equal" : "DIFFERS");
+      if (!same) ++bad;
+    }
     const double fl = 2.0 * M * N * K * 1e-6;
     printf("%-20s M=%6d N=%5d K=%5d | production %7.1f us %5.0f TF", s.name, M, N, K, t_prod, fl / t_prod);
     if (res) printf(" (128-col%s %7.1f us %5.0f TF)", lc ? " LC" : "", t_p128, fl / t_p128);
@@ -309,7 +333,7 @@ int main(int argc, char** argv) {
       }
     }
     fflush(stdout);
-    for (void* ptr : {(void*)x, (void*)w, (void*)y0, (void*)y1, (void*)rs, (void*)bias, (void*)colsum, (void*)rowstat, (void*)so0, (void*)so1, (void*)wblk})
+    for (void* ptr : {(void*)x, (void*)w, (void*)y0, (void*)y1, (void*)rs, (void*)bias, (void*)colsum, (void*)rowstat, (void*)so0, (void*)so1, (void*)wblk, (void*)xblk})
       WX_HIP(hipFree(ptr));
   }
 
