@@ -230,7 +230,7 @@ def long_rollout_golden(name, n_steps, stride, with_fp64=True, family="base", de
     ckpt = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"wx_rollout_golden_{name}_{family}_{n_steps}_{stride}.pt")
     first = 1
     if os.path.isfile(ckpt):
-        st = torch.load(ckpt)
+        st = torch.load(ckpt, weights_only=False)
         first, x, x64, x16, ys, y64s, sums, rel, dense, ac = st["step"] + 1, st["x"], st["x64"], st["x16"], st["ys"], st["y64s"], st["sums"], st["rel"], st["dense"], st["ac"]
         print(f"[golden] {name} ({family}) rollout: resuming at step {first} from {ckpt}", flush=True)
     with torch.no_grad():
