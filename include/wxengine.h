@@ -394,6 +394,7 @@ typedef struct wx_kernel_stat {
  *   "launches"           kernel launches of the last forward
  *   "gemm8p_launches"    ... of which ran on the eight-phase kernel (wx_gemm8p.h: the decoder's deep-K convolutions, round 6)
  *   "attn_blk"           attention sub-blocks of the last forward whose q|k|v and attention output travelled k-blocked (round 6)
+ *   "ff_wide"            FeedForward blocks of the last forward / band step that ran as the C = 512 fused block (lat-band ranks: its hidden split)
  *   "precision"          the wx_config precision the engine was created with
  *   "split_gemms"        GEMM launches of the last forward that ran split-bf16 arithmetic (WX_PREC_FP32_SPLIT)
  *   "ff_split_fused"     ... of whose FeedForward sub-blocks ran as ONE launch (wx_ff_split.h; each counts two split GEMMs), and of those

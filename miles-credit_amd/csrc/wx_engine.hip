@@ -61,7 +61,7 @@ struct ConvW {          // one repacked GEMM operand in the weight arena
   int64_t wt_kb = -1;   // bf16 engine, 1x1 layers with n % 256 == 0: second copy, k-blocked [cin/32][n][32] (wx_gemm_stream.h)
 };
 struct AttnL { ConvW qkv, vonly, out; int64_t bias_tab = -1, bias_tb = -1; int wsz = 0, kind = 0; };
-struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1, pack_pp = -1; const AttnL* next = nullptr; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset; pack_pre: the same preceded by the attention's Wout blocks
+struct FFL { ConvW w1, w2; int64_t pack = -1, pack_pre = -1, pack_pp = -1, pack_wide = -1; const AttnL* next = nullptr; };  // pack: fused-block chunk layout (wx_ff.h), T-arena offset; pack_pre: the same preceded by the attention's Wout blocks
 struct BlockL { AttnL sa; FFL sf; AttnL la; FFL lf; };
 struct PatchW { int64_t wt = -1, bias = -1, wt16 = -1; int n = 0; };   // LDS-patch CrossEmbed branch (wx_embed.h); wt16: split-bf16 mode, offset in the 16-bit patch arena
 struct StageL {
@@ -778,6 +778,8 @@ class Engine : public EngineBase {
         if (prev) f.pack_pre = pack_ff(f, c, 4 * c, &prev->out);
       } else if (ff_plain_supported(c, 4 * c)) {
         f.pack = pack_ff(f, c, 4 * c);
+      } else if (ff_wide && ff_wide_supported(c, 4 * c)) {
+        f.pack_wide = pack_ff(f, c, 4 * c);   // its own field: every rule that reads `pack` (two-stream stages, row windows) stays as it was
       }
     }
     return f;
@@ -993,6 +995,13 @@ class Engine : public EngineBase {
   bool embed_merge = !getenv("WX_NO_EMBED_MERGE");
   bool ff_small_px64 = !(getenv("WX_FF_PX64") && getenv("WX_FF_PX64")[0] == '0');   // C = 128 plain block on 64-pixel tiles when the map yields < 128 tiles of 128 (1-degree stage 1: 21.5 -> 15.5 us)
   int ff_split_tiles = getenv("WX_FF_SPLIT_TILES") ? atoi(getenv("WX_FF_SPLIT_TILES")) : 32;   // pixel tiles, at most
+  // C = 512 (wx_ff.h ff_wide_supported), round 6 -- built, measured, OFF (0): the form is LDS-read-bound and loses both ways.
+  // 1: the chunk blocks are packed (+ 4 MB per FeedForward) and lat-band ranks run the FeedForward of their stage-2 band (2 000 - 4 000
+  // tokens) as the hidden-split fused block + the split-K finish kernel instead of ff1 + split-K ff2 + finish (71 vs 52 us per block);
+  // 2: the unsharded map runs the plain fused block as well (213 vs 104 us per block)
+  int ff_wide = getenv("WX_FF_WIDE") ? atoi(getenv("WX_FF_WIDE")) : 0;
+  int ff_wide_wgs = getenv("WX_FF_WIDE_WGS") ? atoi(getenv("WX_FF_WIDE_WGS")) : 256;   // hidden ranges S: the fewest that yield this many workgroups (<= 8)
+  int n_ff_wide = 0;
   int ff_split_max = getenv("WX_FF_SPLIT") ? atoi(getenv("WX_FF_SPLIT")) : 8;   // hidden ranges of the split fused FeedForward (0 / 1: off)
   bool attn_pack2 = !getenv("WX_NO_ATTN_PACK2");
   int ff_split_tw = getenv("WX_FF_SPLIT_TW") ? atoi(getenv("WX_FF_SPLIT_TW")) : 0;   // 0: by map size
@@ -1023,6 +1032,7 @@ class Engine : public EngineBase {
     size_t b = (size_t)512 * tile;                                                               // plain rule: S * tiles <= 512
     b = std::max(b, (size_t)std::max(band ? std::max(skinny_tiles, skinny_tiles_band) : skinny_tiles, 1) * (size_t)std::max(skinny_max, 1) * tile); // skinny rule: tiles <= skinny_tiles, S <= skinny_max
     b = std::max(b, (size_t)std::max(ff_split_tiles, 1) * 128 * 256 * (size_t)std::max(ff_split_max, 1) * sizeof(float));   // <= ff_split_tiles pixel tiles of <= 128 px, C <= 256
+    if (band && ff_wide) b = std::max(b, (size_t)(std::max(ff_wide_wgs, 256) + 128) * 64 * 512 * sizeof(float));   // C = 512 hidden split: S * tiles < ff_wide_wgs + tiles, tiles <= 128 of 64 px
     return b;
   }
   float* splitk_scratch(size_t need) {
@@ -1289,6 +1299,7 @@ class Engine : public EngineBase {
     if (key == "split_gemms") { *v = n_split_gemms; return true; }
     if (key == "gemm8p_launches") { *v = n_gemm8p; return true; }
     if (key == "attn_blk") { *v = n_attn_blk; return true; }
+    if (key == "ff_wide") { *v = n_ff_wide; return true; }
     if (key == "ff_split_fused") { *v = n_ff_split_fused; return true; }
     if (key == "ff_split_pre") { *v = n_ff_split_pre; return true; }
     if (key == "ff_split_post") { *v = n_ff_split_post; return true; }
@@ -1841,6 +1852,54 @@ class Engine : public EngineBase {
         return;
       }
     }
+    if constexpr (sizeof(T) == 2) {
+      // C = 512 (wx_ff.h ff_wide_supported).  Lat-band ranks: a band of 2 000 - 4 000 stage-2 tokens is 32 - 63 pixel tiles -- the hidden
+      // dimension is cut into S ranges so that ~ff_wide_wgs workgroups each stream 1 / S of W1 | W2, and the split-K finish kernel adds the
+      // ranges (+ b2 + residual, rounding, LayerNorm partials): two launches and no hidden tensor instead of ff1 + split-K ff2 + finish.
+      // WX_FF_WIDE=2 also runs the plain one-launch block on the unsharded map (an experiment; it loses there).
+      const int tiles = (int)cdiv(m, 64);
+      const bool wide_ok = f.pack_wide >= 0 && !pre && fuse_ff && fuse_ln && !dbg_flags && rwn < 0 && f.w2.bias >= 0 && f.w1.colsum >= 0;
+      if (wide_ok && band_on && tiles <= 128) {
+        const int nch = 4 * c / 32;
+        const int S = std::min(8, std::max(2, (int)cdiv(ff_wide_wgs, tiles)));
+        const int ch_per = cdiv(nch, S), S_eff = cdiv(nch, ch_per);
+        const size_t need = (size_t)S_eff * m * c * sizeof(float);
+        splitk_scratch(need);
+        FFParams fp{};
+        fp.x = reinterpret_cast<const bf16_t*>(x); fp.ld = ld; fp.out = reinterpret_cast<bf16_t*>(x); fp.out_ld = ld;
+        fp.M = m; fp.hidden = 4 * c; fp.wpack = reinterpret_cast<const char*>(wt_dev + f.pack_wide);
+        fp.cs1 = f_dev + f.w1.colsum; fp.b1 = f_dev + f.w1.bias; fp.b2 = f_dev + f.w2.bias;
+        fp.partial = splitk_buf; fp.ch_per = ch_per;
+        ConvGemmParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.out_h = h; q.out_w = w; q.n = c; q.partial = splitk_buf; q.k_splits = S_eff;
+        q.bias = f_dev + f.w2.bias; q.res = x; q.res_ld = ld; q.out = x; q.out_ld = ld; q.stat_out = statpart;
+        ++n_ff_wide;
+        timed("ff_fused_split", 16.0 * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] {
+          launch_ff_fused_split(c, fp, zero_page, cur_stream);
+          const int64_t waves = (int64_t)m * conv_gemm_finish_slots(c);
+          hipLaunchKernelGGL(conv_gemm_finish_kernel<T>, dim3((unsigned)cdiv(waves, (int64_t)4)), dim3(256), 0, cur_stream, q);
+          WX_HIP(hipGetLastError());
+        });
+        stat_tiles_ready = conv_gemm_finish_slots(c);
+        last_stat_slots = stat_tiles_ready;
+        capture(dbg_name, x, h, w, c, ld, w);
+        return;
+      }
+      if (wide_ok && !band_on && ff_wide >= 2) {
+        FFParams fp{};
+        fp.x = reinterpret_cast<const bf16_t*>(x); fp.ld = ld; fp.out = reinterpret_cast<bf16_t*>(x); fp.out_ld = ld;
+        fp.M = m; fp.hidden = 4 * c; fp.wpack = reinterpret_cast<const char*>(wt_dev + f.pack_wide);
+        fp.cs1 = f_dev + f.w1.colsum; fp.b1 = f_dev + f.w1.bias; fp.b2 = f_dev + f.w2.bias;
+        fp.stat_out = statpart;
+        ++n_ff_wide;
+        timed("ff_fused", 16.0 * m * c * c, 2.0 * m * c * sizeof(T) + 16.0 * c * c, [&] { launch_ff_fused(c, fp, zero_page, cur_stream, 0); });
+        stat_tiles_ready = 1;
+        last_stat_slots = 1;
+        capture(dbg_name, x, h, w, c, ld, w);
+        return;
+      }
+    }
     if (pre && !(sizeof(T) == 4 && ff_split_fused_ok(f, c))) throw StateError("feedforward: out-projection deferred to a layer that cannot take it");
     const float2* rs = pre ? nullptr : stream_stats(x, ld, c, m);   // the PRE form takes the statistics of x1 itself
     if constexpr (sizeof(T) == 4) {
@@ -2243,6 +2302,7 @@ class Engine : public EngineBase {
     n_ff_split_fused = 0;
     n_ff_split_pre = 0;
     n_ff_split_post = 0;
+    n_ff_wide = 0;
     n_launches = 0;
     // a1: pack + earth halo
     pack_input(x_item, xin, xin_planar, Hp + 2 * halo, 0, Hp, halo, 0, cfg.image_height);
@@ -2952,6 +3012,7 @@ class Engine : public EngineBase {
     cur_stream = s;
     bx_own = x_own; bfrc_own = frc_own; by = y; by_phys = y_phys; bx_next = x_next;
     b_pc = 0;
+    n_ff_wide = 0;
     return band_run();
   }
   // ---- RCCL transport inside the engine: no host code between the segments of a step besides the launches themselves

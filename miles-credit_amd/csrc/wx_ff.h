@@ -566,9 +566,16 @@ inline void launch_ff_fused_split(int c, const FFParams& p, const void* zero_pag
   if (!p.partial || p.ch_per < 1 || p.o || p.qkv) throw std::runtime_error("ff_fused split: plain block with a partial buffer only");
   if (c == 128) launch_ff_fused_v<128, 2, 2, 4, false, false, true>(p, zero_page, stream);
   else if (c == 256) launch_ff_fused_v<256, 1, 2, 4, false, false, true>(p, zero_page, stream);
-  else throw std::runtime_error("ff_fused split: C must be 128 or 256");
+  else if (c == 512) launch_ff_fused_v<512, 1, 1, 4, false, false, true>(p, zero_page, stream);
+  else throw std::runtime_error("ff_fused split: C must be 128, 256 or 512");
 }
 inline bool ff_fused_supported(int c, int hidden) { return (c == 128 || c == 256) && hidden % 32 == 0 && hidden <= 2048; }
+// C = 512 (round 6): the plain block and its hidden split only, one workgroup per CU (the two-stage ring of 64 KB chunk blocks + the
+// parameters fill the 160 KB of LDS exactly; a wave keeps 16 pixels: 64 VGPRs of x fragments + 128 accumulator registers).  Every wave
+// reads the whole chunk block from LDS, so a chunk costs 256 KB of LDS reads against 4 x 64 MFMAs: the form is LDS-read-bound and loses
+// to the persistent GEMM pair on the 20 000-token map; it serves the band-sized maps of lat-band ranks through the
+// hidden split (a few dozen pixel tiles, each workgroup streaming 1 / S of W1 | W2).
+inline bool ff_wide_supported(int c, int hidden) { return c == 512 && hidden == 2048; }
 inline bool ff_plain_supported(int c, int hidden) { return ff_fused_supported(c, hidden) || (c == 64 && hidden == 256); }   // C = 64: no to_out / to_qkv variants
 
 // Register allocation decides these kernels: any scratch reload inside the chunk loop waits on vmcnt, i.e. on the weight
@@ -595,6 +602,9 @@ inline void launch_ff_fused(int c, const FFParams& p, const void* zero_page, hip
       case 2: launch_ff_fused_v<256, 2, 2, 2, false, false>(p, zero_page, stream); break;
       default: launch_ff_fused_v<256, 1, 2, 4, false, false>(p, zero_page, stream); break;
     }
+  } else if (c == 512) {   // plain block only (ff_wide_supported)
+    if (pre || post) throw std::runtime_error("ff_fused: C = 512 has the plain block only");
+    launch_ff_fused_v<512, 1, 1, 4, false, false>(p, zero_page, stream);
   } else if (c == 64) {   // plain block only (stage 0 of the 1-degree model: 180 workgroups, one launch instead of ff1 + ff2)
     if (pre || post) throw std::runtime_error("ff_fused: C = 64 has the plain block only");
     launch_ff_fused_v<64, 2, 2, 4, false, false>(p, zero_page, stream);   // (64 pixels per workgroup: +0.5 %, 256: -2 % on the 1-degree model)

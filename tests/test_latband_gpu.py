@@ -449,3 +449,41 @@ def test_two_processes_rccl_two_gpus():
     _close(y, y0[0, :, 0].cpu(), "fp32")
     _close(xn, x0[0, :, 0].cpu(), "fp32")
     assert all(r[5] > 0 for r in res)
+
+
+def test_wide_fused_feedforward_on_band_ranks_and_unsharded(monkeypatch):
+    """Round 6, built / measured / off by default (WX_FF_WIDE): the one-launch FeedForward at C = 512 (`ff_fused_kernel<512, 1, 1, ...>`,
+    reference op credit/models/crossformer.py:195-207).  WX_FF_WIDE=1 runs every FeedForward of a lat-band rank's stage-2 band as the
+    hidden-split fused block + the split-K finish kernel; WX_FF_WIDE=2 also runs the plain block on the unsharded map.  Both must stay
+    inside the bf16 bar against the default engine (the hidden activations are f16 there instead of bf16, as at C = 128 / 256) and against
+    the reference's golden."""
+    cfg = named_config("C3")
+    sd = synth_state_dict(cfg)
+    x = torch.from_numpy(synth_input(cfg)).cuda()
+    ref = WXEngine(cfg, "bf16", 0)
+    ref.load_state_dict(sd)
+    ref.finalize()
+    y0 = ref.forward(x).clone()
+    assert ref.query("ff_wide") == 0
+    del ref
+    monkeypatch.setenv("WX_FF_WIDE", "2")
+    e2 = WXEngine(cfg, "bf16", 0)
+    e2.load_state_dict(sd)
+    e2.finalize()
+    y2 = e2.forward(x).clone()
+    assert e2.query("ff_wide") == 16
+    del e2
+    _close(y2, y0, "bf16")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_C3.npz"))
+    st = int(g["stride"])
+    want = g["y"].astype(np.float64)
+    got = y2[0, :, 0, ::st, ::st].double().cpu().numpy()
+    l2 = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert l2 <= 2e-2, f"wide fused FeedForward vs reference golden: rel-L2 {l2:.3e}"
+    monkeypatch.setenv("WX_FF_WIDE", "1")
+    vb = VirtualBands(cfg, sd, 8, "bf16")
+    y, _, _ = vb.step(x)
+    assert [r.eng.query("ff_wide") for r in vb.ranks] == [16] * 8
+    _close(y, y0, "bf16")
+    del vb
+    torch.cuda.empty_cache()

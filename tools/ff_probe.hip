@@ -10,7 +10,33 @@
 #include "wx_ff.h"
 using namespace wx;
 static void* dalloc(size_t n) { void* p; WX_HIP(hipMalloc(&p, n)); WX_HIP(hipMemset(p, 0, n)); return p; }
+// FF_PXF / FF_OCC (environment): an explicit <C, PXF, OCC, 4> instantiation instead of the library's choice (round 6: one wave per SIMD
+// with 3 - 5 pixel fragments per wave -- every weight fragment read from LDS then feeds PXF MFMAs instead of 1 - 2)
+static int g_pxf = 0, g_occ = 0;
+template <int C, int PXF, int OCC>
+static void launch_v(const FFParams& p, const void* zero, hipStream_t st) {
+  const bool pre = p.o != nullptr, post = p.qkv != nullptr;
+  if (pre && post) launch_ff_fused_v<C, PXF, OCC, 4, true, true>(p, zero, st);
+  else if (pre) launch_ff_fused_v<C, PXF, OCC, 4, true, false>(p, zero, st);
+  else launch_ff_fused_v<C, PXF, OCC, 4, false, false>(p, zero, st);
+}
+static void launch(int C, const FFParams& p, const void* zero, hipStream_t st) {
+  if (!g_pxf) { launch_ff_fused(C, p, zero, st); return; }
+  const int key = C * 100 + g_pxf * 10 + g_occ;
+  switch (key) {
+    case 25621: launch_v<256, 2, 1>(p, zero, st); break;
+    case 25631: launch_v<256, 3, 1>(p, zero, st); break;
+    case 25641: launch_v<256, 4, 1>(p, zero, st); break;
+    case 12832: launch_v<128, 3, 2>(p, zero, st); break;
+    case 12841: launch_v<128, 4, 1>(p, zero, st); break;
+    case 12851: launch_v<128, 5, 1>(p, zero, st); break;
+    case 12861: launch_v<128, 6, 1>(p, zero, st); break;
+    default: printf("no such instantiation\n"); exit(1);
+  }
+}
 int main(int argc, char** argv) {
+  g_pxf = getenv("FF_PXF") ? atoi(getenv("FF_PXF")) : 0;
+  g_occ = getenv("FF_OCC") ? atoi(getenv("FF_OCC")) : 1;
   const int M = atoi(argv[1]), C = atoi(argv[2]), pre = argc > 3 ? atoi(argv[3]) : 0, post = argc > 4 ? atoi(argv[4]) : 0;
   const int hidden = 4 * C;
   std::mt19937 rng(1);
@@ -31,18 +57,18 @@ int main(int argc, char** argv) {
   if (post) { p.qkv = qkv; p.ld_qkv = 3 * C; p.csq = f; p.bq = f; }
   char* zero = (char*)dalloc(256);
   hipStream_t st; WX_HIP(hipStreamCreate(&st));
-  for (int i = 0; i < 3; ++i) launch_ff_fused(C, p, zero, st);
+  for (int i = 0; i < 3; ++i) launch(C, p, zero, st);
   hipEvent_t e0, e1; WX_HIP(hipEventCreate(&e0)); WX_HIP(hipEventCreate(&e1));
   WX_HIP(hipEventRecord(e0, st));
-  for (int i = 0; i < 10; ++i) launch_ff_fused(C, p, zero, st);
+  for (int i = 0; i < 10; ++i) launch(C, p, zero, st);
   WX_HIP(hipEventRecord(e1, st)); WX_HIP(hipStreamSynchronize(st));
   float ms; WX_HIP(hipEventElapsedTime(&ms, e0, e1));
-  const int tile = (C == 128 ? 2 : 1) * 16 * 4;
+  const int tile = (g_pxf ? g_pxf : (C == 128 ? 2 : 1)) * 16 * 4;
   const size_t waves = (size_t)((M + tile - 1) / tile) * 4;
   printf("M=%d C=%d pre=%d post=%d: %.1f us (%zu waves)\n", M, C, pre, post, ms * 1e2, waves);
   unsigned long long* tr = (unsigned long long*)dalloc(waves * 64);
   p.trace = tr;
-  launch_ff_fused(C, p, zero, st);
+  launch(C, p, zero, st);
   WX_HIP(hipStreamSynchronize(st));
   std::vector<unsigned long long> t(waves * 8);
   WX_HIP(hipMemcpy(t.data(), tr, waves * 64, hipMemcpyDeviceToHost));
